@@ -1,0 +1,318 @@
+"""ctypes binding of include/fedd_hip.h -- the same C ABI a reference-side stub would bind
+(INTEGRATION.md).  Host-side plumbing for tests and bench.py only: every numeric call lands in
+the HIP library; if libfedd_hip.so is missing this module raises (no fallback path)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfedd_hip.so")
+
+FORM_LAPLACE, FORM_LAPLACE_VEC, FORM_MASS, FORM_MASS_VEC, FORM_LINELAS = range(5)
+BLOCK_SCALAR, BLOCK_DIAG, BLOCK_FULL = range(3)
+COMBINE_RESTRICTED, COMBINE_AVERAGING, COMBINE_FULL = range(3)
+(T_SYMBOLIC, T_ASSEMBLE, T_RHS, T_DIRICHLET, T_SPMV, T_SCHWARZ_SETUP, T_SCHWARZ_APPLY, T_ORTHO) = range(8)
+TIMER_NAMES = ["symbolic", "assemble", "rhs", "dirichlet", "spmv", "schwarz_setup", "schwarz_apply", "ortho"]
+
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+# name -> argtypes; every symbol declared in include/fedd_hip.h (tests check the two lists agree)
+SIGNATURES = {
+    "fedd_ctx_create": [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int],
+    "fedd_ctx_destroy": [C.c_void_p],
+    "fedd_last_error": [],
+    "fedd_sync": [C.c_void_p],
+    "fedd_nccl_unique_id": [C.c_void_p],
+    "fedd_mesh_structured_sizes": [C.c_int, _ip, _ip, C.c_int, C.c_int, _i64p, _i64p, _i64p, _i64p],
+    "fedd_mesh_structured_build": [C.c_int, _ip, _ip, C.c_int, _f64p, _f64p, C.c_int, C.c_int, _i32p, _f64p,
+                                   _i64p, _i32p, _i64p, _i32p],
+    "fedd_mesh_structured_owner": [C.c_int, _ip, _ip, C.c_int64, _i64p, _i32p],
+    "fedd_mesh_set": [C.c_void_p, C.c_int, C.c_int, C.c_int64, _i32p, C.c_int64, _f64p, _i64p, C.c_int64,
+                      _i64p, _i32p],
+    "fedd_pattern_build": [C.c_void_p, C.c_int, C.c_int, _i64p],
+    "fedd_assemble": [C.c_void_p, C.c_int, _f64p],
+    "fedd_assemble_rhs": [C.c_void_p, C.c_int, _f64p, C.c_int],
+    "fedd_dirichlet": [C.c_void_p, C.c_int, _i32p, _i32p, _f64p],
+    "fedd_csr_sizes": [C.c_void_p, _i64p, _i64p, _i64p],
+    "fedd_csr_get": [C.c_void_p, _i64p, _i32p, _f64p, _i64p],
+    "fedd_rhs_get": [C.c_void_p, _f64p],
+    "fedd_rhs_set": [C.c_void_p, _f64p],
+    "fedd_solution_get": [C.c_void_p, _f64p],
+    "fedd_spmv": [C.c_void_p, _f64p, _f64p],
+    "fedd_spmv_device": [C.c_void_p, C.c_int],
+    "fedd_schwarz_setup": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],
+    "fedd_schwarz_set_target": [C.c_void_p, C.c_int, C.c_double],
+    "fedd_schwarz_apply": [C.c_void_p, _f64p, _f64p],
+    "fedd_schwarz_apply_device": [C.c_void_p, C.c_int],
+    "fedd_schwarz_info": [C.c_void_p, _i64p, _i64p, _i64p],
+    "fedd_gmres": [C.c_void_p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int, _ip, _f64p],
+    "fedd_timing_enable": [C.c_void_p, C.c_int],
+    "fedd_timing_reset": [C.c_void_p],
+    "fedd_timing_get": [C.c_void_p, C.c_int, _f64p, _i64p],
+    "fedd_halo_plan_sizes": [C.c_void_p, _ip, _i64p, _i64p],
+    "fedd_halo_plan_get": [C.c_void_p, _i32p, _i64p, _i32p, _i64p, _i32p],
+    "fedd_halo_set_owners": [C.c_void_p, C.c_int64, _i64p, _i32p],
+    "fedd_halo_requests_sizes": [C.c_void_p, _i64p],
+    "fedd_halo_requests_get": [C.c_void_p, _i64p],
+    "fedd_halo_requests_set": [C.c_void_p, _i64p, _i64p],
+    "fedd_halo_exchange_setup": [C.c_void_p],
+}
+
+_lib = None
+
+
+class FeddError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FeddError("%s is missing: build it with `python -m feddlib_amd.build` "
+                            "(hipcc, gfx950); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        L.fedd_last_error.restype = C.c_char_p
+        L.fedd_ctx_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise FeddError(lib().fedd_last_error().decode())
+
+
+def _p(a, ty):
+    return None if a is None else a.ctypes.data_as(ty)
+
+
+def _ints(v):
+    return (C.c_int * len(v))(*[int(x) for x in v])
+
+
+def _decomp(dim, N):
+    return [int(N)] * dim if np.isscalar(N) else [int(x) for x in N]
+
+
+def structured_mesh(dim, N, M, rank=0, origin=None, size=None, flags_option=1, ghosts=False):
+    """Product-side structured generator (host code in the library).  N, M: ints or per-direction lists."""
+    L = lib()
+    dec, cel = _decomp(dim, N), _decomp(dim, M)
+    ne, nr, nu, ng = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    _chk(L.fedd_mesh_structured_sizes(dim, _ints(dec), _ints(cel), rank, int(ghosts), C.byref(ne), C.byref(nr),
+                                      C.byref(nu), C.byref(ng)))
+    conn = np.zeros((ne.value, dim + 1), dtype=np.int32)
+    xyz = np.zeros((nr.value, dim), dtype=np.float64)
+    gid_rep = np.zeros(nr.value, dtype=np.int64)
+    flag_rep = np.zeros(nr.value, dtype=np.int32)
+    gid_uni = np.zeros(nu.value, dtype=np.int64)
+    flag_uni = np.zeros(nu.value, dtype=np.int32)
+    o = None if origin is None else np.ascontiguousarray(origin, dtype=np.float64)
+    s = None if size is None else np.ascontiguousarray(size, dtype=np.float64)
+    _chk(L.fedd_mesh_structured_build(dim, _ints(dec), _ints(cel), rank, _p(o, _f64p), _p(s, _f64p), flags_option,
+                                      int(ghosts), _p(conn, _i32p), _p(xyz, _f64p), _p(gid_rep, _i64p),
+                                      _p(flag_rep, _i32p), _p(gid_uni, _i64p), _p(flag_uni, _i32p)))
+    return dict(dim=dim, nen=dim + 1, conn=conn, xyz=xyz, gid_rep=gid_rep, flag_rep=flag_rep, gid_uni=gid_uni,
+                flag_uni=flag_uni, n_global=ng.value, decomp=dec, cells=cel, rank=rank)
+
+
+def structured_owner(dim, N, M, gids):
+    dec, cel = _decomp(dim, N), _decomp(dim, M)
+    g = np.ascontiguousarray(gids, dtype=np.int64)
+    out = np.zeros(g.shape[0], dtype=np.int32)
+    _chk(lib().fedd_mesh_structured_owner(dim, _ints(dec), _ints(cel), g.shape[0], _p(g, _i64p), _p(out, _i32p)))
+    return out
+
+
+def nccl_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    _chk(lib().fedd_nccl_unique_id(buf))
+    return buf.raw
+
+
+class Context:
+    """One per GPU / rank.  device < 0 gives a host-only context (numbering and halo planning only)."""
+
+    def __init__(self, device=0, rank=0, nranks=1, nccl_id: bytes | None = None):
+        self._L = lib()
+        h = C.c_void_p()
+        idbuf = C.create_string_buffer(nccl_id, 128) if nccl_id is not None else None
+        _chk(self._L.fedd_ctx_create(C.byref(h), device, idbuf, rank, nranks))
+        self._h = h
+        self.rank, self.nranks = rank, nranks
+        self.dofs = 1
+
+    def close(self):
+        if self._h:
+            self._L.fedd_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _chk(self._L.fedd_sync(self._h))
+
+    def mesh_set(self, dim, conn, xyz, gid_rep, gid_uni, flag_uni):
+        conn = np.ascontiguousarray(conn, dtype=np.int32)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        gid_rep = np.ascontiguousarray(gid_rep, dtype=np.int64)
+        gid_uni = np.ascontiguousarray(gid_uni, dtype=np.int64)
+        flag_uni = None if flag_uni is None else np.ascontiguousarray(flag_uni, dtype=np.int32)
+        _chk(self._L.fedd_mesh_set(self._h, dim, conn.shape[1], conn.shape[0], _p(conn, _i32p), xyz.shape[0],
+                                   _p(xyz, _f64p), _p(gid_rep, _i64p), gid_uni.shape[0], _p(gid_uni, _i64p),
+                                   _p(flag_uni, _i32p)))
+        self.n_own = gid_uni.shape[0]
+
+    def mesh_set_dict(self, m):
+        self.mesh_set(m["dim"], m["conn"], m["xyz"], m["gid_rep"], m["gid_uni"], m["flag_uni"])
+
+    def pattern_build(self, dofs=1, block_mode=BLOCK_SCALAR) -> int:
+        nnz = C.c_int64()
+        _chk(self._L.fedd_pattern_build(self._h, dofs, block_mode, C.byref(nnz)))
+        self.dofs = dofs
+        return nnz.value
+
+    def assemble(self, form, params=None):
+        p = None if params is None else np.ascontiguousarray(params, dtype=np.float64)
+        _chk(self._L.fedd_assemble(self._h, form, _p(p, _f64p)))
+
+    def assemble_rhs(self, f_const, extra_degree=0):
+        f = np.ascontiguousarray(np.atleast_1d(f_const), dtype=np.float64)
+        _chk(self._L.fedd_assemble_rhs(self._h, self.dofs, _p(f, _f64p), extra_degree))
+
+    def dirichlet(self, flags, values=None, comp_mask=None):
+        fl = np.ascontiguousarray(flags, dtype=np.int32)
+        n = fl.shape[0]
+        v = np.zeros(n * self.dofs) if values is None else np.ascontiguousarray(values, dtype=np.float64).ravel()
+        m = None if comp_mask is None else np.ascontiguousarray(comp_mask, dtype=np.int32).ravel()
+        _chk(self._L.fedd_dirichlet(self._h, n, _p(fl, _i32p), _p(m, _i32p), _p(v, _f64p)))
+
+    def csr_sizes(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _chk(self._L.fedd_csr_sizes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def csr_get(self):
+        nr, nc, nnz = self.csr_sizes()
+        rowptr = np.zeros(nr + 1, dtype=np.int64)
+        col = np.zeros(nnz, dtype=np.int32)
+        val = np.zeros(nnz, dtype=np.float64)
+        gid = np.zeros(nc, dtype=np.int64)
+        _chk(self._L.fedd_csr_get(self._h, _p(rowptr, _i64p), _p(col, _i32p), _p(val, _f64p), _p(gid, _i64p)))
+        return rowptr, col, val, gid
+
+    def rhs_get(self):
+        nr = self.csr_sizes()[0]
+        out = np.zeros(nr)
+        _chk(self._L.fedd_rhs_get(self._h, _p(out, _f64p)))
+        return out
+
+    def rhs_set(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        _chk(self._L.fedd_rhs_set(self._h, _p(b, _f64p)))
+
+    def solution_get(self):
+        nr = self.csr_sizes()[0]
+        out = np.zeros(nr)
+        _chk(self._L.fedd_solution_get(self._h, _p(out, _f64p)))
+        return out
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(x)
+        _chk(self._L.fedd_spmv(self._h, _p(x, _f64p), _p(y, _f64p)))
+        return y
+
+    def spmv_device(self, reps):
+        _chk(self._L.fedd_spmv_device(self._h, reps))
+
+    def schwarz_set_target(self, target, scale=1.0):
+        _chk(self._L.fedd_schwarz_set_target(self._h, target, scale))
+
+    def schwarz_setup(self, overlap=1, combine=COMBINE_RESTRICTED, two_level=0, coarse_kind=0):
+        _chk(self._L.fedd_schwarz_setup(self._h, overlap, combine, two_level, coarse_kind))
+
+    def schwarz_info(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _chk(self._L.fedd_schwarz_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(n_subdomains=a.value, max_size=b.value, inverse_bytes=c.value)
+
+    def schwarz_apply(self, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        _chk(self._L.fedd_schwarz_apply(self._h, _p(r, _f64p), _p(z, _f64p)))
+        return z
+
+    def schwarz_apply_device(self, reps):
+        _chk(self._L.fedd_schwarz_apply_device(self._h, reps))
+
+    def gmres(self, b=None, rtol=1e-8, max_it=100, restart=100, use_prec=True, want_x=True):
+        bb = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        nr = self.csr_sizes()[0]
+        x = np.zeros(nr) if want_x else None
+        its, rel = C.c_int(), C.c_double()
+        _chk(self._L.fedd_gmres(self._h, _p(bb, _f64p), _p(x, _f64p), rtol, max_it, restart, int(use_prec),
+                                C.byref(its), C.byref(rel)))
+        return x, its.value, rel.value
+
+    def timing_enable(self, on=True):
+        _chk(self._L.fedd_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        _chk(self._L.fedd_timing_reset(self._h))
+
+    def timing_get(self):
+        out = {}
+        for i, name in enumerate(TIMER_NAMES):
+            ms, n = C.c_double(), C.c_int64()
+            _chk(self._L.fedd_timing_get(self._h, i, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    # ---- halo plan ----
+    def halo_set_owners(self, gid_rep, owner_rep):
+        g = np.ascontiguousarray(gid_rep, dtype=np.int64)
+        o = np.ascontiguousarray(owner_rep, dtype=np.int32)
+        _chk(self._L.fedd_halo_set_owners(self._h, g.shape[0], _p(g, _i64p), _p(o, _i32p)))
+
+    def halo_requests(self):
+        cnt = np.zeros(self.nranks, dtype=np.int64)
+        _chk(self._L.fedd_halo_requests_sizes(self._h, _p(cnt, _i64p)))
+        g = np.zeros(int(cnt.sum()), dtype=np.int64)
+        _chk(self._L.fedd_halo_requests_get(self._h, _p(g, _i64p)))
+        return cnt, g
+
+    def halo_requests_set(self, count_from_rank, gids):
+        cnt = np.ascontiguousarray(count_from_rank, dtype=np.int64)
+        g = np.ascontiguousarray(gids, dtype=np.int64)
+        _chk(self._L.fedd_halo_requests_set(self._h, _p(cnt, _i64p), _p(g, _i64p)))
+
+    def halo_exchange_setup(self):
+        _chk(self._L.fedd_halo_exchange_setup(self._h))
+
+    def halo_plan(self):
+        npeers, ns, nr = C.c_int(), C.c_int64(), C.c_int64()
+        _chk(self._L.fedd_halo_plan_sizes(self._h, C.byref(npeers), C.byref(ns), C.byref(nr)))
+        peers = np.zeros(npeers.value, dtype=np.int32)
+        sp = np.zeros(npeers.value + 1, dtype=np.int64)
+        rp = np.zeros(npeers.value + 1, dtype=np.int64)
+        sl = np.zeros(ns.value, dtype=np.int32)
+        rl = np.zeros(nr.value, dtype=np.int32)
+        _chk(self._L.fedd_halo_plan_get(self._h, _p(peers, _i32p), _p(sp, _i64p), _p(sl, _i32p), _p(rp, _i64p),
+                                        _p(rl, _i32p)))
+        return dict(peers=peers, send_ptr=sp, send_lid=sl, recv_ptr=rp, recv_lid=rl)

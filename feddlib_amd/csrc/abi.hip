@@ -1,0 +1,454 @@
+// extern "C" entry points: context, mesh upload, read-back, timing.  gfx950 only.
+#include "fedd_internal.hpp"
+#include <rccl/rccl.h>
+#include <algorithm>
+#include <cstring>
+#include <unordered_map>
+
+namespace fedd {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int timing_flush(fedd_ctx* c) {
+    for (int t = 0; t < FEDD_T_COUNT; ++t) {
+        auto& s = c->timers[t];
+        for (auto& pr : s.pending) {
+            float ms = 0.f;
+            FEDD_HIP(hipEventSynchronize(pr.second));
+            FEDD_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+            s.total_ms += ms;
+            s.launches += 1;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        s.pending.clear();
+    }
+    return 0;
+}
+
+}  // namespace fedd
+
+using namespace fedd;
+
+#define NEED_DEVICE(c)                                                                           \
+    FEDD_CHECK((c) && (c)->device >= 0,                                                          \
+               "this call needs a GPU context (fedd_ctx_create with device >= 0); there is no CPU fallback")
+
+extern "C" const char* fedd_last_error(void) { return g_err.c_str(); }
+
+extern "C" int fedd_nccl_unique_id(void* id128) {
+    FEDD_CHECK(id128, "fedd_nccl_unique_id: null output");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    FEDD_CHECK(r == ncclSuccess, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    memcpy(id128, &id, 128);
+    return 0;
+}
+
+extern "C" int fedd_ctx_create(fedd_ctx** out, int device, const void* nccl_unique_id, int rank, int nranks) {
+    FEDD_CHECK(out, "fedd_ctx_create: null output pointer");
+    FEDD_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "fedd_ctx_create: bad rank %d of %d", rank, nranks);
+    fedd_ctx* c = new fedd_ctx();
+    c->device = device;
+    c->rank = rank;
+    c->nranks = nranks;
+    if (device >= 0) {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) {
+            set_error("fedd_ctx_create: no HIP device visible (%s); this library has no CPU path",
+                      hipGetErrorString(e));
+            delete c;
+            return 1;
+        }
+        if (device >= ndev) {
+            set_error("fedd_ctx_create: device %d requested, %d visible", device, ndev);
+            delete c;
+            return 1;
+        }
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+            set_error("fedd_ctx_create: cannot initialise device %d", device);
+            delete c;
+            return 1;
+        }
+        if (hipHostMalloc((void**)&c->h_pinned, 4096 * sizeof(double)) != hipSuccess) {
+            set_error("fedd_ctx_create: pinned allocation failed");
+            delete c;
+            return 1;
+        }
+        if (nranks > 1) {
+            if (!nccl_unique_id) {
+                set_error("fedd_ctx_create: nranks > 1 needs the shared ncclUniqueId");
+                delete c;
+                return 1;
+            }
+            ncclUniqueId id;
+            memcpy(&id, nccl_unique_id, 128);
+            ncclComm_t comm;
+            ncclResult_t r = ncclCommInitRank(&comm, nranks, id, rank);
+            if (r != ncclSuccess) {
+                set_error("ncclCommInitRank: %s", ncclGetErrorString(r));
+                delete c;
+                return 1;
+            }
+            c->comm = comm;
+        }
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void fedd_ctx_destroy(fedd_ctx* c) {
+    if (!c) return;
+    if (c->device >= 0) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)timing_flush(c);
+        if (c->comm) ncclCommDestroy((ncclComm_t)c->comm);
+        fedd::DevBuf<int32_t>* ib[] = {&c->d_conn, &c->d_flag, &c->d_n2e_ptr, &c->d_n2e, &c->d_rowptr,
+                                       &c->d_colind, &c->d_isdir, &c->d_node_bin, &c->d_bin_ptr,
+                                       &c->d_bin_nodes, &c->d_sub_n, &c->d_sub_nown, &c->d_sub_dofs,
+                                       &c->d_itmp0, &c->d_itmp1, &c->d_itmp2, &c->d_flags, &c->halo.d_send_lid};
+        for (auto* b : ib) b->release();
+        fedd::DevBuf<double>* db[] = {&c->d_xyz, &c->d_val, &c->d_rhs, &c->d_x, &c->d_xcol, &c->d_ycol,
+                                      &c->d_inv, &c->d_mult, &c->d_V, &c->d_Z, &c->d_w, &c->d_part,
+                                      &c->d_small, &c->d_dtmp0, &c->halo.d_send_buf, &c->halo.d_recv_buf};
+        for (auto* b : db) b->release();
+        c->d_inv_ptr.release();
+        for (auto& b : c->d_scan) b.release();
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+extern "C" int fedd_sync(fedd_ctx* c) {
+    NEED_DEVICE(c);
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int fedd_mesh_set(fedd_ctx* c, int dim, int nen, int64_t n_elem, const int32_t* conn,
+                             int64_t n_rep, const double* xyz, const int64_t* gid_rep, int64_t n_uni,
+                             const int64_t* gid_uni, const int32_t* bcflag_uni) {
+    FEDD_CHECK(c, "fedd_mesh_set: null context");
+    FEDD_CHECK(dim == 2 || dim == 3, "fedd_mesh_set: dimension must be 2 or 3");
+    const bool okel = (dim == 2 && (nen == 3 || nen == 6)) || (dim == 3 && (nen == 4 || nen == 10));
+    FEDD_CHECK(okel, "fedd_mesh_set: unsupported element with %d nodes in %dD (P1/P2 simplices only)", nen, dim);
+    FEDD_CHECK(n_elem >= 0 && n_rep >= 0 && n_uni >= 0, "fedd_mesh_set: negative size");
+    FEDD_CHECK(n_rep < (int64_t)1 << 31 && n_elem * nen < (int64_t)1 << 31,
+               "fedd_mesh_set: local mesh too large for 32-bit local ordinals");
+    FEDD_CHECK((n_elem == 0 || conn) && (n_rep == 0 || (xyz && gid_rep)) && (n_uni == 0 || gid_uni),
+               "fedd_mesh_set: null array");
+    c->dim = dim;
+    c->nen = nen;
+    c->n_elem = n_elem;
+    c->n_own = n_uni;
+    c->have_adj = c->have_pattern = c->have_schwarz = false;
+    c->halo = fedd::HaloPlan();
+
+    // column-local numbering: owned nodes in unique-map order, then ghosts sorted by global id
+    std::unordered_map<int64_t, int32_t> own;
+    own.reserve((size_t)n_uni * 2);
+    for (int64_t i = 0; i < n_uni; ++i) {
+        auto ins = own.emplace(gid_uni[i], (int32_t)i);
+        FEDD_CHECK(ins.second, "fedd_mesh_set: global id %lld listed twice in the unique map", (long long)gid_uni[i]);
+    }
+    std::vector<int32_t> col_of_rep((size_t)n_rep, -1);
+    std::vector<std::pair<int64_t, int32_t>> ghosts;
+    std::vector<char> seen((size_t)n_uni, 0);
+    for (int64_t i = 0; i < n_rep; ++i) {
+        auto it = own.find(gid_rep[i]);
+        if (it != own.end()) {
+            col_of_rep[i] = it->second;
+            seen[it->second] = 1;
+        } else {
+            ghosts.emplace_back(gid_rep[i], (int32_t)i);
+        }
+    }
+    for (int64_t i = 0; i < n_uni; ++i)
+        FEDD_CHECK(seen[i], "fedd_mesh_set: unique node %lld is missing from the repeated map", (long long)gid_uni[i]);
+    std::sort(ghosts.begin(), ghosts.end());
+    int64_t ng = 0;
+    std::vector<int64_t> ghost_gid;
+    for (size_t k = 0; k < ghosts.size(); ++k) {
+        if (k == 0 || ghosts[k].first != ghosts[k - 1].first) {
+            ghost_gid.push_back(ghosts[k].first);
+            ++ng;
+        }
+        col_of_rep[ghosts[k].second] = (int32_t)(n_uni + ng - 1);
+    }
+    c->n_node = n_uni + ng;
+    c->h_node_gid.assign(gid_uni, gid_uni + n_uni);
+    c->h_node_gid.insert(c->h_node_gid.end(), ghost_gid.begin(), ghost_gid.end());
+
+    std::vector<int32_t> conn2((size_t)(n_elem * nen));
+    for (int64_t k = 0; k < n_elem * nen; ++k) {
+        FEDD_CHECK(conn[k] >= 0 && conn[k] < n_rep, "fedd_mesh_set: element node id %d out of range", conn[k]);
+        conn2[k] = col_of_rep[conn[k]];
+    }
+    std::vector<double> xyz2((size_t)(c->n_node * dim));
+    for (int64_t i = 0; i < n_rep; ++i)
+        for (int d = 0; d < dim; ++d) xyz2[(size_t)col_of_rep[i] * dim + d] = xyz[i * dim + d];
+
+    if (c->device < 0) return 0;  // host-only context: numbering only
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_TRY(c->d_conn.ensure(conn2.size()));
+    FEDD_TRY(c->d_xyz.ensure(xyz2.size()));
+    FEDD_TRY(c->d_flag.ensure((size_t)n_uni));
+    FEDD_HIP(hipMemcpyAsync(c->d_conn.p, conn2.data(), conn2.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    FEDD_HIP(hipMemcpyAsync(c->d_xyz.p, xyz2.data(), xyz2.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (bcflag_uni)
+        FEDD_HIP(hipMemcpyAsync(c->d_flag.p, bcflag_uni, (size_t)n_uni * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    else
+        FEDD_HIP(hipMemsetAsync(c->d_flag.p, 0, (size_t)n_uni * sizeof(int32_t), c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int fedd_pattern_build(fedd_ctx* c, int dofs_per_node, int block_mode, int64_t* nnz_out) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->n_node > 0, "fedd_pattern_build: call fedd_mesh_set first");
+    FEDD_CHECK(dofs_per_node >= 1 && dofs_per_node <= MAX_DOFS, "fedd_pattern_build: dofs_per_node %d", dofs_per_node);
+    FEDD_CHECK(block_mode >= 0 && block_mode <= 2, "fedd_pattern_build: block mode %d", block_mode);
+    FEDD_CHECK((dofs_per_node == 1) == (block_mode == FEDD_BLOCK_SCALAR),
+               "fedd_pattern_build: block mode SCALAR <=> one dof per node");
+    FEDD_HIP(hipSetDevice(c->device));
+    {
+        ScopedTimer t(c, FEDD_T_SYMBOLIC);
+        if (!c->have_adj) FEDD_TRY(build_adjacency(c));
+        FEDD_TRY(build_pattern(c, dofs_per_node, block_mode));
+    }
+    if (nnz_out) *nnz_out = c->nnz;
+    return 0;
+}
+
+extern "C" int fedd_assemble(fedd_ctx* c, int form, const double* params) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_assemble: call fedd_pattern_build first");
+    FEDD_HIP(hipSetDevice(c->device));
+    return assemble_matrix(c, form, params);
+}
+
+extern "C" int fedd_assemble_rhs(fedd_ctx* c, int dofs_per_node, const double* f_const, int extra_degree) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_assemble_rhs: call fedd_pattern_build first");
+    FEDD_CHECK(dofs_per_node == c->dofs, "fedd_assemble_rhs: dofs_per_node %d differs from the pattern's %d", dofs_per_node, c->dofs);
+    FEDD_CHECK(f_const, "fedd_assemble_rhs: null f_const");
+    FEDD_HIP(hipSetDevice(c->device));
+    return assemble_rhs(c, dofs_per_node, f_const, extra_degree);
+}
+
+extern "C" int fedd_dirichlet(fedd_ctx* c, int n_bc, const int32_t* flags, const int32_t* comp_mask, const double* values) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_dirichlet: call fedd_pattern_build first");
+    FEDD_CHECK(n_bc >= 0 && n_bc <= MAX_BC, "fedd_dirichlet: at most %d boundary conditions", MAX_BC);
+    FEDD_CHECK(n_bc == 0 || (flags && values), "fedd_dirichlet: null array");
+    FEDD_HIP(hipSetDevice(c->device));
+    return apply_dirichlet(c, n_bc, flags, comp_mask, values);
+}
+
+extern "C" int fedd_csr_sizes(fedd_ctx* c, int64_t* n_rows, int64_t* n_cols, int64_t* nnz) {
+    FEDD_CHECK(c && c->have_pattern, "fedd_csr_sizes: no pattern");
+    if (n_rows) *n_rows = c->n_rows;
+    if (n_cols) *n_cols = c->n_cols;
+    if (nnz) *nnz = c->nnz;
+    return 0;
+}
+
+extern "C" int fedd_csr_get(fedd_ctx* c, int64_t* rowptr, int32_t* colind, double* val, int64_t* col_gid) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_csr_get: no pattern");
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    if (rowptr) {
+        std::vector<int32_t> rp((size_t)c->n_rows + 1);
+        FEDD_HIP(hipMemcpy(rp.data(), c->d_rowptr.p, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < rp.size(); ++i) rowptr[i] = rp[i];
+    }
+    if (colind) FEDD_HIP(hipMemcpy(colind, c->d_colind.p, (size_t)c->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (val) FEDD_HIP(hipMemcpy(val, c->d_val.p, (size_t)c->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    if (col_gid)
+        for (int64_t n = 0; n < c->n_node; ++n)
+            for (int d = 0; d < c->dofs; ++d) col_gid[n * c->dofs + d] = c->h_node_gid[n] * c->dofs + d;
+    return 0;
+}
+
+extern "C" int fedd_rhs_get(fedd_ctx* c, double* rhs) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern && rhs, "fedd_rhs_get: no pattern / null pointer");
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    FEDD_HIP(hipMemcpy(rhs, c->d_rhs.p, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int fedd_rhs_set(fedd_ctx* c, const double* rhs) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern && rhs, "fedd_rhs_set: no pattern / null pointer");
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_HIP(hipMemcpy(c->d_rhs.p, rhs, (size_t)c->n_rows * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int fedd_solution_get(fedd_ctx* c, double* x) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern && x, "fedd_solution_get: no pattern / null pointer");
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    FEDD_HIP(hipMemcpy(x, c->d_x.p, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int fedd_spmv(fedd_ctx* c, const double* x_owned, double* y_owned) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern && x_owned && y_owned, "fedd_spmv: no matrix / null pointer");
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_TRY(c->d_dtmp0.ensure((size_t)c->n_rows * 2));
+    double* dx = c->d_dtmp0.p;
+    double* dy = dx + c->n_rows;
+    FEDD_HIP(hipMemcpyAsync(dx, x_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    FEDD_TRY(spmv_owned(c, dx, dy));
+    FEDD_HIP(hipMemcpyAsync(y_owned, dy, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int fedd_spmv_device(fedd_ctx* c, int reps) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_spmv_device: no matrix");
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_TRY(c->d_dtmp0.ensure((size_t)c->n_rows * 2));
+    double* dx = c->d_dtmp0.p;
+    double* dy = dx + c->n_rows;
+    FEDD_HIP(hipMemcpyAsync(dx, c->d_rhs.p, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    for (int r = 0; r < reps; ++r) FEDD_TRY(spmv_owned(c, dx, dy));
+    return 0;
+}
+
+extern "C" int fedd_schwarz_set_target(fedd_ctx* c, int target_nodes, double scale) {
+    FEDD_CHECK(c, "null context");
+    FEDD_CHECK(target_nodes >= 1 && scale > 0, "fedd_schwarz_set_target: target %d scale %g", target_nodes, scale);
+    c->sw_target = target_nodes;
+    c->sw_scale = scale;
+    return 0;
+}
+
+extern "C" int fedd_schwarz_setup(fedd_ctx* c, int overlap, int combine, int two_level, int coarse_kind) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_schwarz_setup: assemble the matrix first");
+    FEDD_CHECK(overlap >= 0 && overlap <= 4, "fedd_schwarz_setup: overlap %d", overlap);
+    FEDD_CHECK(combine >= 0 && combine <= 2, "fedd_schwarz_setup: combine mode %d", combine);
+    FEDD_CHECK(two_level == 0, "fedd_schwarz_setup: the GDSW coarse level (coarse_kind %d) is not built yet", coarse_kind);
+    FEDD_HIP(hipSetDevice(c->device));
+    c->sw_overlap = overlap;
+    c->sw_combine = combine;
+    return schwarz_setup(c);
+}
+
+extern "C" int fedd_schwarz_info(fedd_ctx* c, int64_t* n_sub, int64_t* max_size, int64_t* inverse_bytes) {
+    FEDD_CHECK(c && c->have_schwarz, "fedd_schwarz_info: no preconditioner");
+    if (n_sub) *n_sub = c->sw_nsub;
+    if (max_size) *max_size = c->sw_max_size;
+    if (inverse_bytes) *inverse_bytes = c->sw_inv_elems * (int64_t)sizeof(double);
+    return 0;
+}
+
+extern "C" int fedd_schwarz_apply(fedd_ctx* c, const double* r_owned, double* z_owned) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_schwarz && r_owned && z_owned, "fedd_schwarz_apply: no preconditioner / null pointer");
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_TRY(c->d_dtmp0.ensure((size_t)c->n_rows * 2));
+    double* dr = c->d_dtmp0.p;
+    double* dz = dr + c->n_rows;
+    FEDD_HIP(hipMemcpyAsync(dr, r_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    FEDD_TRY(schwarz_apply(c, dr, dz));
+    FEDD_HIP(hipMemcpyAsync(z_owned, dz, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int fedd_schwarz_apply_device(fedd_ctx* c, int reps) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_schwarz, "fedd_schwarz_apply_device: no preconditioner");
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_TRY(c->d_dtmp0.ensure((size_t)c->n_rows * 2));
+    double* dr = c->d_dtmp0.p;
+    double* dz = dr + c->n_rows;
+    FEDD_HIP(hipMemcpyAsync(dr, c->d_rhs.p, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    for (int r = 0; r < reps; ++r) FEDD_TRY(schwarz_apply(c, dr, dz));
+    return 0;
+}
+
+extern "C" int fedd_gmres(fedd_ctx* c, const double* b_owned, double* x_owned, double rtol, int max_it,
+                          int restart, int use_prec, int* its_out, double* relres_out) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_gmres: no matrix");
+    FEDD_CHECK(!use_prec || c->have_schwarz, "fedd_gmres: preconditioner requested but fedd_schwarz_setup was not called");
+    FEDD_CHECK(rtol > 0 && max_it >= 1 && restart >= 1 && restart <= 1000, "fedd_gmres: bad rtol/max_it/restart");
+    FEDD_HIP(hipSetDevice(c->device));
+    if (b_owned) FEDD_HIP(hipMemcpyAsync(c->d_rhs.p, b_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    FEDD_TRY(gmres_solve(c, c->d_rhs.p, c->d_x.p, rtol, max_it, restart, use_prec, its_out, relres_out));
+    if (x_owned) {
+        FEDD_HIP(hipMemcpyAsync(x_owned, c->d_x.p, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+extern "C" int fedd_timing_enable(fedd_ctx* c, int on) {
+    NEED_DEVICE(c);
+    c->timing = on != 0;
+    return 0;
+}
+
+extern "C" int fedd_timing_reset(fedd_ctx* c) {
+    NEED_DEVICE(c);
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    FEDD_TRY(timing_flush(c));
+    for (int t = 0; t < FEDD_T_COUNT; ++t) {
+        c->timers[t].total_ms = 0;
+        c->timers[t].launches = 0;
+    }
+    return 0;
+}
+
+extern "C" int fedd_timing_get(fedd_ctx* c, int timer, double* total_ms, int64_t* launches) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(timer >= 0 && timer < FEDD_T_COUNT, "fedd_timing_get: timer %d", timer);
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    FEDD_TRY(timing_flush(c));
+    if (total_ms) *total_ms = c->timers[timer].total_ms;
+    if (launches) *launches = c->timers[timer].launches;
+    return 0;
+}
+
+extern "C" int fedd_halo_plan_sizes(fedd_ctx* c, int* n_peers, int64_t* n_send_total, int64_t* n_recv_total) {
+    FEDD_CHECK(c, "null context");
+    if (n_peers) *n_peers = (int)c->halo.peers.size();
+    if (n_send_total) *n_send_total = (int64_t)c->halo.send_lid.size();
+    if (n_recv_total) *n_recv_total = (int64_t)c->halo.recv_lid.size();
+    return 0;
+}
+
+extern "C" int fedd_halo_plan_get(fedd_ctx* c, int32_t* peers, int64_t* send_ptr, int32_t* send_lid,
+                                  int64_t* recv_ptr, int32_t* recv_lid) {
+    FEDD_CHECK(c, "null context");
+    const auto& h = c->halo;
+    if (peers) std::copy(h.peers.begin(), h.peers.end(), peers);
+    if (send_ptr) std::copy(h.send_ptr.begin(), h.send_ptr.end(), send_ptr);
+    if (send_lid) std::copy(h.send_lid.begin(), h.send_lid.end(), send_lid);
+    if (recv_ptr) std::copy(h.recv_ptr.begin(), h.recv_ptr.end(), recv_ptr);
+    if (recv_lid) std::copy(h.recv_lid.begin(), h.recv_lid.end(), recv_lid);
+    return 0;
+}

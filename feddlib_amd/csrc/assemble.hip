@@ -1,0 +1,390 @@
+// Numeric FE assembly on the device, gather formulation (no atomics, bitwise reproducible):
+// one lane per owned dof row walks the (element, local index) list of its node, evaluates the
+// row of each incident element's local matrix and adds it into an LDS-resident copy of the CSR
+// row; the row is written to HBM once.
+//
+// Arithmetic follows (not copies) the reference's element loops:
+//   FE::assemblyLaplace          feddlib/core/FE/FE_def.hpp:604-667
+//   FE::assemblyLaplaceVecField  feddlib/core/FE/FE_def.hpp:670-734
+//   FE::assemblyMass             feddlib/core/FE/FE_def.hpp:454-524
+//   FE::assemblyLinElasXDim      feddlib/core/FE/FE_def.hpp:2739-3040 (epsilonTensor :4931-4944)
+//   FE::assemblyRHS              feddlib/core/FE/FE_def.hpp:4694-4766
+//   FE::buildTransformation      feddlib/core/FE/FE_def.hpp:5342-5357
+//   SmallMatrix::computeInverse  feddlib/core/General/SmallMatrix.hpp:306-357
+//   FE::applyBTinv               feddlib/core/FE/FE_def.hpp:83-96
+//   BCBuilder::setSystem/setRHS  feddlib/core/General/BCBuilder_def.hpp:589-707, 93-170
+// Quadrature points/weights and reference basis values/gradients are staged in LDS once per
+// workgroup.
+#include "fedd_internal.hpp"
+#include <algorithm>
+
+namespace fedd {
+namespace {
+
+enum { F_LAPLACE = 0, F_MASS = 1, F_LINELAS = 2 };
+
+struct AsmArgs {
+    const int32_t* conn;
+    const int32_t* n2e_ptr;
+    const int32_t* n2e;
+    const int32_t* rowptr;
+    const int32_t* colind;
+    const double* xyz;
+    double* val;
+    const double* tab;  // w[nq] | phi[nq*nen] | dphi[nq*nen*dim]
+    int nq;
+    int32_t n_rows;
+    int dofs;
+    double p0, p1;  // LINELAS: lambda, mu
+};
+
+__device__ __forceinline__ int find_slot(const int32_t* __restrict__ cols, int n, int32_t col) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cols[mid] < col) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// affine map of a simplex: B[i][j] = x_{j+1}[i] - x_0[i]; returns det, fills Binv = adj(B)/det
+template <int DIM>
+__device__ __forceinline__ double affine(const double (&X)[DIM + 1][DIM], double (&Binv)[DIM][DIM]) {
+    double B[DIM][DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j)
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) B[i][j] = X[j + 1][i] - X[0][i];
+    if constexpr (DIM == 2) {
+        const double det = B[0][0] * B[1][1] - B[1][0] * B[0][1];
+        Binv[0][0] = B[1][1] / det;
+        Binv[0][1] = (-B[0][1]) / det;
+        Binv[1][0] = (-B[1][0]) / det;
+        Binv[1][1] = B[0][0] / det;
+        return det;
+    } else {
+        const double det = B[0][0] * B[1][1] * B[2][2] + B[0][1] * B[1][2] * B[2][0] + B[0][2] * B[1][0] * B[2][1] -
+                           B[2][0] * B[1][1] * B[0][2] - B[2][1] * B[1][2] * B[0][0] - B[2][2] * B[1][0] * B[0][1];
+        Binv[0][0] = (B[1][1] * B[2][2] - B[1][2] * B[2][1]) / det;
+        Binv[0][1] = (B[0][2] * B[2][1] - B[0][1] * B[2][2]) / det;
+        Binv[0][2] = (B[0][1] * B[1][2] - B[0][2] * B[1][1]) / det;
+        Binv[1][0] = (B[1][2] * B[2][0] - B[1][0] * B[2][2]) / det;
+        Binv[1][1] = (B[0][0] * B[2][2] - B[0][2] * B[2][0]) / det;
+        Binv[1][2] = (B[0][2] * B[1][0] - B[0][0] * B[1][2]) / det;
+        Binv[2][0] = (B[1][0] * B[2][1] - B[1][1] * B[2][0]) / det;
+        Binv[2][1] = (B[0][1] * B[2][0] - B[0][0] * B[2][1]) / det;
+        Binv[2][2] = (B[0][0] * B[1][1] - B[0][1] * B[1][0]) / det;
+        return det;
+    }
+}
+
+template <int DIM>
+__device__ __forceinline__ double affine_det(const double (&X)[DIM + 1][DIM]) {
+    double B[DIM][DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j)
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) B[i][j] = X[j + 1][i] - X[0][i];
+    if constexpr (DIM == 2) {
+        return B[0][0] * B[1][1] - B[1][0] * B[0][1];
+    } else {
+        return B[0][0] * B[1][1] * B[2][2] + B[0][1] * B[1][2] * B[2][0] + B[0][2] * B[1][0] * B[2][1] -
+               B[2][0] * B[1][1] * B[0][2] - B[2][1] * B[1][2] * B[0][0] - B[2][2] * B[1][0] * B[0][1];
+    }
+}
+
+// transformed gradient of basis function i at quadrature point q: g[d] = sum_d2 dphi[q][i][d2] Binv[d2][d]
+template <int DIM, int NEN>
+__device__ __forceinline__ void grad_t(const double* __restrict__ s_dphi, int q, int i, const double (&Binv)[DIM][DIM],
+                                       double (&g)[DIM]) {
+    const double* dp = s_dphi + (q * NEN + i) * DIM;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        double s = 0.0;
+#pragma unroll
+        for (int d2 = 0; d2 < DIM; ++d2) s += dp[d2] * Binv[d2][d];
+        g[d] = s;
+    }
+}
+
+template <int DIM, int NEN, int FORM>
+__global__ void k_assemble(AsmArgs a) {
+    extern __shared__ double sm[];
+    const int nq = a.nq;
+    double* s_w = sm;
+    double* s_phi = s_w + nq;
+    double* s_dphi = s_phi + nq * NEN;
+    double* acc = s_dphi + nq * NEN * DIM;
+    const int tid = threadIdx.x;
+    const int BS = blockDim.x;
+    const int ntab = nq * (1 + NEN + NEN * DIM);
+    for (int i = tid; i < ntab; i += BS) sm[i] = a.tab[i];
+    __syncthreads();
+    const int32_t row = blockIdx.x * BS + tid;
+    if (row >= a.n_rows) return;
+    const int dofs = a.dofs;
+    const int32_t node = row / dofs;
+    const int comp = row - node * dofs;
+    const int32_t rs = a.rowptr[row];
+    const int rn = a.rowptr[row + 1] - rs;
+    const int32_t* __restrict__ cols = a.colind + rs;
+    for (int s = 0; s < rn; ++s) acc[s * BS + tid] = 0.0;
+
+    for (int32_t p = a.n2e_ptr[node]; p < a.n2e_ptr[node + 1]; ++p) {
+        const int32_t idx = a.n2e[p];
+        const int32_t e = idx / NEN;
+        const int li = idx - e * NEN;
+        int32_t nd[NEN];
+#pragma unroll
+        for (int j = 0; j < NEN; ++j) nd[j] = a.conn[(int64_t)e * NEN + j];
+        double X[DIM + 1][DIM];
+#pragma unroll
+        for (int v = 0; v <= DIM; ++v)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) X[v][d] = a.xyz[(int64_t)nd[v] * DIM + d];
+
+        if constexpr (FORM == F_MASS) {
+            const double absdet = fabs(affine_det<DIM>(X));
+#pragma unroll
+            for (int j = 0; j < NEN; ++j) {
+                double v = 0.0;
+                for (int q = 0; q < nq; ++q) v += s_w[q] * s_phi[q * NEN + li] * s_phi[q * NEN + j];
+                v *= absdet;
+                const int slot = find_slot(cols, rn, nd[j] * dofs + comp);
+                acc[slot * BS + tid] += v;
+            }
+        } else {
+            double Binv[DIM][DIM];
+            const double absdet = fabs(affine<DIM>(X, Binv));
+            if constexpr (FORM == F_LAPLACE) {
+#pragma unroll
+                for (int j = 0; j < NEN; ++j) {
+                    double v = 0.0;
+                    for (int q = 0; q < nq; ++q) {
+                        double gi[DIM], gj[DIM];
+                        grad_t<DIM, NEN>(s_dphi, q, li, Binv, gi);
+                        grad_t<DIM, NEN>(s_dphi, q, j, Binv, gj);
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) v += s_w[q] * gi[d] * gj[d];
+                    }
+                    v *= absdet;
+                    const int slot = find_slot(cols, rn, nd[j] * dofs + comp);
+                    acc[slot * BS + tid] += v;
+                }
+            } else {  // F_LINELAS, row (node, comp): full dofs x dofs coupling, dofs == DIM
+                const double lam = a.p0, mu = a.p1;
+#pragma unroll
+                for (int j = 0; j < NEN; ++j) {
+                    double vb[DIM];
+#pragma unroll
+                    for (int b = 0; b < DIM; ++b) vb[b] = 0.0;
+                    for (int q = 0; q < nq; ++q) {
+                        double gi[DIM], gj[DIM];
+                        grad_t<DIM, NEN>(s_dphi, q, li, Binv, gi);
+                        grad_t<DIM, NEN>(s_dphi, q, j, Binv, gj);
+                        double dot = 0.0;
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) dot += gi[d] * gj[d];
+                        double gia = 0.0, gja = 0.0;
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) {
+                            gia = d == comp ? gi[d] : gia;
+                            gja = d == comp ? gj[d] : gja;
+                        }
+#pragma unroll
+                        for (int b = 0; b < DIM; ++b) {
+                            // 2 mu eps_i:eps_j + lam tr(eps_i) tr(eps_j) with eps from epsilonTensor
+                            const double e = mu * ((b == comp ? dot : 0.0) + gi[b] * gja) + lam * gia * gj[b];
+                            vb[b] += s_w[q] * e;
+                        }
+                    }
+                    const int slot0 = find_slot(cols, rn, nd[j] * dofs);
+#pragma unroll
+                    for (int b = 0; b < DIM; ++b) acc[(slot0 + b) * BS + tid] += absdet * vb[b];
+                }
+            }
+        }
+    }
+    for (int s = 0; s < rn; ++s) a.val[rs + s] = acc[s * BS + tid];
+}
+
+struct RhsArgs {
+    const int32_t* conn;
+    const int32_t* n2e_ptr;
+    const int32_t* n2e;
+    const double* xyz;
+    double* rhs;
+    int32_t n_own;
+    int nen, dofs;
+    double base[10];  // sum_q w_q phi_q,i
+    double f[MAX_DOFS];
+};
+
+template <int DIM>
+__global__ void k_rhs(RhsArgs a) {
+    const int32_t node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= a.n_own) return;
+    double sum = 0.0;
+    for (int32_t p = a.n2e_ptr[node]; p < a.n2e_ptr[node + 1]; ++p) {
+        const int32_t idx = a.n2e[p];
+        const int32_t e = idx / a.nen;
+        const int li = idx - e * a.nen;
+        double X[DIM + 1][DIM];
+#pragma unroll
+        for (int v = 0; v <= DIM; ++v) {
+            const int32_t nd = a.conn[(int64_t)e * a.nen + v];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) X[v][d] = a.xyz[(int64_t)nd * DIM + d];
+        }
+        double b = 0.0;
+        for (int i = 0; i < 10; ++i) b = i == li ? a.base[i] : b;
+        sum += b * fabs(affine_det<DIM>(X));
+    }
+    for (int d = 0; d < a.dofs; ++d) a.rhs[(int64_t)node * a.dofs + d] = sum * a.f[d];
+}
+
+struct BcArgs {
+    int n, dofs;
+    int32_t flag[MAX_BC];
+    int32_t mask[MAX_BC * MAX_DOFS];
+    double value[MAX_BC * MAX_DOFS];
+};
+
+__global__ void k_dirichlet(BcArgs b, const int32_t* __restrict__ nflag, const int32_t* __restrict__ rowptr,
+                            const int32_t* __restrict__ colind, double* val, double* rhs, int32_t* isdir,
+                            int32_t n_rows) {
+    const int32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const int32_t node = row / b.dofs;
+    const int comp = row - node * b.dofs;
+    const int32_t f = nflag[node];
+    int hit = -1;
+    for (int k = 0; k < b.n; ++k)
+        if (hit < 0 && b.flag[k] == f && b.mask[k * b.dofs + comp]) hit = k;
+    if (hit < 0) return;
+    for (int32_t p = rowptr[row]; p < rowptr[row + 1]; ++p) val[p] = colind[p] == row ? 1.0 : 0.0;
+    rhs[row] = b.value[hit * b.dofs + comp];
+    isdir[row] = 1;
+}
+
+template <int DIM, int NEN>
+int launch_assemble(fedd_ctx* c, int kform, const AsmArgs& a, int ntab) {
+    const int rowcap = std::max(1, c->max_row_nnz);
+    int bs = 256;
+    auto need = [&](int b) { return ((size_t)ntab + (size_t)rowcap * b) * sizeof(double); };
+    while (bs > 64 && need(bs) > 64 * 1024) bs >>= 1;
+    const size_t lds = need(bs);
+    FEDD_CHECK(lds <= 160 * 1024, "assembly: a CSR row with %d entries does not fit the LDS row buffer", rowcap);
+    const dim3 grid((unsigned)((c->n_rows + bs - 1) / bs)), block(bs);
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024)
+            FEDD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ScopedTimer t(c, FEDD_T_ASSEMBLE);
+        hipLaunchKernelGGL(kern, grid, block, lds, c->stream, a);
+        t.stop();
+        FEDD_HIP(hipGetLastError());
+        return 0;
+    };
+    if (kform == F_LAPLACE) return go(k_assemble<DIM, NEN, F_LAPLACE>);
+    if (kform == F_MASS) return go(k_assemble<DIM, NEN, F_MASS>);
+    return go(k_assemble<DIM, NEN, F_LINELAS>);
+}
+
+}  // namespace
+
+int assemble_matrix(fedd_ctx* c, int form, const double* params) {
+    const int dim = c->dim, nen = c->nen;
+    int kform, degree;
+    const int dg = fe_degree(nen, dim, true), ds = fe_degree(nen, dim, false);
+    switch (form) {
+        case FEDD_FORM_LAPLACE:
+            FEDD_CHECK(c->dofs == 1, "assemblyLaplace needs a scalar pattern");
+            kform = F_LAPLACE; degree = dg + dg; break;
+        case FEDD_FORM_LAPLACE_VEC:
+            FEDD_CHECK(c->dofs == dim && c->block_mode == FEDD_BLOCK_DIAG, "assemblyLaplaceVecField needs a DIAG pattern with dim dofs per node");
+            kform = F_LAPLACE; degree = dg + dg; break;
+        case FEDD_FORM_MASS:
+            FEDD_CHECK(c->dofs == 1, "assemblyMass(Scalar) needs a scalar pattern");
+            kform = F_MASS; degree = ds + ds; break;
+        case FEDD_FORM_MASS_VEC:
+            FEDD_CHECK(c->dofs == dim && c->block_mode == FEDD_BLOCK_DIAG, "assemblyMass(Vector) needs a DIAG pattern with dim dofs per node");
+            kform = F_MASS; degree = ds + ds; break;
+        case FEDD_FORM_LINELAS:
+            FEDD_CHECK(c->dofs == dim && c->block_mode == FEDD_BLOCK_FULL, "assemblyLinElasXDim needs a FULL pattern with dim dofs per node");
+            FEDD_CHECK(params, "assemblyLinElasXDim needs params = {lambda, mu}");
+            kform = F_LINELAS; degree = dg + dg; break;
+        default:
+            FEDD_CHECK(false, "fedd_assemble: unknown form %d", form);
+    }
+    if (degree == 0) degree = 1;  // FE::determineDegree, FE_def.hpp:5508-5509
+    FeTables tb;
+    FEDD_TRY(fe_tables(dim, nen, degree, tb));
+    const int ntab = tb.nq * (1 + nen + nen * dim);
+    std::vector<double> host(ntab);
+    std::copy(tb.w.begin(), tb.w.end(), host.begin());
+    std::copy(tb.phi.begin(), tb.phi.end(), host.begin() + tb.nq);
+    std::copy(tb.dphi.begin(), tb.dphi.end(), host.begin() + tb.nq + tb.nq * nen);
+    FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>(ntab, c->d_dtmp0.cap)));
+    FEDD_HIP(hipMemcpyAsync(c->d_dtmp0.p, host.data(), ntab * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    AsmArgs a;
+    a.conn = c->d_conn.p; a.n2e_ptr = c->d_n2e_ptr.p; a.n2e = c->d_n2e.p; a.rowptr = c->d_rowptr.p;
+    a.colind = c->d_colind.p; a.xyz = c->d_xyz.p; a.val = c->d_val.p; a.tab = c->d_dtmp0.p;
+    a.nq = tb.nq; a.n_rows = (int32_t)c->n_rows; a.dofs = c->dofs;
+    a.p0 = params ? params[0] : 0.0;
+    a.p1 = params ? params[1] : 0.0;
+    c->have_schwarz = false;
+    if (dim == 2 && nen == 3) return launch_assemble<2, 3>(c, kform, a, ntab);
+    if (dim == 2 && nen == 6) return launch_assemble<2, 6>(c, kform, a, ntab);
+    if (dim == 3 && nen == 4) return launch_assemble<3, 4>(c, kform, a, ntab);
+    return launch_assemble<3, 10>(c, kform, a, ntab);
+}
+
+int assemble_rhs(fedd_ctx* c, int dofs, const double* f_const, int extra_degree) {
+    const int dim = c->dim, nen = c->nen;
+    int degree = fe_degree(nen, dim, false);
+    if (degree == 0) degree = 1;
+    degree += extra_degree;  // FE_def.hpp:4717-4718
+    FeTables tb;
+    FEDD_TRY(fe_tables(dim, nen, degree, tb));
+    RhsArgs a;
+    a.conn = c->d_conn.p; a.n2e_ptr = c->d_n2e_ptr.p; a.n2e = c->d_n2e.p; a.xyz = c->d_xyz.p;
+    a.rhs = c->d_rhs.p; a.n_own = (int32_t)c->n_own; a.nen = nen; a.dofs = dofs;
+    for (int i = 0; i < 10; ++i) a.base[i] = 0.0;
+    for (int i = 0; i < nen; ++i) {
+        double s = 0.0;
+        for (int q = 0; q < tb.nq; ++q) s += tb.w[q] * tb.phi[(size_t)q * nen + i];
+        a.base[i] = s;
+    }
+    for (int d = 0; d < MAX_DOFS; ++d) a.f[d] = d < dofs ? f_const[d] : 0.0;
+    const dim3 grid((unsigned)((c->n_own + 255) / 256)), block(256);
+    ScopedTimer t(c, FEDD_T_RHS);
+    if (dim == 2) hipLaunchKernelGGL(k_rhs<2>, grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL(k_rhs<3>, grid, block, 0, c->stream, a);
+    t.stop();
+    FEDD_HIP(hipGetLastError());
+    return 0;
+}
+
+int apply_dirichlet(fedd_ctx* c, int n_bc, const int32_t* flags, const int32_t* comp_mask, const double* values) {
+    BcArgs b;
+    b.n = n_bc;
+    b.dofs = c->dofs;
+    for (int k = 0; k < n_bc; ++k) {
+        b.flag[k] = flags[k];
+        for (int d = 0; d < c->dofs; ++d) {
+            b.mask[k * c->dofs + d] = comp_mask ? comp_mask[k * c->dofs + d] : 1;
+            b.value[k * c->dofs + d] = values[k * c->dofs + d];
+        }
+    }
+    const dim3 grid((unsigned)((c->n_rows + 255) / 256)), block(256);
+    ScopedTimer t(c, FEDD_T_DIRICHLET);
+    hipLaunchKernelGGL(k_dirichlet, grid, block, 0, c->stream, b, c->d_flag.p, c->d_rowptr.p, c->d_colind.p,
+                       c->d_val.p, c->d_rhs.p, c->d_isdir.p, (int32_t)c->n_rows);
+    t.stop();
+    FEDD_HIP(hipGetLastError());
+    c->have_schwarz = false;
+    return 0;
+}
+
+}  // namespace fedd

@@ -1,0 +1,221 @@
+// Internal declarations shared by the translation units of libfedd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstdarg>
+#include "../../include/fedd_hip.h"
+
+struct ncclComm;
+
+namespace fedd {
+
+void set_error(const char* fmt, ...);
+
+#define FEDD_HIP(call)                                                                          \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            fedd::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return 1;                                                                           \
+        }                                                                                       \
+    } while (0)
+
+#define FEDD_CHECK(cond, ...)                                                                   \
+    do {                                                                                        \
+        if (!(cond)) {                                                                          \
+            fedd::set_error(__VA_ARGS__);                                                       \
+            return 1;                                                                           \
+        }                                                                                       \
+    } while (0)
+
+#define FEDD_TRY(expr)                                                                          \
+    do {                                                                                        \
+        int r__ = (expr);                                                                       \
+        if (r__) return r__;                                                                    \
+    } while (0)
+
+// A device allocation that remembers its size; grows on demand, never shrinks.
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    int ensure(size_t n) {
+        if (n <= cap && p) return 0;
+        if (p) {
+            hipError_t e = hipFree(p);
+            (void)e;
+            p = nullptr;
+            cap = 0;
+        }
+        if (n == 0) n = 1;
+        FEDD_HIP(hipMalloc((void**)&p, n * sizeof(T)));
+        cap = n;
+        return 0;
+    }
+    void release() {
+        if (p) {
+            hipError_t e = hipFree(p);
+            (void)e;
+        }
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+constexpr int MAX_BC = 16;
+constexpr int MAX_DOFS = 3;
+constexpr int SCHWARZ_NMAX = 256;  // largest overlapping subdomain (dofs) the dense kernels take
+
+struct HaloPlan {
+    std::vector<int32_t> peers;
+    std::vector<int64_t> send_ptr, recv_ptr;   // per peer, in dofs-per-node = 1 units (nodes)
+    std::vector<int32_t> send_lid, recv_lid;   // owned node ids to pack / ghost node ids to fill
+    std::vector<int64_t> req_count, req_gid;   // what this rank asks of every other rank (by rank, gid asc)
+    DevBuf<int32_t> d_send_lid, d_recv_lid;
+    DevBuf<double> d_send_buf, d_recv_buf;     // sized for MAX_DOFS * nodes
+    bool ready = false;
+};
+
+struct TimerSlot {
+    double total_ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace fedd
+
+struct fedd_ctx {
+    int device = -1;  // < 0: host-only context (no HIP calls; host logic tests)
+    int rank = 0, nranks = 1;
+    hipStream_t stream = nullptr;
+    ncclComm* comm = nullptr;
+
+    // ---- mesh (column-local numbering: owned nodes [0,n_own) in unique-map order, then ghosts
+    //      sorted by global id) ----
+    int dim = 0, nen = 0;
+    int64_t n_elem = 0, n_own = 0, n_node = 0;  // n_node = owned + ghost
+    std::vector<int64_t> h_node_gid;            // [n_node]
+    std::vector<int32_t> h_ghost_owner;         // [n_node - n_own]
+    fedd::DevBuf<int32_t> d_conn;               // [n_elem*nen]
+    fedd::DevBuf<double> d_xyz;                 // [n_node*dim]
+    fedd::DevBuf<int32_t> d_flag;               // [n_own] bc flags of owned nodes
+
+    // ---- node -> (element, local index) adjacency of owned nodes ----
+    fedd::DevBuf<int32_t> d_n2e_ptr, d_n2e;     // [n_own+1], [sum]
+    int max_deg = 0;
+    bool have_adj = false;
+
+    // ---- CSR (dof level, owned rows) ----
+    int dofs = 0, block_mode = 0;
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int max_row_nnz = 0;
+    fedd::DevBuf<int32_t> d_rowptr, d_colind;
+    fedd::DevBuf<double> d_val;
+    fedd::DevBuf<double> d_rhs, d_x;            // [n_rows]
+    fedd::DevBuf<double> d_xcol, d_ycol;        // [n_cols] work vectors with ghost tail
+    fedd::DevBuf<int32_t> d_isdir;              // [n_rows] 1 = Dirichlet row
+    bool have_pattern = false;
+
+    // ---- Schwarz ----
+    int sw_target = 27;
+    double sw_scale = 1.0;
+    int sw_overlap = 1, sw_combine = 0;
+    int64_t sw_nsub = 0, sw_max_size = 0, sw_inv_elems = 0;
+    fedd::DevBuf<int32_t> d_node_bin;           // [n_own] compact bin id of each owned node
+    fedd::DevBuf<int32_t> d_bin_ptr, d_bin_nodes;   // [nsub+1], [n_own]
+    fedd::DevBuf<int32_t> d_sub_n, d_sub_nown;  // [nsub] total / owned dofs of each subdomain
+    fedd::DevBuf<int32_t> d_sub_dofs;           // [nsub*NMAX] local dof ids (owned first)
+    fedd::DevBuf<int64_t> d_inv_ptr;            // [nsub+1] offsets into d_inv (elements)
+    fedd::DevBuf<double> d_inv;                 // per subdomain [n_i][rp_i] column-major slab
+    fedd::DevBuf<double> d_mult;                // [n_cols] multiplicity (averaging)
+    bool have_schwarz = false;
+
+    // ---- GMRES workspace ----
+    fedd::DevBuf<double> d_V, d_Z;              // [(m+1)*n_rows], [n_cols] scratch
+    fedd::DevBuf<double> d_w;                   // [n_rows]
+    fedd::DevBuf<double> d_part;                // dot partials
+    fedd::DevBuf<double> d_small;               // H, cs, sn, g, h, scalars
+    double* h_pinned = nullptr;                 // small pinned host mirror
+    int gm_restart_alloc = 0;
+
+    // ---- generic scratch ----
+    fedd::DevBuf<int32_t> d_itmp0, d_itmp1, d_itmp2;
+    fedd::DevBuf<int64_t> d_scan[3];            // block sums of the device scan, one per level
+    fedd::DevBuf<double> d_dtmp0;
+    fedd::DevBuf<int32_t> d_flags;              // [16] device flags: 0 max scratch, 1 bad pivot, 2 DGKS gate
+
+    fedd::HaloPlan halo;
+
+    // ---- timing ----
+    bool timing = false;
+    fedd::TimerSlot timers[FEDD_T_COUNT];
+};
+
+namespace fedd {
+
+// RAII-ish helper: records a start event at construction and a stop event at stop().
+struct ScopedTimer {
+    fedd_ctx* c;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(fedd_ctx* ctx, int timer) : c(ctx), id(timer) {
+        if (c->timing) {
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+                (void)hipEventRecord(a, c->stream);
+        }
+    }
+    void stop() {
+        if (c->timing && a && b) {
+            (void)hipEventRecord(b, c->stream);
+            c->timers[id].pending.emplace_back(a, b);
+            a = b = nullptr;
+        }
+    }
+    ~ScopedTimer() { stop(); }
+};
+
+int timing_flush(fedd_ctx* c);
+
+// device utilities (scan.hip)
+int exclusive_scan_i32(fedd_ctx* c, const int32_t* d_in, int32_t* d_out, int64_t n, int64_t* total_out);
+int exclusive_scan_i64(fedd_ctx* c, const int64_t* d_in, int64_t* d_out, int64_t n, int64_t* total_out);
+int reduce_max_i32(fedd_ctx* c, const int32_t* d_in, int64_t n, int32_t* out);
+
+// symbolic.hip
+int build_adjacency(fedd_ctx* c);
+int build_pattern(fedd_ctx* c, int dofs, int block_mode);
+
+// assemble.hip
+int assemble_matrix(fedd_ctx* c, int form, const double* params);
+int assemble_rhs(fedd_ctx* c, int dofs, const double* f_const, int extra_degree);
+int apply_dirichlet(fedd_ctx* c, int n_bc, const int32_t* flags, const int32_t* comp_mask,
+                    const double* values);
+
+// spmv.hip
+int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned);   // incl. ghost import
+int halo_import(fedd_ctx* c, double* d_xcol, int dofs);                    // fill ghost tail
+
+// schwarz.hip
+int schwarz_setup(fedd_ctx* c);
+int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned);
+
+// gmres.hip
+int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart,
+                int use_prec, int* its_out, double* relres_out);
+int allreduce_sum(fedd_ctx* c, double* d_buf, int n);
+
+// FE tables (fe_tables.cpp): reference-simplex quadrature and basis values
+struct FeTables {
+    int dim = 0, nen = 0, nq = 0;
+    std::vector<double> w;      // [nq]
+    std::vector<double> phi;    // [nq*nen]
+    std::vector<double> dphi;   // [nq*nen*dim]
+};
+int fe_quadrature(int dim, int degree, std::vector<double>& pts, std::vector<double>& w);
+int fe_tables(int dim, int nen, int degree, FeTables& out);
+int fe_degree(int nen, int dim, bool grad);   // determineDegree building block: P1 Std 1/Grad 0, P2 2/1
+
+}  // namespace fedd

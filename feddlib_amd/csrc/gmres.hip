@@ -1,0 +1,304 @@
+// Right-preconditioned restarted GMRES on the device, block size 1.
+//
+// Stands in for Thyra::solve on the Belos "Block GMRES" LOWS that
+// LinearSolver::solveMonolithic builds (feddlib/problems/Solver/LinearSolver_def.hpp:72-135) with
+// the settings of feddlib/problems/tests/laplace/parametersSolver.xml:5-15 (Block Size 1, DGKS
+// orthogonalisation, relative residual tolerance, maximum iterations) and the preconditioner
+// attached as Thyra "unspecified" side = right.  Belos is not in the reference tree; this is the
+// published algorithm (Saad, Iterative Methods, Alg. 9.5):
+//   - classical Gram-Schmidt as one fused multi-dot + one fused multi-axpy over the Krylov basis,
+//     second pass only when ||w_new|| < ||w_old|| / sqrt(2) (the DGKS test), decided on the device;
+//   - Givens QR of the Hessenberg matrix on the device (single lane), the host reads one double
+//     per iteration (implicit relative residual) to decide convergence;
+//   - x = x0 + M^-1 (V y) at the end of a cycle (M is a fixed linear operator, so Z is not stored).
+// All sums run in a fixed order: results are bitwise reproducible run to run.
+#include "fedd_internal.hpp"
+#include <rccl/rccl.h>
+#include <algorithm>
+#include <cmath>
+
+namespace fedd {
+namespace {
+
+constexpr int DOT_BLOCKS = 512;
+
+// partial[col*DOT_BLOCKS + blk] = sum over the block's rows of V_col . w ; col == ncolsV means w . w
+__global__ __launch_bounds__(256) void k_multidot(const double* __restrict__ V, int64_t n, int ncolsV,
+                                                  const double* __restrict__ w, double* __restrict__ partial,
+                                                  const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;
+    __shared__ double sh[256];
+    const int col = blockIdx.y;
+    const double* __restrict__ a = col < ncolsV ? V + (int64_t)col * n : w;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)DOT_BLOCKS * 256) s += a[i] * w[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(int64_t)col * DOT_BLOCKS + blockIdx.x] = sh[0];
+}
+
+// out[col] = sum_blk partial[col][blk]   (one workgroup per column, fixed order)
+__global__ __launch_bounds__(256) void k_reduce_cols(const double* __restrict__ partial, double* __restrict__ out,
+                                                     const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;
+    __shared__ double sh[256];
+    const int col = blockIdx.x;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < DOT_BLOCKS; k += 256) s += partial[(int64_t)col * DOT_BLOCKS + k];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[col] = sh[0];
+}
+
+// w -= sum_c h[c] V_c ; also partial sums of ||w_new||^2 into partial[blk]
+__global__ __launch_bounds__(256) void k_multiaxpy(const double* __restrict__ V, int64_t n, int ncols,
+                                                   const double* __restrict__ h, double* __restrict__ w,
+                                                   double* __restrict__ partial, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;
+    __shared__ double sh[256];
+    double nrm = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)DOT_BLOCKS * 256) {
+        double v = w[i];
+        for (int c = 0; c < ncols; ++c) v -= h[c] * V[(int64_t)c * n + i];
+        w[i] = v;
+        nrm += v * v;
+    }
+    sh[threadIdx.x] = nrm;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// scalars layout in d_small (doubles): see Offsets below
+struct Off {
+    int H, cs, sn, g, h1, h2, nrm, y, misc;
+};
+
+// after pass 1: decide DGKS re-orthogonalisation.  nrm[0] = w.w before, nrm[1] = after pass 1.
+__global__ void k_dgks_gate(const double* __restrict__ nrm, int32_t* __restrict__ gate) {
+    gate[0] = nrm[1] < 0.5 * nrm[0] ? 1 : 0;
+}
+
+// Finish column j of the Hessenberg matrix: h = h1 (+ h2), h_{j+1,j} = ||w||; apply the previous
+// rotations, create the new one, update g.  misc[0] = |g_{j+1}|, misc[1] = 1/h_{j+1,j}.
+__global__ void k_givens(double* __restrict__ S, Off o, int j, int m, const int32_t* __restrict__ gate) {
+    double* H = S + o.H + (int64_t)j * (m + 1);
+    const double* h1 = S + o.h1;
+    const double* h2 = S + o.h2;
+    const bool two = gate[0] != 0;
+    for (int i = 0; i <= j; ++i) H[i] = h1[i] + (two ? h2[i] : 0.0);
+    const double hn = sqrt(two ? S[o.nrm + 2] : S[o.nrm + 1]);
+    H[j + 1] = hn;
+    double* cs = S + o.cs;
+    double* sn = S + o.sn;
+    double* g = S + o.g;
+    for (int i = 0; i < j; ++i) {
+        const double t = cs[i] * H[i] + sn[i] * H[i + 1];
+        H[i + 1] = -sn[i] * H[i] + cs[i] * H[i + 1];
+        H[i] = t;
+    }
+    const double d = hypot(H[j], H[j + 1]);
+    cs[j] = d > 0 ? H[j] / d : 1.0;
+    sn[j] = d > 0 ? H[j + 1] / d : 0.0;
+    H[j] = d;
+    H[j + 1] = 0.0;
+    g[j + 1] = -sn[j] * g[j];
+    g[j] = cs[j] * g[j];
+    S[o.misc + 0] = fabs(g[j + 1]);
+    S[o.misc + 1] = hn > 0 ? 1.0 / hn : 0.0;
+    S[o.misc + 2] = hn;
+}
+
+__global__ void k_scale_to(const double* __restrict__ w, const double* __restrict__ scal, double* __restrict__ out,
+                           int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = w[i] * scal[0];
+}
+
+// start of a cycle: beta = sqrt(nrm2[0]); V0 = r / beta; g = (beta, 0, ...)
+__global__ void k_cycle_init(double* __restrict__ S, Off o, int m, const double* __restrict__ rr) {
+    const double beta = sqrt(rr[0]);
+    for (int i = 0; i <= m; ++i) S[o.g + i] = 0.0;
+    S[o.g] = beta;
+    S[o.misc + 1] = beta > 0 ? 1.0 / beta : 0.0;
+    S[o.misc + 3] = beta;
+}
+
+// y = R^-1 g for the k x k upper triangle (column-major H with leading dimension m+1)
+__global__ void k_backsolve(double* __restrict__ S, Off o, int k, int m) {
+    double* y = S + o.y;
+    const double* g = S + o.g;
+    const double* H = S + o.H;
+    for (int i = k - 1; i >= 0; --i) {
+        double s = g[i];
+        for (int c = i + 1; c < k; ++c) s -= H[(int64_t)c * (m + 1) + i] * y[c];
+        y[i] = s / H[(int64_t)i * (m + 1) + i];
+    }
+}
+
+// u = sum_c y[c] V_c
+__global__ __launch_bounds__(256) void k_combine(const double* __restrict__ V, int64_t n, int k,
+                                                 const double* __restrict__ y, double* __restrict__ u) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = 0.0;
+    for (int c = 0; c < k; ++c) v += y[c] * V[(int64_t)c * n + i];
+    u[i] = v;
+}
+
+__global__ void k_axpby(double a, const double* __restrict__ x, double b, const double* __restrict__ y,
+                        double* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i];
+}
+
+}  // namespace
+
+int allreduce_sum(fedd_ctx* c, double* d_buf, int n) {
+    if (c->nranks == 1) return 0;
+    FEDD_CHECK(c->comm, "allreduce: no communicator");
+    ncclResult_t r = ncclAllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream);
+    FEDD_CHECK(r == ncclSuccess, "ncclAllReduce: %s", ncclGetErrorString(r));
+    return 0;
+}
+
+int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart, int use_prec,
+                int* its_out, double* relres_out) {
+    const int64_t n = c->n_rows;
+    const int m = std::min(restart, max_it);
+    FEDD_TRY(c->d_V.ensure((size_t)(m + 1) * n));
+    FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)n, c->d_w.cap)));
+    FEDD_TRY(c->d_Z.ensure((size_t)n * 2));
+    FEDD_TRY(c->d_part.ensure((size_t)(m + 2) * DOT_BLOCKS));
+    Off o;
+    int p = 0;
+    o.H = p; p += (m + 1) * m;
+    o.cs = p; p += m;
+    o.sn = p; p += m;
+    o.g = p; p += m + 1;
+    o.h1 = p; p += m + 2;
+    o.h2 = p; p += m + 2;
+    o.nrm = p; p += 4;
+    o.y = p; p += m;
+    o.misc = p; p += 8;
+    FEDD_TRY(c->d_small.ensure((size_t)p + 8));
+    double* S = c->d_small.p;
+    FEDD_TRY(c->d_flags.ensure(16));
+    int32_t* gate = c->d_flags.p + 2;
+    double* V = c->d_V.p;
+    double* w = c->d_w.p;
+    double* z = c->d_Z.p;       // M^-1 v
+    double* r = c->d_Z.p + n;   // residual / u
+    const dim3 gn((unsigned)((n + 255) / 256)), blk(256);
+    hipStream_t st = c->stream;
+
+    auto norm2_into = [&](const double* v, double* out) -> int {  // out[0] = v.v (global)
+        hipLaunchKernelGGL(k_multidot, dim3(DOT_BLOCKS, 1), blk, 0, st, v, n, 0, v, c->d_part.p, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, out, (const int32_t*)nullptr);
+        return allreduce_sum(c, out, 1);
+    };
+    auto residual = [&]() -> int {  // r = b - A x
+        FEDD_TRY(spmv_owned(c, d_x, r));
+        hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, d_b, -1.0, (const double*)r, r, n);
+        return 0;
+    };
+
+    FEDD_HIP(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), st));  // "Zero Initial Guess" (LinearSolver_def.hpp:76-78)
+    FEDD_HIP(hipMemcpyAsync(r, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    FEDD_TRY(norm2_into(r, S + o.nrm + 3));
+    FEDD_HIP(hipMemcpyAsync(c->h_pinned, S + o.nrm + 3, sizeof(double), hipMemcpyDeviceToHost, st));
+    FEDD_HIP(hipStreamSynchronize(st));
+    const double beta0 = std::sqrt(c->h_pinned[0]);
+    int its = 0;
+    double relres = beta0 > 0 ? 1.0 : 0.0;
+    if (!(beta0 > 0)) {
+        if (its_out) *its_out = 0;
+        if (relres_out) *relres_out = 0.0;
+        return 0;
+    }
+    bool converged = false;
+    while (!converged && its < max_it) {
+        hipLaunchKernelGGL(k_cycle_init, dim3(1), dim3(1), 0, st, S, o, m, (const double*)(S + o.nrm + 3));
+        hipLaunchKernelGGL(k_scale_to, gn, blk, 0, st, (const double*)r, (const double*)(S + o.misc + 1), V, n);
+        int k = 0;
+        for (int j = 0; j < m && its < max_it; ++j) {
+            const double* vj = V + (int64_t)j * n;
+            if (use_prec) FEDD_TRY(schwarz_apply(c, vj, z));
+            FEDD_TRY(spmv_owned(c, use_prec ? z : vj, w));
+            {
+                ScopedTimer t(c, FEDD_T_ORTHO);
+                // pass 1: h1 = V^T w, nrm[0] = w.w ; w -= V h1, nrm[1] = ||w||^2
+                hipLaunchKernelGGL(k_multidot, dim3(DOT_BLOCKS, j + 2), blk, 0, st, (const double*)V, n, j + 1,
+                                   (const double*)w, c->d_part.p, (const int32_t*)nullptr);
+                hipLaunchKernelGGL(k_reduce_cols, dim3(j + 2), blk, 0, st, (const double*)c->d_part.p, S + o.h1,
+                                   (const int32_t*)nullptr);
+                FEDD_TRY(allreduce_sum(c, S + o.h1, j + 2));
+                // h1[j+1] holds w.w -> move to nrm[0] is implicit: k_dgks_gate reads nrm[], so copy
+                FEDD_HIP(hipMemcpyAsync(S + o.nrm, S + o.h1 + j + 1, sizeof(double), hipMemcpyDeviceToDevice, st));
+                hipLaunchKernelGGL(k_multiaxpy, dim3(DOT_BLOCKS), blk, 0, st, (const double*)V, n, j + 1,
+                                   (const double*)(S + o.h1), w, c->d_part.p, (const int32_t*)nullptr);
+                hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, S + o.nrm + 1,
+                                   (const int32_t*)nullptr);
+                FEDD_TRY(allreduce_sum(c, S + o.nrm + 1, 1));
+                hipLaunchKernelGGL(k_dgks_gate, dim3(1), dim3(1), 0, st, (const double*)(S + o.nrm), gate);
+                // pass 2 (gated on the device; on several ranks the gate is identical everywhere
+                // because it is computed from all-reduced numbers, so the collectives stay matched)
+                hipLaunchKernelGGL(k_multidot, dim3(DOT_BLOCKS, j + 1), blk, 0, st, (const double*)V, n, j + 1,
+                                   (const double*)w, c->d_part.p, (const int32_t*)gate);
+                hipLaunchKernelGGL(k_reduce_cols, dim3(j + 1), blk, 0, st, (const double*)c->d_part.p, S + o.h2,
+                                   (const int32_t*)gate);
+                FEDD_TRY(allreduce_sum(c, S + o.h2, j + 1));
+                hipLaunchKernelGGL(k_multiaxpy, dim3(DOT_BLOCKS), blk, 0, st, (const double*)V, n, j + 1,
+                                   (const double*)(S + o.h2), w, c->d_part.p, (const int32_t*)gate);
+                hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, S + o.nrm + 2,
+                                   (const int32_t*)gate);
+                FEDD_TRY(allreduce_sum(c, S + o.nrm + 2, 1));
+                t.stop();
+            }
+            hipLaunchKernelGGL(k_givens, dim3(1), dim3(1), 0, st, S, o, j, m, (const int32_t*)gate);
+            hipLaunchKernelGGL(k_scale_to, gn, blk, 0, st, (const double*)w, (const double*)(S + o.misc + 1),
+                               V + (int64_t)(j + 1) * n, n);
+            FEDD_HIP(hipMemcpyAsync(c->h_pinned, S + o.misc, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            FEDD_HIP(hipStreamSynchronize(st));
+            ++its;
+            k = j + 1;
+            relres = c->h_pinned[0] / beta0;
+            const bool breakdown = !(c->h_pinned[2] > 0.0);
+            if (relres <= rtol || breakdown) {
+                converged = true;
+                break;
+            }
+        }
+        // x += M^-1 (V y)
+        hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(1), 0, st, S, o, k, m);
+        hipLaunchKernelGGL(k_combine, gn, blk, 0, st, (const double*)V, n, k, (const double*)(S + o.y), r);
+        if (use_prec) {
+            FEDD_TRY(schwarz_apply(c, r, z));
+            hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)z, d_x, n);
+        } else {
+            hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)r, d_x, n);
+        }
+        if (!converged && its < max_it) {
+            FEDD_TRY(residual());
+            FEDD_TRY(norm2_into(r, S + o.nrm + 3));
+        }
+    }
+    FEDD_HIP(hipGetLastError());
+    FEDD_HIP(hipStreamSynchronize(st));
+    if (its_out) *its_out = its;
+    if (relres_out) *relres_out = relres;
+    return 0;
+}
+
+}  // namespace fedd

@@ -1,0 +1,204 @@
+// Symbolic phase on the device: node -> (element, local index) adjacency of the owned nodes and
+// the CSR pattern of the owned rows.
+//
+// Replaces what Tpetra discovers dynamically through Matrix::insertGlobalValues + fillComplete
+// (feddlib/core/LinearAlgebra/Matrix_def.hpp:88-92,192-199; the inserts are issued at
+// feddlib/core/FE/FE_def.hpp:657-659): duplicate (row,col) pairs collapse to one entry, every
+// inserted pair stays structurally (also when its value is 0), columns end up sorted.
+// No dynamic insert here: counting sort by node, per-row sorted-unique merge in LDS, closed-form
+// expansion to dofs.
+#include "fedd_internal.hpp"
+
+namespace fedd {
+namespace {
+
+__global__ void k_count_n2e(const int32_t* __restrict__ conn, int64_t n_ent, int32_t n_own, int32_t* cnt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ent; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t nd = conn[i];
+        if (nd < n_own) atomicAdd(&cnt[nd], 1);
+    }
+}
+
+__global__ void k_fill_n2e(const int32_t* __restrict__ conn, int64_t n_ent, int32_t n_own, int32_t* cursor,
+                           int32_t* __restrict__ n2e) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ent; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t nd = conn[i];
+        if (nd < n_own) {
+            const int32_t pos = atomicAdd(&cursor[nd], 1);
+            n2e[pos] = (int32_t)i;
+        }
+    }
+}
+
+// the atomics above leave each node's list in arrival order; sort it so that every later sum over
+// the list runs in a fixed (element-id) order => bitwise reproducible assembly.
+__global__ void k_sort_n2e(const int32_t* __restrict__ ptr, int32_t n_own, int32_t* n2e) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_own) return;
+    const int32_t b = ptr[r], e = ptr[r + 1];
+    for (int32_t i = b + 1; i < e; ++i) {
+        const int32_t v = n2e[i];
+        int32_t j = i - 1;
+        while (j >= b && n2e[j] > v) {
+            n2e[j + 1] = n2e[j];
+            --j;
+        }
+        n2e[j + 1] = v;
+    }
+}
+
+// One lane per owned node: merge the node lists of its incident elements into a sorted unique
+// list held in LDS (layout [k][lane], so lanes never share a bank row).  FILL = false counts,
+// FILL = true writes the columns.
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_node_pattern(const int32_t* __restrict__ conn, int nen,
+                                                     const int32_t* __restrict__ n2e_ptr,
+                                                     const int32_t* __restrict__ n2e, int32_t n_own, int cap,
+                                                     int32_t* __restrict__ row_cnt,
+                                                     const int32_t* __restrict__ rowptr,
+                                                     int32_t* __restrict__ colind) {
+    extern __shared__ int32_t lst[];
+    const int lane = threadIdx.x;
+    const int32_t r = blockIdx.x * 64 + lane;
+    if (r >= n_own) return;
+    int len = 0;
+    for (int32_t p = n2e_ptr[r]; p < n2e_ptr[r + 1]; ++p) {
+        const int32_t e = n2e[p] / nen;
+        for (int j = 0; j < nen; ++j) {
+            const int32_t col = conn[(int64_t)e * nen + j];
+            int pos = 0;
+            while (pos < len && lst[pos * 64 + lane] < col) ++pos;
+            if (pos < len && lst[pos * 64 + lane] == col) continue;
+            if (len < cap) {
+                for (int k = len; k > pos; --k) lst[k * 64 + lane] = lst[(k - 1) * 64 + lane];
+                lst[pos * 64 + lane] = col;
+                ++len;
+            }
+        }
+    }
+    if (!FILL) {
+        row_cnt[r] = len;
+    } else {
+        const int32_t b = rowptr[r];
+        for (int k = 0; k < len; ++k) colind[b + k] = lst[k * 64 + lane];
+    }
+}
+
+// node pattern -> dof pattern, closed form (no scan): node-wise interleaved dofs
+// (feddlib/core/LinearAlgebra/Map_def.hpp:101-104).
+__global__ void k_expand_pattern(const int32_t* __restrict__ nptr, const int32_t* __restrict__ ncol, int32_t n_own,
+                                 int dofs, int full, int32_t* __restrict__ rowptr, int32_t* __restrict__ colind) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_rows = (int64_t)n_own * dofs;
+    if (row > n_rows) return;
+    if (row == n_rows) {
+        rowptr[row] = nptr[n_own] * dofs * (full ? dofs : 1);
+        return;
+    }
+    const int32_t nd = (int32_t)(row / dofs);
+    const int a = (int)(row % dofs);
+    const int32_t nb = nptr[nd], nn = nptr[nd + 1] - nb;
+    if (full) {
+        const int32_t start = nb * dofs * dofs + a * nn * dofs;
+        rowptr[row] = start;
+        for (int32_t s = 0; s < nn; ++s)
+            for (int b = 0; b < dofs; ++b) colind[start + s * dofs + b] = ncol[nb + s] * dofs + b;
+    } else {
+        const int32_t start = nb * dofs + a * nn;
+        rowptr[row] = start;
+        for (int32_t s = 0; s < nn; ++s) colind[start + s] = ncol[nb + s] * dofs + a;
+    }
+}
+
+}  // namespace
+
+int build_adjacency(fedd_ctx* c) {
+    const int64_t n_ent = c->n_elem * c->nen;
+    const int32_t n_own = (int32_t)c->n_own;
+    FEDD_TRY(c->d_n2e_ptr.ensure((size_t)n_own + 1));
+    FEDD_TRY(c->d_itmp0.ensure((size_t)n_own + 1));
+    int32_t* cnt = c->d_itmp0.p;
+    FEDD_HIP(hipMemsetAsync(cnt, 0, ((size_t)n_own + 1) * sizeof(int32_t), c->stream));
+    const int nb = (int)std::min<int64_t>(4096, std::max<int64_t>(1, (n_ent + 255) / 256));
+    if (n_ent > 0) hipLaunchKernelGGL(k_count_n2e, dim3(nb), dim3(256), 0, c->stream, c->d_conn.p, n_ent, n_own, cnt);
+    int32_t md = 0;
+    FEDD_TRY(reduce_max_i32(c, cnt, n_own, &md));
+    c->max_deg = md;
+    int64_t total = 0;
+    FEDD_TRY(exclusive_scan_i32(c, cnt, c->d_n2e_ptr.p, n_own, &total));
+    FEDD_TRY(c->d_n2e.ensure((size_t)total));
+    FEDD_HIP(hipMemcpyAsync(cnt, c->d_n2e_ptr.p, (size_t)n_own * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    if (n_ent > 0) {
+        hipLaunchKernelGGL(k_fill_n2e, dim3(nb), dim3(256), 0, c->stream, c->d_conn.p, n_ent, n_own, cnt, c->d_n2e.p);
+        hipLaunchKernelGGL(k_sort_n2e, dim3((n_own + 255) / 256), dim3(256), 0, c->stream, c->d_n2e_ptr.p, n_own, c->d_n2e.p);
+    }
+    FEDD_HIP(hipGetLastError());
+    c->have_adj = true;
+    return 0;
+}
+
+int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
+    const int32_t n_own = (int32_t)c->n_own;
+    const int nen = c->nen;
+    // upper bound for the distinct columns of one node row
+    int cap = c->max_deg * (nen - 1) + 1;
+    if (cap < 1) cap = 1;
+    const size_t lds = (size_t)cap * 64 * sizeof(int32_t);
+    FEDD_CHECK(lds <= 160 * 1024, "pattern build: a node with %d incident elements exceeds the LDS list (cap %d)", c->max_deg, cap);
+    const dim3 grid((n_own + 63) / 64), block(64);
+    const bool scalar = dofs == 1;
+    // node-level pattern goes straight into the final arrays when dofs == 1
+    FEDD_TRY(c->d_itmp1.ensure((size_t)n_own + 1));  // node row counts -> node rowptr
+    int32_t* nptr = c->d_itmp1.p;
+    if (lds > 64 * 1024)
+        FEDD_HIP(hipFuncSetAttribute((const void*)k_node_pattern<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_node_pattern<false>, grid, block, lds, c->stream, c->d_conn.p, nen, c->d_n2e_ptr.p,
+                       c->d_n2e.p, n_own, cap, nptr, (const int32_t*)nullptr, (int32_t*)nullptr);
+    int32_t max_nn = 0;
+    FEDD_TRY(reduce_max_i32(c, nptr, n_own, &max_nn));
+    int64_t node_nnz = 0;
+    FEDD_TRY(exclusive_scan_i32(c, nptr, nptr, n_own, &node_nnz));
+    const int64_t mult = scalar ? 1 : (block_mode == FEDD_BLOCK_FULL ? (int64_t)dofs * dofs : dofs);
+    const int64_t nnz = node_nnz * mult;
+    FEDD_CHECK(nnz < ((int64_t)1 << 31), "pattern build: %lld nonzeros exceed 32-bit local offsets", (long long)nnz);
+    c->dofs = dofs;
+    c->block_mode = block_mode;
+    c->n_rows = (int64_t)n_own * dofs;
+    c->n_cols = c->n_node * dofs;
+    c->nnz = nnz;
+    c->max_row_nnz = max_nn * (block_mode == FEDD_BLOCK_FULL ? dofs : 1);
+    FEDD_TRY(c->d_rowptr.ensure((size_t)c->n_rows + 1));
+    FEDD_TRY(c->d_colind.ensure((size_t)nnz));
+    FEDD_TRY(c->d_val.ensure((size_t)nnz));
+    FEDD_TRY(c->d_rhs.ensure((size_t)c->n_rows));
+    FEDD_TRY(c->d_x.ensure((size_t)c->n_rows));
+    FEDD_TRY(c->d_xcol.ensure((size_t)c->n_cols));
+    FEDD_TRY(c->d_isdir.ensure((size_t)c->n_rows));
+    FEDD_HIP(hipMemsetAsync(c->d_val.p, 0, (size_t)nnz * sizeof(double), c->stream));
+    FEDD_HIP(hipMemsetAsync(c->d_rhs.p, 0, (size_t)c->n_rows * sizeof(double), c->stream));
+    FEDD_HIP(hipMemsetAsync(c->d_x.p, 0, (size_t)c->n_rows * sizeof(double), c->stream));
+    FEDD_HIP(hipMemsetAsync(c->d_isdir.p, 0, (size_t)c->n_rows * sizeof(int32_t), c->stream));
+    int32_t* ncol = c->d_colind.p;
+    if (!scalar) {
+        FEDD_TRY(c->d_itmp2.ensure((size_t)node_nnz));
+        ncol = c->d_itmp2.p;
+    }
+    if (lds > 64 * 1024)
+        FEDD_HIP(hipFuncSetAttribute((const void*)k_node_pattern<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_node_pattern<true>, grid, block, lds, c->stream, c->d_conn.p, nen, c->d_n2e_ptr.p,
+                       c->d_n2e.p, n_own, cap, (int32_t*)nullptr, (const int32_t*)nptr, ncol);
+    if (scalar) {
+        FEDD_HIP(hipMemcpyAsync(c->d_rowptr.p, nptr, ((size_t)n_own + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        const int64_t nthreads = c->n_rows + 1;
+        hipLaunchKernelGGL(k_expand_pattern, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream,
+                           (const int32_t*)nptr, (const int32_t*)ncol, n_own, dofs,
+                           block_mode == FEDD_BLOCK_FULL ? 1 : 0, c->d_rowptr.p, c->d_colind.p);
+    }
+    FEDD_HIP(hipGetLastError());
+    c->have_pattern = true;
+    c->have_schwarz = false;
+    return 0;
+}
+
+}  // namespace fedd

@@ -1,0 +1,184 @@
+/* fedd_hip.h -- C ABI of the MI355X (gfx950) FE-assembly + Schwarz/GMRES hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ / torch / Trilinos types.
+ * Every entry point names the reference interface (path:line under /root/reference) whose work
+ * it replaces.  Conventions:
+ *   - all functions return 0 on success, non-zero on failure; fedd_last_error() gives the message
+ *     (the reference throws std::logic_error / std::runtime_error via TEUCHOS_TEST_FOR_EXCEPTION);
+ *   - the caller owns every host buffer; the library owns device memory behind fedd_ctx;
+ *   - one fedd_ctx per GPU / rank, not thread-safe per handle;
+ *   - scalar = double, local ordinal = int32_t, global ordinal = int64_t
+ *     (feddlib/core/General/DefaultTypeDefs.hpp:6-15).
+ *   - vector fields are node-wise interleaved: dof = dofs_per_node*node + d
+ *     (feddlib/core/LinearAlgebra/Map_def.hpp:101-104).
+ */
+#ifndef FEDD_HIP_H
+#define FEDD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fedd_ctx fedd_ctx;
+
+/* ---- forms understood by fedd_assemble (feddlib/core/FE/FE_decl.hpp:130-257) ---- */
+enum fedd_form {
+    FEDD_FORM_LAPLACE     = 0, /* FE::assemblyLaplace          FE_def.hpp:604-667   (dofs 1)          */
+    FEDD_FORM_LAPLACE_VEC = 1, /* FE::assemblyLaplaceVecField  FE_def.hpp:670-734   (dofs dim, diag)  */
+    FEDD_FORM_MASS        = 2, /* FE::assemblyMass "Scalar"    FE_def.hpp:454-524   (dofs 1)          */
+    FEDD_FORM_MASS_VEC    = 3, /* FE::assemblyMass "Vector"    FE_def.hpp:454-524   (dofs dim, diag)  */
+    FEDD_FORM_LINELAS     = 4  /* FE::assemblyLinElasXDim      FE_def.hpp:2739-3040 (dofs dim, full);
+                                  params = {lambda, mu}                                              */
+};
+
+/* ---- how the dofs of a node couple in the CSR pattern ---- */
+enum fedd_block_mode {
+    FEDD_BLOCK_SCALAR = 0,     /* dofs_per_node == 1                                                  */
+    FEDD_BLOCK_DIAG   = 1,     /* (dim*i+d, dim*j+d) only        -- what assemblyLaplaceVecField inserts */
+    FEDD_BLOCK_FULL   = 2      /* every (a,b) pair                -- what assemblyLinElasXDim inserts    */
+};
+
+enum fedd_combine {            /* FROSch "Combine Values in Overlap" (laplace/parametersPrec.xml:31)    */
+    FEDD_COMBINE_RESTRICTED = 0,
+    FEDD_COMBINE_AVERAGING  = 1,
+    FEDD_COMBINE_FULL       = 2
+};
+
+/* kernel classes whose device time the library accumulates with HIP events when timing is on */
+enum fedd_timer {
+    FEDD_T_SYMBOLIC = 0,  /* adjacency + CSR pattern                           */
+    FEDD_T_ASSEMBLE = 1,  /* matrix gather-assembly kernel                     */
+    FEDD_T_RHS      = 2,
+    FEDD_T_DIRICHLET= 3,
+    FEDD_T_SPMV     = 4,
+    FEDD_T_SCHWARZ_SETUP = 5,
+    FEDD_T_SCHWARZ_APPLY = 6,
+    FEDD_T_ORTHO    = 7,  /* GMRES multi-dot / multi-axpy kernels              */
+    FEDD_T_COUNT    = 8
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * context  (replaces the per-rank Teuchos::Comm + Tpetra node the reference gets from
+ * Xpetra::DefaultPlatform, feddlib/problems/tests/laplace/main.cpp:60-62)
+ * nccl_unique_id: NULL for a single rank; else the 128-byte ncclUniqueId shared by all ranks.
+ * ---------------------------------------------------------------------------------------------- */
+int  fedd_ctx_create(fedd_ctx** out, int device, const void* nccl_unique_id, int rank, int nranks);
+void fedd_ctx_destroy(fedd_ctx* ctx);
+const char* fedd_last_error(void);
+int  fedd_sync(fedd_ctx* ctx);                       /* hipStreamSynchronize on the context's stream */
+int  fedd_nccl_unique_id(void* id128);               /* rank 0 calls this, then shares the 128 bytes */
+
+/* ------------------------------------------------------------------------------------------------
+ * structured mesh generator, host side
+ * replaces MeshStructured::buildMesh2D/3D P1 branch + setStructuredMeshFlags + Map::buildUniqueMap
+ * (feddlib/core/Mesh/MeshStructured_def.hpp:348-463, 703-806, 2974-3203;
+ *  feddlib/core/LinearAlgebra/Map_def.hpp:184-210) as sequenced by Domain::buildMesh
+ * (feddlib/core/FE/Domain_def.hpp:201-265).
+ * decomp[3] = blocks per direction (the reference supports only N x N x N; {N,N,N} reproduces it
+ * exactly, other shapes are the 1x1x2 / 1x2x2 splits of the same global grid used for the 2- and
+ * 4-GPU scaling points).  cells[3] = cells per block and direction (the reference's M).
+ * with_ghost_elements != 0 appends the neighbour blocks' elements that touch an owned node (and
+ * their nodes), so that every owned row can be assembled without a matrix exchange.
+ * ---------------------------------------------------------------------------------------------- */
+int fedd_mesh_structured_sizes(int dim, const int* decomp, const int* cells, int rank,
+                               int with_ghost_elements,
+                               int64_t* n_elem, int64_t* n_rep, int64_t* n_uni, int64_t* n_global);
+int fedd_mesh_structured_build(int dim, const int* decomp, const int* cells, int rank,
+                               const double* origin, const double* size, int flags_option,
+                               int with_ghost_elements,
+                               int32_t* conn /*[n_elem*(dim+1)] local repeated ids*/,
+                               double* xyz /*[n_rep*dim]*/, int64_t* gid_rep /*[n_rep]*/,
+                               int32_t* flag_rep /*[n_rep]*/,
+                               int64_t* gid_uni /*[n_uni]*/, int32_t* flag_uni /*[n_uni]*/);
+
+/* ------------------------------------------------------------------------------------------------
+ * mesh upload: what FE::assemblyXxx reads through domainVec_[FEloc]->getElementsC(),
+ * getPointsRepeated(), getMapRepeated() (feddlib/core/FE/FE_def.hpp:617-621) and what BCBuilder
+ * reads through getBCFlagUnique()/getMapUnique() (feddlib/core/General/BCBuilder_def.hpp:625-626).
+ * nen = nodes per element (P1: dim+1, P2: 6 / 10).  The first dim+1 nodes are the vertices
+ * (FE::buildTransformation uses only those, FE_def.hpp:5342-5357).
+ * ---------------------------------------------------------------------------------------------- */
+int fedd_mesh_set(fedd_ctx* ctx, int dim, int nen, int64_t n_elem, const int32_t* conn,
+                  int64_t n_rep, const double* xyz, const int64_t* gid_rep,
+                  int64_t n_uni, const int64_t* gid_uni, const int32_t* bcflag_uni);
+
+/* symbolic CSR on the owned (unique-map) rows: what Tpetra's dynamic insert + fillComplete
+ * discover (feddlib/core/LinearAlgebra/Matrix_def.hpp:88-92,192-199). */
+int fedd_pattern_build(fedd_ctx* ctx, int dofs_per_node, int block_mode, int64_t* nnz_out);
+
+/* numeric assembly into the pattern; FE::assemblyXxx + fillComplete (file:line per form above). */
+int fedd_assemble(fedd_ctx* ctx, int form, const double* params);
+
+/* FE::assemblyRHS + MultiVector::exportFromVector(...,"Add") (FE_def.hpp:4694-4766,
+ * feddlib/problems/abstract/Problem_def.hpp:184-216): constant f per dof, quadrature degree
+ * determineDegree(dim,FE,Std) + extra_degree. */
+int fedd_assemble_rhs(fedd_ctx* ctx, int dofs_per_node, const double* f_const, int extra_degree);
+
+/* BCBuilder::setSystem + setRHS for constant boundary values (BCBuilder_def.hpp:589-707, 93-170):
+ * rows of nodes whose flag is in flags[] become unit rows (pattern kept), rhs <- values.
+ * comp_mask[n_bc*dofs] (nullable = all components), values[n_bc*dofs]. */
+int fedd_dirichlet(fedd_ctx* ctx, int n_bc, const int32_t* flags, const int32_t* comp_mask,
+                   const double* values);
+
+/* read-back for Tpetra::CrsMatrix fill / parity (Matrix::getLocalRowView analog). col_gid maps
+ * a local column index to its global dof id. */
+int fedd_csr_sizes(fedd_ctx* ctx, int64_t* n_rows, int64_t* n_cols, int64_t* nnz);
+int fedd_csr_get(fedd_ctx* ctx, int64_t* rowptr, int32_t* colind, double* val, int64_t* col_gid);
+int fedd_rhs_get(fedd_ctx* ctx, double* rhs_owned);
+int fedd_rhs_set(fedd_ctx* ctx, const double* rhs_owned);
+int fedd_solution_get(fedd_ctx* ctx, double* x_owned);
+
+/* y = A x on owned rows incl. ghost import: Matrix::apply (Matrix_def.hpp:245-254).
+ * host pointers; fedd_spmv_device runs `reps` launches on the resident vectors (bench). */
+int fedd_spmv(fedd_ctx* ctx, const double* x_owned, double* y_owned);
+int fedd_spmv_device(fedd_ctx* ctx, int reps);
+
+/* one-level overlapping additive Schwarz (replaces Thyra::initializePrec on the FROSch factory,
+ * feddlib/problems/Solver/Preconditioner_def.hpp:243-463; options from
+ * feddlib/problems/tests/laplace/parametersPrec.xml:10-61).  Subdomains are `target_nodes`-node
+ * boxes of the rank's owned nodes (batched, many per GPU), extended by `overlap` graph
+ * layers; exact dense local solves.  two_level/coarse_kind: reserved (GDSW is a "next" row). */
+int fedd_schwarz_setup(fedd_ctx* ctx, int overlap, int combine, int two_level, int coarse_kind);
+int fedd_schwarz_set_target(fedd_ctx* ctx, int target_nodes, double scale);
+int fedd_schwarz_apply(fedd_ctx* ctx, const double* r_owned, double* z_owned);
+int fedd_schwarz_apply_device(fedd_ctx* ctx, int reps);
+int fedd_schwarz_info(fedd_ctx* ctx, int64_t* n_subdomains, int64_t* max_size, int64_t* inverse_bytes);
+
+/* right-preconditioned restarted GMRES (replaces Thyra::solve on the Belos "Block GMRES"
+ * LOWS, feddlib/problems/Solver/LinearSolver_def.hpp:72-135; parametersSolver.xml:5-15).
+ * b_owned / x_owned may be NULL: then the assembled rhs is used and the solution stays on the
+ * device (fedd_solution_get reads it).  use_prec = 0 runs unpreconditioned. Returns the iteration
+ * count the way Problem::solve does (its_out). */
+int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rtol, int max_it,
+               int restart, int use_prec, int* its_out, double* relres_out);
+
+/* device-time accounting (HIP events on the context's stream around each kernel class) */
+int fedd_timing_enable(fedd_ctx* ctx, int on);
+int fedd_timing_reset(fedd_ctx* ctx);
+int fedd_timing_get(fedd_ctx* ctx, int timer, double* total_ms, int64_t* launches);
+
+/* multi-GPU: exchange plan for the owned/ghost split (import of ghost x / r entries before SpMV
+ * and Schwarz -- the Tpetra Import behind Matrix::apply, Matrix_def.hpp:245-254; GMRES dots are
+ * ncclAllReduce).  After fedd_mesh_set:
+ *   fedd_halo_set_owners   owner rank of every repeated node (what the Tpetra directory knows);
+ *   fedd_halo_exchange_setup  swaps the request lists over RCCL and finalises the plan;
+ * or, transport-agnostic (used by the gloo CPU tests): fedd_halo_requests_sizes/_get on every
+ * rank, all-to-all of the lists by the caller, fedd_halo_requests_set.
+ * fedd_mesh_structured_owner: owner of structured-grid nodes under the lowest-rank rule. */
+int fedd_mesh_structured_owner(int dim, const int* decomp, const int* cells, int64_t n,
+                               const int64_t* gid, int32_t* owner_rank);
+int fedd_halo_set_owners(fedd_ctx* ctx, int64_t n_rep, const int64_t* gid_rep, const int32_t* owner_rep);
+int fedd_halo_requests_sizes(fedd_ctx* ctx, int64_t* count_to_rank /*[nranks]*/);
+int fedd_halo_requests_get(fedd_ctx* ctx, int64_t* gids /*concatenated by rank*/);
+int fedd_halo_requests_set(fedd_ctx* ctx, const int64_t* count_from_rank /*[nranks]*/, const int64_t* gids);
+int fedd_halo_exchange_setup(fedd_ctx* ctx);
+int fedd_halo_plan_sizes(fedd_ctx* ctx, int* n_peers, int64_t* n_send_total, int64_t* n_recv_total);
+int fedd_halo_plan_get(fedd_ctx* ctx, int32_t* peers, int64_t* send_ptr, int32_t* send_lid,
+                       int64_t* recv_ptr, int32_t* recv_lid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEDD_HIP_H */
