@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py -- DoF/s of the assemble + solve hot path on the 3D P1-Laplace cube (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full pass of the hot path over the resident mesh: symbolic CSR pattern ->
+element assembly (matrix + rhs) -> Dirichlet rows -> one-level Schwarz setup -> right-preconditioned
+GMRES(100) to 1e-8 (feddlib/problems/tests/laplace/main.cpp:199-208 with 3D/P1/structured
+parameters).  The mesh (connectivity, coordinates, flags) is generated on the host and uploaded
+BEFORE the timed region (metric definition).
+
+Workload: N = 1 -> BASELINE.json configs[1]: unit cube, 100^3 cells, 1 030 301 dofs.
+          N > 1 -> weak scaling: every GPU owns a 100^3-cell block (1x1x2, 1x2x2, 2x2x2 blocks);
+                   the reference generator has no 2/4-rank cube (laplace/main.cpp:132), the slab /
+                   pencil splits of the same lattice are this repo's extension.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DECOMP = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cells", type=int, default=100, help="cells per direction and GPU (M = H/h)")
+    ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--restart", type=int, default=100)
+    ap.add_argument("--max-it", type=int, default=2000)
+    ap.add_argument("--target", type=int, default=27, help="nodes per Schwarz subdomain")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cells", type=int, default=0, help="cells per direction of the CPU-baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def one_step(c, capi, a):
+    c.pattern_build(1, capi.BLOCK_SCALAR)
+    c.assemble(capi.FORM_LAPLACE)
+    c.assemble_rhs([1.0])
+    c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+    c.schwarz_set_target(a.target, 1.0)
+    c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+    _, its, rel = c.gmres(None, rtol=a.rtol, max_it=a.max_it, restart=a.restart, use_prec=True, want_x=False)
+    return its, rel
+
+
+def cpu_baseline(a):
+    """The CPU restatement (oracle, kind 'port') timed on this box's host cores on a bounded
+    sample of the same workload: same driver sequence, same preconditioner definition, same
+    tolerance, smaller cube.  Reported beside the GPU number; never the thing measured as `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import oracle_c
+        have_c = oracle_c.available()
+    except Exception:
+        have_c = False
+    if have_c:
+        M = a.cpu_cells or 64
+        r = oracle_c.run_laplace3d(M, a.target, a.rtol, a.restart, a.max_it)
+        return {"value": r["dofs"] / r["seconds"], "unit": "DoF/s", "cores": r["threads"], "kind": "port",
+                "sample": "same path on a %d^3-cell cube (%d dofs, %d GMRES its, %.1f s): C/OpenMP oracle, "
+                          "one-level RAS with %d-node subdomains" % (M, r["dofs"], r["its"], r["seconds"], a.target)}
+    import fedd_oracle as fo
+    M = a.cpu_cells or 32
+    t0 = time.perf_counter()
+    m = fo.build_mesh_structured(3, 1, M)
+    t_mesh = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    A_bc, rhs_bc, _, _, _ = fo.laplace_problem(m)
+    nb_, nb, _ = fo.schwarz_bins(m.xyz_uni, a.target)
+    ras = fo.RAS(A_bc, nb_, nb)
+    x, its, hist = fo.gmres_right(A_bc, rhs_bc, ras.apply, rtol=a.rtol, max_it=a.max_it, restart=a.restart)
+    dt = time.perf_counter() - t0
+    return {"value": m.n_global / dt, "unit": "DoF/s", "cores": 1, "kind": "port",
+            "sample": "same path on a %d^3-cell cube (%d dofs, %d GMRES its, %.1f s): numpy/scipy oracle"
+                      % (M, m.n_global, its, dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    N = a.gpus
+    if world != N:
+        if world == 1 and N > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (N, N))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, N))
+    if N not in DECOMP:
+        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    import torch
+    import torch.distributed as dist
+    from feddlib_amd import capi
+    torch.cuda.set_device(local_rank)
+    nccl_id = None
+    if N > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(capi.nccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        nccl_id = bytes(idt.cpu().numpy().tobytes())
+
+    def barrier():
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dec = DECOMP[N]
+    cells = [a.cells] * 3
+    t0 = time.perf_counter()
+    m = capi.structured_mesh(3, dec, cells, rank, ghosts=N > 1)
+    t_mesh = time.perf_counter() - t0
+    c = capi.Context(device=local_rank, rank=rank, nranks=N, nccl_id=nccl_id)
+    t0 = time.perf_counter()
+    c.mesh_set_dict(m)
+    if N > 1:
+        c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, cells, m["gid_rep"]))
+        c.halo_exchange_setup()
+    c.sync()
+    t_upload = time.perf_counter() - t0
+    n_global = m["n_global"]
+
+    for _ in range(a.warmup):
+        one_step(c, capi, a)
+    c.sync()
+    c.timing_enable(True)
+    c.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    its = rel = None
+    for _ in range(a.steps):
+        its, rel = one_step(c, capi, a)
+    c.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if N > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    tm = c.timing_get()
+    nr, ncol, nnz = c.csr_sizes()
+    info = c.schwarz_info()
+
+    if rank == 0:
+        # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md), this rank's share
+        models = {
+            "spmv": 12.0 * nnz + 20.0 * nr,
+            "schwarz_apply": info["inverse_bytes"] + 3 * 8.0 * nr,
+            "assemble": 4.0 * m["conn"].size + 8.0 * 3 * m["xyz"].shape[0] + 12.0 * nnz + 4.0 * (nr + 1),
+        }
+        kern = {}
+        for k, b in models.items():
+            ms, nl = tm[k]
+            if nl:
+                kern[k] = dict(ms_per_launch=ms / nl, launches=nl, total_ms=ms, GBs=b / (ms / nl) / 1e6, bytes=b)
+        # GMRES orthogonalisation: 2 passes over the basis per DGKS pass; total bytes over the solve
+        ms, nl = tm["ortho"]
+        dominant = max(kern, key=lambda k: kern[k]["total_ms"])
+        d = kern[dominant]
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": d["GBs"] / HBM_PEAK_GBS, "traffic": None,
+                    "ms_per_launch": d["ms_per_launch"], "algorithmic_bytes_per_launch": d["bytes"]}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                roofline["traffic"] = json.load(open(pmc)).get(dominant)
+            except Exception:
+                pass
+        out = {
+            "metric": "DoF/s assemble+solve, 3D P1-Laplace cube",
+            "value": n_global * a.steps / dt,
+            "unit": "DoF/s",
+            "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (structured unit cube, f=1, homogeneous Dirichlet; reference generator semantics)",
+            "config": {"workload": "3D P1 Laplace, structured cube, %s blocks x %d^3 cells, %d dofs, nnz %d/GPU; "
+                                   "GMRES(%d) rtol %g + one-level RAS (overlap 1, %d-node subdomains, exact local solves)"
+                                   % ("x".join(map(str, dec)), a.cells, n_global, nnz, a.restart, a.rtol, a.target),
+                       "dofs": n_global, "gmres_iterations": its, "relres": rel,
+                       "subdomains_per_gpu": info["n_subdomains"], "max_subdomain_size": info["max_size"]},
+            "roofline": roofline,
+            "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()},
+            "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in tm.items()},
+            "spmv_frac_hbm_peak": kern["spmv"]["GBs"] / HBM_PEAK_GBS if "spmv" in kern else None,
+            "mesh_generation_s": t_mesh, "mesh_upload_s": t_upload,
+        }
+        if N == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(out), flush=True)
+    c.close()
+    if N > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

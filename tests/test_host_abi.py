@@ -1,0 +1,208 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/fedd_hip.h declares, the
+host logic (structured generator, numbering, halo planning) agrees with the oracle, compute calls
+fail loudly without a GPU, and the N > 1 path is exercised with world_size-2 gloo."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+import fedd_oracle as fo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "fedd_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fedd_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(fedd_lib):
+    names = header_functions()
+    assert len(names) >= 35
+    L = ctypes.CDLL(fedd_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), "libfedd_hip.so does not export %s" % n
+    assert sorted(fedd_lib.SIGNATURES.keys()) == names, "capi.SIGNATURES and include/fedd_hip.h differ"
+
+
+def test_no_cpu_fallback(fedd_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(fedd_lib.FeddError, match="no HIP device|no CPU"):
+        fedd_lib.Context(device=0)
+    c = fedd_lib.Context(device=-1)
+    c.mesh_set_dict(fedd_lib.structured_mesh(3, 1, 2))
+    for call in (lambda: c.pattern_build(), lambda: c.assemble(0), lambda: c.spmv(np.zeros(27)),
+                 lambda: c.schwarz_setup(), lambda: c.sync()):
+        with pytest.raises(fedd_lib.FeddError, match="needs a GPU context"):
+            call()
+    c.close()
+
+
+def test_product_never_imports_oracle():
+    """The product path (feddlib_amd/, include/, bench's timed region) must not route through oracle/."""
+    for base, _, files in os.walk(os.path.join(ROOT, "feddlib_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                src = open(os.path.join(base, f)).read()
+                assert "fedd_oracle" not in src and "oracle_c" not in src and "oracle/" not in src, f
+
+
+@pytest.mark.parametrize("dim,N,M", [(3, 1, 4), (3, 2, 3), (2, 2, 5), (2, 1, 7), (2, 3, 2)])
+def test_structured_generator_matches_oracle(fedd_lib, dim, N, M):
+    for rank in range(N ** dim):
+        m = fedd_lib.structured_mesh(dim, N, M, rank)
+        o = fo.build_mesh_structured(dim, N, M, rank)
+        np.testing.assert_array_equal(m["conn"], o.conn)
+        np.testing.assert_array_equal(m["xyz"], o.xyz)            # bit-equal coordinates
+        np.testing.assert_array_equal(m["gid_rep"], o.gid_rep)
+        np.testing.assert_array_equal(m["gid_uni"], o.gid_uni)
+        np.testing.assert_array_equal(m["flag_uni"], o.flag_uni)
+        np.testing.assert_array_equal(fedd_lib.structured_owner(dim, N, M, m["gid_rep"]),
+                                      fo.structured_owner(dim, N, M, o.gid_rep))
+
+
+def test_structured_generator_errors(fedd_lib):
+    with pytest.raises(fedd_lib.FeddError, match="H/h"):
+        fedd_lib.structured_mesh(3, 1, 0)
+    with pytest.raises(fedd_lib.FeddError, match="rank"):
+        fedd_lib.structured_mesh(3, 2, 2, rank=8)
+    with pytest.raises(fedd_lib.FeddError, match="dimension"):
+        fedd_lib.structured_mesh(1, 1, 2)
+
+
+@pytest.mark.parametrize("dim,dec,M", [(3, (2, 2, 2), 3), (3, (1, 1, 2), 4), (3, (1, 2, 2), 3), (2, (2, 2), 4)])
+def test_ghost_element_layer_completes_owned_rows(fedd_lib, dim, dec, M):
+    """With the ghost-element layer every owned row can be assembled with no matrix exchange, and
+    slab / pencil splits number the same global lattice."""
+    nr = int(np.prod(dec))
+    cells_glob = [d * M for d in dec]
+    assert len(set(cells_glob)) == 1 or True
+    ref_cells = cells_glob
+    ref = fedd_lib.structured_mesh(dim, [1] * dim, ref_cells, 0)
+    oref = fo.Mesh(dim=dim, fe="P1", conn=ref["conn"], xyz=ref["xyz"], gid_rep=ref["gid_rep"], flag_rep=ref["flag_rep"],
+                   gid_uni=ref["gid_uni"], flag_uni=ref["flag_uni"], xyz_uni=None, n_global=ref["n_global"])
+    Aref = fo.assembly_laplace(oref)
+    owned = np.zeros(ref["n_global"], dtype=int)
+    for rank in range(nr):
+        m = fedd_lib.structured_mesh(dim, dec, [M] * dim, rank, ghosts=True)
+        om = fo.Mesh(dim=dim, fe="P1", conn=m["conn"], xyz=m["xyz"], gid_rep=m["gid_rep"], flag_rep=m["flag_rep"],
+                     gid_uni=m["gid_uni"], flag_uni=m["flag_uni"], xyz_uni=None, n_global=m["n_global"])
+        A = fo.assembly_laplace(om)
+        assert abs(A[m["gid_uni"]] - Aref[m["gid_uni"]]).max() < 1e-14
+        np.testing.assert_array_equal(m["xyz"], ref["xyz"][m["gid_rep"]])
+        np.testing.assert_array_equal(m["flag_uni"], ref["flag_uni"][m["gid_uni"]])
+        owned[m["gid_uni"]] += 1
+    assert (owned == 1).all()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, dim, dec, M, q):
+    import torch
+    import torch.distributed as dist
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from feddlib_amd import capi
+    import fedd_oracle as fo2
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = capi.structured_mesh(dim, dec, [M] * dim, rank, ghosts=True)
+        c = capi.Context(device=-1, rank=rank, nranks=world)      # host-only: numbering + halo planning
+        c.mesh_set_dict(m)
+        c.halo_set_owners(m["gid_rep"], capi.structured_owner(dim, dec, [M] * dim, m["gid_rep"]))
+        cnt, gids = c.halo_requests()
+        # all-to-all of the request lists over gloo (what fedd_halo_exchange_setup does over RCCL)
+        cnt_all = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(cnt_all, torch.from_numpy(cnt))
+        from_me = np.array([int(cnt_all[p][rank]) for p in range(world)], dtype=np.int64)
+        recv = [torch.zeros(int(n), dtype=torch.int64) for n in from_me]
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        reqs = []
+        for p in range(world):
+            if p == rank:
+                continue
+            if cnt[p] > 0:
+                reqs.append(dist.isend(torch.from_numpy(gids[off[p]:off[p + 1]].copy()), p))
+            if from_me[p] > 0:
+                reqs.append(dist.irecv(recv[p], p))
+        for r in reqs:
+            r.wait()
+        c.halo_requests_set(from_me, np.concatenate([t.numpy() for t in recv]) if from_me.sum() else np.zeros(0, np.int64))
+        plan = c.halo_plan()
+        # ---- use the plan: distributed SpMV on oracle-assembled owned rows, exchange over gloo ----
+        om = fo2.Mesh(dim=dim, fe="P1", conn=m["conn"], xyz=m["xyz"], gid_rep=m["gid_rep"], flag_rep=m["flag_rep"],
+                      gid_uni=m["gid_uni"], flag_uni=m["flag_uni"], xyz_uni=None, n_global=m["n_global"])
+        A = fo2.assembly_laplace(om)[m["gid_uni"]]                 # owned rows, global columns
+        n_own = m["gid_uni"].shape[0]
+        # the library's column-local numbering: owned in unique order, ghosts by ascending gid
+        ghost_gid = np.setdiff1d(m["gid_rep"], m["gid_uni"])
+        node_gid = np.concatenate([m["gid_uni"], ghost_gid])
+        rng = np.random.default_rng(5)
+        xg = rng.standard_normal(m["n_global"])                    # same on all ranks (same seed)
+        xcol = np.zeros(node_gid.shape[0])
+        xcol[:n_own] = xg[m["gid_uni"]]
+        reqs = []
+        bufs = {}
+        for k, p in enumerate(plan["peers"]):
+            s0, s1 = plan["send_ptr"][k], plan["send_ptr"][k + 1]
+            r0, r1 = plan["recv_ptr"][k], plan["recv_ptr"][k + 1]
+            if s1 > s0:
+                reqs.append(dist.isend(torch.from_numpy(xcol[plan["send_lid"][s0:s1]].copy()), int(p)))
+            if r1 > r0:
+                bufs[k] = torch.zeros(int(r1 - r0), dtype=torch.float64)
+                reqs.append(dist.irecv(bufs[k], int(p)))
+        for r in reqs:
+            r.wait()
+        for k, b in bufs.items():
+            r0, r1 = plan["recv_ptr"][k], plan["recv_ptr"][k + 1]
+            xcol[plan["recv_lid"][r0:r1]] = b.numpy()
+        ok_ghost = np.array_equal(xcol, xg[node_gid])
+        y = A[:, node_gid] @ xcol
+        y_ref = A @ xg
+        # all-reduced dot product, as GMRES does
+        loc = torch.tensor([float(y @ y)], dtype=torch.float64)
+        dist.all_reduce(loc)
+        q.put((rank, ok_ghost, float(np.abs(y - y_ref).max()), float(loc.item()), int(plan["peers"].shape[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dim,dec,M", [(3, (1, 1, 2), 3), (2, (2, 1), 4)])
+def test_two_rank_halo_plan_over_gloo(fedd_lib, dim, dec, M):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, dim, dec, M, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # reference: global matrix applied to the same vector
+    ref = fedd_lib.structured_mesh(dim, [1] * dim, [d * M for d in dec], 0)
+    oref = fo.Mesh(dim=dim, fe="P1", conn=ref["conn"], xyz=ref["xyz"], gid_rep=ref["gid_rep"], flag_rep=ref["flag_rep"],
+                   gid_uni=ref["gid_uni"], flag_uni=ref["flag_uni"], xyz_uni=None, n_global=ref["n_global"])
+    xg = np.random.default_rng(5).standard_normal(ref["n_global"])
+    yy = fo.assembly_laplace(oref) @ xg
+    for rank, ok_ghost, err, dot, npeers in res:
+        assert ok_ghost, "ghost values after the halo import differ"
+        assert err < 1e-13
+        assert npeers == 1
+        np.testing.assert_allclose(dot, yy @ yy, rtol=1e-12)

@@ -1,0 +1,232 @@
+"""Pins the CPU oracle with analytic known answers.  The reference has no
+golden numbers and cannot be built here, so these are the strongest anchors available."""
+import os
+
+import numpy as np
+import pytest
+
+import fedd_oracle as fo
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_csr(d, p, n):
+    import scipy.sparse as sp
+    return sp.csr_matrix((d[p + "_data"], d[p + "_indices"], d[p + "_indptr"]), shape=(n, n))
+
+
+def test_reference_tet_stiffness_mass_rhs():
+    m = fo.read_mesh_file(os.path.join(GOLD, "tetrahedron.mesh"), 3, volume_id=0)
+    if m.conn.shape[0] != 1:     # whatever flag the file carries, keep its single element
+        m = fo.read_mesh_file(os.path.join(GOLD, "tetrahedron.mesh"), 3, volume_id=int(m.elem_flag[0]))
+    assert m.conn.shape == (1, 4)
+    K = fo.assembly_laplace(m).toarray()
+    Kexp = np.array([[3, -1, -1, -1], [-1, 1, 0, 0], [-1, 0, 1, 0], [-1, 0, 0, 1]]) / 6.0
+    np.testing.assert_allclose(K, Kexp, atol=1e-15)
+    Mm = fo.assembly_mass(m).toarray()
+    np.testing.assert_allclose(Mm, (1 + np.eye(4)) / 120.0, rtol=1e-14)
+    np.testing.assert_allclose(fo.assembly_rhs(m, [1.0]), np.full(4, 1 / 24.0), rtol=1e-14)
+
+
+@pytest.mark.parametrize("dim,deg,exact", [(2, 1, 1), (2, 2, 2), (2, 5, 5), (3, 1, 1), (3, 3, 3), (3, 5, 5)])
+def test_quadrature_exactness(dim, deg, exact):
+    pts, w = fo.quadrature(dim, deg)
+    np.testing.assert_allclose(w.sum(), 1 / 2.0 if dim == 2 else 1 / 6.0, rtol=1e-13)
+    from math import factorial
+    import itertools
+    for e in itertools.product(range(exact + 1), repeat=dim):
+        if sum(e) > exact:
+            continue
+        val = (w * np.prod(pts ** np.array(e), axis=1)).sum()
+        ex = np.prod([factorial(k) for k in e]) / factorial(sum(e) + dim)
+        tol = 1e-13 if not (dim == 2 and deg == 5) else 5e-13     # 15-digit tabulated constants
+        assert abs(val - ex) < tol, (e, val, ex)
+
+
+def test_quadrature_degree_remaps():
+    assert fo.quadrature(3, 2)[1].shape[0] == 5 and fo.quadrature(3, 4)[1].shape[0] == 15
+    assert fo.quadrature(2, 3)[1].shape[0] == 7 and fo.quadrature(2, 4)[1].shape[0] == 7
+
+
+@pytest.mark.parametrize("dim,fe", [(2, "P1"), (2, "P2"), (3, "P1"), (3, "P2")])
+def test_partition_of_unity_and_nodal_basis(dim, fe):
+    pts, _ = fo.quadrature(dim, 5)
+    np.testing.assert_allclose(fo.phi(dim, fe, pts).sum(axis=1), 1.0, atol=1e-14)
+    np.testing.assert_allclose(fo.grad_phi(dim, fe, pts).sum(axis=1), 0.0, atol=1e-13)
+    # Lagrange property at the nodes (vertex + edge-midpoint order of the reference)
+    V = np.vstack([np.zeros(dim), np.eye(dim)])
+    nodes = [V[i] for i in range(dim + 1)]
+    if fe == "P2":
+        edges = [(0, 1), (1, 2), (0, 2)] if dim == 2 else [(0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3)]
+        nodes += [(V[a] + V[b]) / 2 for a, b in edges]
+    np.testing.assert_allclose(fo.phi(dim, fe, np.array(nodes)), np.eye(len(nodes)), atol=1e-14)
+    # gradients are the derivatives of phi (central differences)
+    p = np.full((1, dim), 0.21)
+    g = fo.grad_phi(dim, fe, p)[0]
+    for d in range(dim):
+        e = np.zeros((1, dim)); e[0, d] = 1e-6
+        fd = (fo.phi(dim, fe, p + e) - fo.phi(dim, fe, p - e))[0] / 2e-6
+        np.testing.assert_allclose(g[:, d], fd, atol=1e-8)
+
+
+def test_determine_degree():
+    assert fo.determine_degree("P1", "P1", "Grad", "Grad") == 1
+    assert fo.determine_degree("P2", "P2", "Grad", "Grad") == 2
+    assert fo.determine_degree("P1", "P1", "Std", "Std") == 2
+    assert fo.determine_degree("P2", "P2", "Std", "Std") == 4
+    assert fo.determine_degree("P2", "P1", "Grad", "Std") == 2
+
+
+def test_kuhn_cube_stencil_and_orientation():
+    M = 4
+    m = fo.build_mesh_structured(3, 1, M)
+    h = 1.0 / M
+    det = fo.det_small(fo.build_transformation(m))
+    np.testing.assert_allclose(np.abs(det), h ** 3, rtol=1e-12)
+    assert (det > 0).any() and (det < 0).any()
+    A = fo.assembly_laplace(m)
+    P = M + 1
+    assert A.nnz == P ** 3 + 2 * (3 * M * P * P + 3 * M * M * P + M ** 3)
+    c = 2 + 2 * P + 2 * P * P
+    row = A[c].toarray().ravel()
+    assert A[c].nnz == 15
+    np.testing.assert_allclose(row[c], 6 * h, rtol=1e-13)
+    for off in (1, P, P * P):
+        np.testing.assert_allclose([row[c - off], row[c + off]], -h, rtol=1e-13)
+    others = np.setdiff1d(A[c].indices, [c, c - 1, c + 1, c - P, c + P, c - P * P, c + P * P])
+    assert others.shape[0] == 8 and np.abs(row[others]).max() < 1e-15     # structural zeros kept
+    assert np.abs(A @ np.ones(P ** 3)).max() < 1e-14
+    assert abs(A - A.T).max() < 1e-15
+
+
+def test_square_stencil():
+    M = 6
+    m = fo.build_mesh_structured(2, 1, M)
+    A = fo.assembly_laplace(m)
+    P = M + 1
+    c = 3 + 3 * P
+    row = A[c].toarray().ravel()
+    assert A[c].nnz == 7
+    np.testing.assert_allclose(row[c], 4.0, rtol=1e-13)
+    np.testing.assert_allclose([row[c - 1], row[c + 1], row[c - P], row[c + P]], -1.0, rtol=1e-13)
+
+
+def test_loop_restatement_equals_vectorised():
+    for dim, M in [(2, 3), (3, 2)]:
+        m = fo.build_mesh_structured(dim, 1, M)
+        assert abs(fo.assembly_laplace(m) - fo.assembly_laplace_loops(m)).max() < 1e-15
+
+
+def test_elasticity_rigid_body_modes():
+    m = fo.build_mesh_structured(3, 1, 3)
+    A = fo.assembly_linelas(m, lam=3.0, mu=2.0)
+    assert abs(A - A.T).max() < 1e-13
+    X = m.xyz
+    modes = []
+    for d in range(3):
+        t = np.zeros_like(X); t[:, d] = 1.0; modes.append(t.ravel())
+    for a, b in [(0, 1), (1, 2), (0, 2)]:
+        r = np.zeros_like(X); r[:, a] = -X[:, b]; r[:, b] = X[:, a]; modes.append(r.ravel())
+    for v in modes:
+        assert np.abs(A @ v).max() < 1e-12
+    assert A.nnz == 9 * fo.assembly_laplace(m).nnz
+
+
+def test_p2_build_and_stokes_blocks():
+    m1 = fo.read_mesh_file(os.path.join(GOLD, "DFG3DCylinder_1k.mesh"), 3, volume_id=0)
+    m2 = fo.build_p2_of_p1(m1)
+    assert m2.conn.shape[1] == 10
+    # P2 stiffness: rows sum to zero, symmetric; mass integrates the volume
+    K = fo.assembly_laplace(m2)
+    assert np.abs(K @ np.ones(K.shape[0])).max() < 1e-11
+    Mm = fo.assembly_mass(m2)
+    vol = np.abs(fo.det_small(fo.build_transformation(m1))).sum() / 6.0
+    np.testing.assert_allclose(Mm.sum(), vol, rtol=1e-12)
+    B, BT = fo.assembly_div_and_divt(m2, m1)
+    assert abs(B - BT.T).max() < 1e-14
+    # divergence of a constant field vanishes: B @ const = 0
+    u = np.tile([1.0, -2.0, 0.5], m2.n_global)
+    assert np.abs(B @ u).max() < 1e-12
+    # divergence of u = (x, 0, 0) is 1: sum_j B_ij u_j = int psi_i
+    u = np.zeros(3 * m2.n_global); u[0::3] = m2.xyz[:, 0]
+    np.testing.assert_allclose(B @ u, fo.assembly_rhs(m1, [1.0]), atol=1e-12)
+
+
+def test_structured_global_numbering_consistent_across_ranks():
+    for dim, N, M in [(3, 2, 2), (2, 3, 2)]:
+        g = fo.build_mesh_structured_global(dim, N, M)
+        seen = np.zeros(g.n_global, dtype=int)
+        meshes = [fo.build_mesh_structured(dim, N, M, r) for r in range(N ** dim)]
+        for mm in meshes:
+            np.testing.assert_array_equal(mm.xyz, g.xyz[mm.gid_rep])         # bit-equal coordinates
+            seen[mm.gid_uni] += 1
+            np.testing.assert_array_equal(mm.flag_uni, g.flag_uni[mm.gid_uni])
+        assert (seen == 1).all()                                             # every node owned exactly once
+        A_bc, rhs_bc, A, rhs, flags = fo.laplace_problem(meshes)
+        A_bc1, rhs_bc1, A1, rhs1, flags1 = fo.laplace_problem(g)
+        assert abs(A - A1).max() < 1e-14 and np.abs(rhs - rhs1).max() < 1e-15
+        assert abs(A_bc - A_bc1).max() < 1e-14
+
+
+def test_structured_flags_3d():
+    m = fo.build_mesh_structured(3, 1, 4)
+    X, f = m.xyz_uni, m.flag_uni
+    assert (f[X[:, 0] == 0] == 2).all()
+    inner_face = (X[:, 0] == 1) & (X[:, 1] > 0) & (X[:, 1] < 1) & (X[:, 2] > 0) & (X[:, 2] < 1)
+    assert (f[inner_face] == 3).all()
+    interior = np.all((X > 0) & (X < 1), axis=1)
+    assert (f[interior] == 0).all() and (f[~interior] > 0).all()
+    assert (interior.sum()) == 27
+
+
+def test_dirichlet_rows_keep_pattern_and_columns():
+    m = fo.build_mesh_structured(3, 1, 3)
+    A_bc, rhs_bc, A, rhs, flags = fo.laplace_problem(m)
+    assert A_bc.nnz == A.nnz                                 # pattern kept (structural zeros)
+    bnd = flags > 0
+    D = A_bc[bnd].toarray()
+    assert np.array_equal(D, np.eye(A.shape[0])[bnd])
+    assert abs(A_bc - A_bc.T).max() > 0                      # columns not eliminated -> non-symmetric
+    assert np.all(rhs_bc[bnd] == 0.0)
+
+
+def test_golden_fixtures_reproduce():
+    d = np.load(os.path.join(GOLD, "laplace_square_mesh.npz"))
+    m = fo.read_mesh_file(os.path.join(GOLD, "square.mesh"), 2, volume_id=10)
+    assert m.xyz.shape == (29, 2) and m.conn.shape == (40, 3)
+    A_bc, rhs_bc, A, rhs, flags = fo.laplace_problem(m, bc_flags=(1, 2, 3))
+    assert abs(A_bc - load_csr(d, "Abc", 29)).max() < 1e-14
+    np.testing.assert_allclose(rhs_bc, d["rhs_bc"], atol=1e-15)
+    np.testing.assert_allclose(fo.direct_solve(A_bc, rhs_bc), d["x"], atol=1e-13)
+    # the three left-edge interior nodes (flag 4) stay natural-Neumann
+    assert (flags == 4).sum() == 3 and np.abs(A_bc[flags == 4].toarray().sum(axis=1)).max() < 1e-13
+    d = np.load(os.path.join(GOLD, "laplace_cube_N2M2.npz"))
+    for r in range(8):
+        mm = fo.build_mesh_structured(3, 2, 2, r)
+        np.testing.assert_array_equal(mm.conn, d["conn_%d" % r])
+        np.testing.assert_array_equal(mm.gid_rep, d["gid_rep_%d" % r])
+        np.testing.assert_array_equal(mm.gid_uni, d["gid_uni_%d" % r])
+        np.testing.assert_array_equal(mm.xyz, d["xyz_%d" % r])
+    d = np.load(os.path.join(GOLD, "linelas_cube_M3.npz"))
+    A_bc, rhs_bc, A, rhs, flags = fo.linelas_problem(fo.build_mesh_structured(3, 1, 3), 2.0e6, 0.4)
+    assert abs(A - load_csr(d, "A", A.shape[0])).max() < 1e-9 * abs(A).max()
+
+
+def test_solver_invariants():
+    m = fo.build_mesh_structured(3, 1, 8)
+    A_bc, rhs_bc, _, _, _ = fo.laplace_problem(m)
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    nb_, nb, g = fo.schwarz_bins(m.xyz_uni, 27)
+    for combine in ("restricted", "averaging", "full"):
+        ras = fo.RAS(A_bc, nb_, nb, combine=combine)
+        x, its, hist = fo.gmres_right(A_bc, rhs_bc, ras.apply, rtol=1e-13, max_it=200, restart=200)
+        np.testing.assert_allclose(x, xd, atol=1e-10 * np.abs(xd).max())
+        assert all(hist[i + 1] <= hist[i] * (1 + 1e-12) for i in range(len(hist) - 1))    # monotone
+    # one subdomain + exact local solve => one iteration
+    ras = fo.RAS(A_bc, np.zeros(m.n_global, dtype=np.int64), 1)
+    x, its, hist = fo.gmres_right(A_bc, rhs_bc, ras.apply, rtol=1e-12)
+    assert its == 1
+    np.testing.assert_allclose(x, xd, atol=1e-12)
+    # restarted, unpreconditioned
+    x, its, hist = fo.gmres_right(A_bc, rhs_bc, None, rtol=1e-12, max_it=2000, restart=9)
+    np.testing.assert_allclose(x, xd, atol=1e-9 * np.abs(xd).max())
