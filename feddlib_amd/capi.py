@@ -52,6 +52,7 @@ SIGNATURES = {
     "fedd_schwarz_apply_device": [C.c_void_p, C.c_int],
     "fedd_schwarz_info": [C.c_void_p, _i64p, _i64p, _i64p],
     "fedd_gmres": [C.c_void_p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int, _ip, _f64p],
+    "fedd_set_option": [C.c_void_p, C.c_char_p, C.c_double],
     "fedd_timing_enable": [C.c_void_p, C.c_int],
     "fedd_timing_reset": [C.c_void_p],
     "fedd_timing_get": [C.c_void_p, C.c_int, _f64p, _i64p],
@@ -269,6 +270,9 @@ class Context:
         _chk(self._L.fedd_gmres(self._h, _p(bb, _f64p), _p(x, _f64p), rtol, max_it, restart, int(use_prec),
                                 C.byref(its), C.byref(rel)))
         return x, its.value, rel.value
+
+    def set_option(self, key, value):
+        _chk(self._L.fedd_set_option(self._h, key.encode(), float(value)))
 
     def timing_enable(self, on=True):
         _chk(self._L.fedd_timing_enable(self._h, int(on)))

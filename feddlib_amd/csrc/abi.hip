@@ -406,6 +406,14 @@ extern "C" int fedd_gmres(fedd_ctx* c, const double* b_owned, double* x_owned, d
     return 0;
 }
 
+extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
+    FEDD_CHECK(c && key, "fedd_set_option: null");
+    const std::string k(key);
+    if (k == "spmv_kind") c->spmv_kind = (int)value;
+    else FEDD_CHECK(false, "fedd_set_option: unknown key '%s'", key);
+    return 0;
+}
+
 extern "C" int fedd_timing_enable(fedd_ctx* c, int on) {
     NEED_DEVICE(c);
     c->timing = on != 0;

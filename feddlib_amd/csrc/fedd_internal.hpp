@@ -118,6 +118,7 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_xcol, d_ycol;        // [n_cols] work vectors with ghost tail
     fedd::DevBuf<int32_t> d_isdir;              // [n_rows] 1 = Dirichlet row
     bool have_pattern = false;
+    int spmv_kind = 0;                          // 0 = CSR-stream kernel, 1 = row-per-lane-group kernel
 
     // ---- Schwarz ----
     int sw_target = 27;

@@ -20,35 +20,68 @@
 namespace fedd {
 namespace {
 
-constexpr int DOT_BLOCKS = 512;
+constexpr int MD_ROWS = 2048;  // rows per workgroup of the multi-dot (256 lanes x 4 x double2)
+constexpr int MD_CG = 8;       // basis columns per workgroup of the multi-dot
+constexpr int AX_ROWS = 512;   // rows per workgroup of the multi-axpy (256 lanes x double2)
 
-// partial[col*DOT_BLOCKS + blk] = sum over the block's rows of V_col . w ; col == ncolsV means w . w
-__global__ __launch_bounds__(256) void k_multidot(const double* __restrict__ V, int64_t n, int ncolsV,
+__device__ __forceinline__ double2 ld2(const double* __restrict__ p, int64_t r, int64_t n) {
+    if (r + 1 < n) return *reinterpret_cast<const double2*>(p + r);
+    double2 v;
+    v.x = r < n ? p[r] : 0.0;
+    v.y = 0.0;
+    return v;
+}
+
+// partial[col*nblk + blk] = sum over the workgroup's rows of V_col . w ; col == ncolsV means w . w.
+// A workgroup keeps its 2048 rows of w in registers and sweeps MD_CG basis columns, so the basis
+// is read from HBM exactly once per pass with 16-byte loads; w is re-read from L2.
+__global__ __launch_bounds__(256) void k_multidot(const double* __restrict__ V, int64_t ldv, int64_t n, int ncolsV,
                                                   const double* __restrict__ w, double* __restrict__ partial,
-                                                  const int32_t* __restrict__ gate) {
+                                                  int nblk, const int32_t* __restrict__ gate) {
     if (gate && !*gate) return;
-    __shared__ double sh[256];
-    const int col = blockIdx.y;
-    const double* __restrict__ a = col < ncolsV ? V + (int64_t)col * n : w;
-    double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)DOT_BLOCKS * 256) s += a[i] * w[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
-        __syncthreads();
+    __shared__ double sh[4][MD_CG];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * MD_ROWS + 2 * tid;
+    double2 wv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv[k] = ld2(w, r0 + 512 * k, n);
+    double acc[MD_CG];
+#pragma unroll
+    for (int cc = 0; cc < MD_CG; ++cc) {
+        const int col = blockIdx.y * MD_CG + cc;
+        double s = 0.0;
+        if (col <= ncolsV) {
+            const double* __restrict__ a = col < ncolsV ? V + (int64_t)col * ldv : w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double2 v = ld2(a, r0 + 512 * k, n);
+                s += v.x * wv[k].x + v.y * wv[k].y;
+            }
+        }
+        acc[cc] = s;
     }
-    if (threadIdx.x == 0) partial[(int64_t)col * DOT_BLOCKS + blockIdx.x] = sh[0];
+#pragma unroll
+    for (int cc = 0; cc < MD_CG; ++cc) {
+        double s = acc[cc];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((tid & 63) == 0) sh[tid >> 6][cc] = s;
+    }
+    __syncthreads();
+    if (tid < MD_CG) {
+        const int col = blockIdx.y * MD_CG + tid;
+        if (col <= ncolsV) partial[(int64_t)col * nblk + blockIdx.x] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+    }
 }
 
 // out[col] = sum_blk partial[col][blk]   (one workgroup per column, fixed order)
 __global__ __launch_bounds__(256) void k_reduce_cols(const double* __restrict__ partial, double* __restrict__ out,
-                                                     const int32_t* __restrict__ gate) {
+                                                     int nblk, const int32_t* __restrict__ gate) {
     if (gate && !*gate) return;
     __shared__ double sh[256];
     const int col = blockIdx.x;
     double s = 0.0;
-    for (int k = threadIdx.x; k < DOT_BLOCKS; k += 256) s += partial[(int64_t)col * DOT_BLOCKS + k];
+    for (int k = threadIdx.x; k < nblk; k += 256) s += partial[(int64_t)col * nblk + k];
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) {
@@ -58,26 +91,48 @@ __global__ __launch_bounds__(256) void k_reduce_cols(const double* __restrict__ 
     if (threadIdx.x == 0) out[col] = sh[0];
 }
 
-// w -= sum_c h[c] V_c ; also partial sums of ||w_new||^2 into partial[blk]
-__global__ __launch_bounds__(256) void k_multiaxpy(const double* __restrict__ V, int64_t n, int ncols,
+// w -= sum_c h[c] V_c ; also partial sums of ||w_new||^2 into partial[blk].  One double2 of w per
+// lane, the column loop unrolled 8x keeps 8 x 16 B loads in flight per lane.
+__global__ __launch_bounds__(256) void k_multiaxpy(const double* __restrict__ V, int64_t ldv, int64_t n, int ncols,
                                                    const double* __restrict__ h, double* __restrict__ w,
                                                    double* __restrict__ partial, const int32_t* __restrict__ gate) {
     if (gate && !*gate) return;
-    __shared__ double sh[256];
-    double nrm = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)DOT_BLOCKS * 256) {
-        double v = w[i];
-        for (int c = 0; c < ncols; ++c) v -= h[c] * V[(int64_t)c * n + i];
-        w[i] = v;
-        nrm += v * v;
-    }
-    sh[threadIdx.x] = nrm;
+    __shared__ double sh_h[1024];
+    __shared__ double sh[4];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < ncols; c += 256) sh_h[c] = h[c];
     __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
-        __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * AX_ROWS + 2 * tid;
+    double2 v = ld2(w, r, n);
+    int c = 0;
+    for (; c + 8 <= ncols; c += 8) {
+        double2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = ld2(V + (int64_t)(c + u) * ldv, r, n);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v.x -= sh_h[c + u] * t[u].x;
+            v.y -= sh_h[c + u] * t[u].y;
+        }
     }
-    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+    for (; c < ncols; ++c) {
+        const double2 t = ld2(V + (int64_t)c * ldv, r, n);
+        v.x -= sh_h[c] * t.x;
+        v.y -= sh_h[c] * t.y;
+    }
+    double nrm = 0.0;
+    if (r + 1 < n) {
+        *reinterpret_cast<double2*>(w + r) = v;
+        nrm = v.x * v.x + v.y * v.y;
+    } else if (r < n) {
+        w[r] = v.x;
+        nrm = v.x * v.x;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+    if ((tid & 63) == 0) sh[tid >> 6] = nrm;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
 // scalars layout in d_small (doubles): see Offsets below
@@ -148,12 +203,12 @@ __global__ void k_backsolve(double* __restrict__ S, Off o, int k, int m) {
 }
 
 // u = sum_c y[c] V_c
-__global__ __launch_bounds__(256) void k_combine(const double* __restrict__ V, int64_t n, int k,
+__global__ __launch_bounds__(256) void k_combine(const double* __restrict__ V, int64_t ldv, int64_t n, int k,
                                                  const double* __restrict__ y, double* __restrict__ u) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double v = 0.0;
-    for (int c = 0; c < k; ++c) v += y[c] * V[(int64_t)c * n + i];
+    for (int c = 0; c < k; ++c) v += y[c] * V[(int64_t)c * ldv + i];
     u[i] = v;
 }
 
@@ -177,10 +232,13 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
                 int* its_out, double* relres_out) {
     const int64_t n = c->n_rows;
     const int m = std::min(restart, max_it);
-    FEDD_TRY(c->d_V.ensure((size_t)(m + 1) * n));
+    const int64_t ldv = (n + 15) & ~(int64_t)15;  // 128-byte aligned basis columns
+    FEDD_CHECK(m + 2 <= 1024, "gmres: restart length above 1022 is not supported");
+    const int nblk = (int)((n + MD_ROWS - 1) / MD_ROWS), nblk2 = (int)((n + AX_ROWS - 1) / AX_ROWS);
+    FEDD_TRY(c->d_V.ensure((size_t)(m + 1) * ldv));
     FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)n, c->d_w.cap)));
     FEDD_TRY(c->d_Z.ensure((size_t)n * 2));
-    FEDD_TRY(c->d_part.ensure((size_t)(m + 2) * DOT_BLOCKS));
+    FEDD_TRY(c->d_part.ensure(std::max((size_t)(m + 2) * nblk, (size_t)nblk2)));
     Off o;
     int p = 0;
     o.H = p; p += (m + 1) * m;
@@ -204,8 +262,8 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
     hipStream_t st = c->stream;
 
     auto norm2_into = [&](const double* v, double* out) -> int {  // out[0] = v.v (global)
-        hipLaunchKernelGGL(k_multidot, dim3(DOT_BLOCKS, 1), blk, 0, st, v, n, 0, v, c->d_part.p, (const int32_t*)nullptr);
-        hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, out, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(k_multidot, dim3(nblk, 1), blk, 0, st, v, ldv, n, 0, v, c->d_part.p, nblk, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, out, nblk, (const int32_t*)nullptr);
         return allreduce_sum(c, out, 1);
     };
     auto residual = [&]() -> int {  // r = b - A x
@@ -233,42 +291,42 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
         hipLaunchKernelGGL(k_scale_to, gn, blk, 0, st, (const double*)r, (const double*)(S + o.misc + 1), V, n);
         int k = 0;
         for (int j = 0; j < m && its < max_it; ++j) {
-            const double* vj = V + (int64_t)j * n;
+            const double* vj = V + (int64_t)j * ldv;
             if (use_prec) FEDD_TRY(schwarz_apply(c, vj, z));
             FEDD_TRY(spmv_owned(c, use_prec ? z : vj, w));
             {
                 ScopedTimer t(c, FEDD_T_ORTHO);
                 // pass 1: h1 = V^T w, nrm[0] = w.w ; w -= V h1, nrm[1] = ||w||^2
-                hipLaunchKernelGGL(k_multidot, dim3(DOT_BLOCKS, j + 2), blk, 0, st, (const double*)V, n, j + 1,
-                                   (const double*)w, c->d_part.p, (const int32_t*)nullptr);
-                hipLaunchKernelGGL(k_reduce_cols, dim3(j + 2), blk, 0, st, (const double*)c->d_part.p, S + o.h1,
+                hipLaunchKernelGGL(k_multidot, dim3(nblk, (j + 2 + MD_CG - 1) / MD_CG), blk, 0, st, (const double*)V, ldv, n,
+                                   j + 1, (const double*)w, c->d_part.p, nblk, (const int32_t*)nullptr);
+                hipLaunchKernelGGL(k_reduce_cols, dim3(j + 2), blk, 0, st, (const double*)c->d_part.p, S + o.h1, nblk,
                                    (const int32_t*)nullptr);
                 FEDD_TRY(allreduce_sum(c, S + o.h1, j + 2));
                 // h1[j+1] holds w.w -> move to nrm[0] is implicit: k_dgks_gate reads nrm[], so copy
                 FEDD_HIP(hipMemcpyAsync(S + o.nrm, S + o.h1 + j + 1, sizeof(double), hipMemcpyDeviceToDevice, st));
-                hipLaunchKernelGGL(k_multiaxpy, dim3(DOT_BLOCKS), blk, 0, st, (const double*)V, n, j + 1,
+                hipLaunchKernelGGL(k_multiaxpy, dim3(nblk2), blk, 0, st, (const double*)V, ldv, n, j + 1,
                                    (const double*)(S + o.h1), w, c->d_part.p, (const int32_t*)nullptr);
-                hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, S + o.nrm + 1,
+                hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, S + o.nrm + 1, nblk2,
                                    (const int32_t*)nullptr);
                 FEDD_TRY(allreduce_sum(c, S + o.nrm + 1, 1));
                 hipLaunchKernelGGL(k_dgks_gate, dim3(1), dim3(1), 0, st, (const double*)(S + o.nrm), gate);
                 // pass 2 (gated on the device; on several ranks the gate is identical everywhere
                 // because it is computed from all-reduced numbers, so the collectives stay matched)
-                hipLaunchKernelGGL(k_multidot, dim3(DOT_BLOCKS, j + 1), blk, 0, st, (const double*)V, n, j + 1,
-                                   (const double*)w, c->d_part.p, (const int32_t*)gate);
-                hipLaunchKernelGGL(k_reduce_cols, dim3(j + 1), blk, 0, st, (const double*)c->d_part.p, S + o.h2,
+                hipLaunchKernelGGL(k_multidot, dim3(nblk, (j + 2 + MD_CG - 1) / MD_CG), blk, 0, st, (const double*)V, ldv, n,
+                                   j + 1, (const double*)w, c->d_part.p, nblk, (const int32_t*)gate);
+                hipLaunchKernelGGL(k_reduce_cols, dim3(j + 1), blk, 0, st, (const double*)c->d_part.p, S + o.h2, nblk,
                                    (const int32_t*)gate);
                 FEDD_TRY(allreduce_sum(c, S + o.h2, j + 1));
-                hipLaunchKernelGGL(k_multiaxpy, dim3(DOT_BLOCKS), blk, 0, st, (const double*)V, n, j + 1,
+                hipLaunchKernelGGL(k_multiaxpy, dim3(nblk2), blk, 0, st, (const double*)V, ldv, n, j + 1,
                                    (const double*)(S + o.h2), w, c->d_part.p, (const int32_t*)gate);
-                hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, S + o.nrm + 2,
+                hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, S + o.nrm + 2, nblk2,
                                    (const int32_t*)gate);
                 FEDD_TRY(allreduce_sum(c, S + o.nrm + 2, 1));
                 t.stop();
             }
             hipLaunchKernelGGL(k_givens, dim3(1), dim3(1), 0, st, S, o, j, m, (const int32_t*)gate);
             hipLaunchKernelGGL(k_scale_to, gn, blk, 0, st, (const double*)w, (const double*)(S + o.misc + 1),
-                               V + (int64_t)(j + 1) * n, n);
+                               V + (int64_t)(j + 1) * ldv, n);
             FEDD_HIP(hipMemcpyAsync(c->h_pinned, S + o.misc, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
             FEDD_HIP(hipStreamSynchronize(st));
             ++its;
@@ -282,7 +340,7 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
         }
         // x += M^-1 (V y)
         hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(1), 0, st, S, o, k, m);
-        hipLaunchKernelGGL(k_combine, gn, blk, 0, st, (const double*)V, n, k, (const double*)(S + o.y), r);
+        hipLaunchKernelGGL(k_combine, gn, blk, 0, st, (const double*)V, ldv, n, k, (const double*)(S + o.y), r);
         if (use_prec) {
             FEDD_TRY(schwarz_apply(c, r, z));
             hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)z, d_x, n);

@@ -194,10 +194,130 @@ __device__ __forceinline__ int bsearch_i32(const int32_t* a, int n, int32_t v) {
     return -1;
 }
 
+// Register-tiled Gauss-Jordan inversion of one subdomain matrix per workgroup, n <= 16*T.
+// The 256 threads form a 16 x 16 grid; thread (ty, tx) keeps the cyclic sub-matrix
+// A[ty + 16 a][tx + 16 b], a, b < T, in registers for the whole elimination (T*T f64 = 2 T^2 VGPRs).
+// Per pivot k = 16 kb + kc: the owners of column k / row k publish them through a double-buffered
+// LDS line (one barrier per pivot), every thread then does T*T FMAs.  The pivot's tile index kb
+// is a compile-time constant (outer loop unrolled), so no register array is indexed dynamically.
+// Rows/columns n..16T-1 are identity padding.  No pivoting: see k_invert's note.
+template <int T>
+__global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict__ sub_n,
+                                                       const int32_t* __restrict__ sub_nown,
+                                                       const int32_t* __restrict__ sub_dofs,
+                                                       const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ colind,
+                                                       const double* __restrict__ val, int32_t n_rows,
+                                                       int restricted, const int64_t* __restrict__ inv_ptr,
+                                                       double* __restrict__ inv, int32_t* __restrict__ bad,
+                                                       int n_lo, int n_hi) {
+    constexpr int NP = 16 * T;
+    __shared__ int32_t sdof[NP];
+    __shared__ double stage[16][NP + 1];
+    __shared__ double colbuf[2][NP], rowbuf[2][NP];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = sub_n[b];
+    if (n <= n_lo || n > n_hi) return;  // another size class handles this subdomain
+    const int no = sub_nown[b];
+    const int ty = tid & 15, tx = tid >> 4;
+    for (int k = tid; k < NP; k += 256) sdof[k] = k < n ? sub_dofs[(int64_t)b * NMAX + k] : -1;
+    __syncthreads();
+    double A[T][T];
+    // ---- dense extraction, 16 rows at a time through the LDS stage ----
+#pragma unroll
+    for (int a = 0; a < T; ++a) {
+        for (int e = tid; e < 16 * (NP + 1); e += 256) (&stage[0][0])[e] = 0.0;
+        __syncthreads();
+        {
+            const int r = tid >> 4, l = tid & 15;
+            const int i = r + 16 * a;
+            if (i < n) {
+                const int32_t g = sdof[i];
+                if (g < n_rows) {
+                    for (int32_t p = rowptr[g] + l; p < rowptr[g + 1]; p += 16) {
+                        const int32_t col = colind[p];
+                        int cidx = bsearch_i32(sdof, no, col);
+                        if (cidx < 0) {
+                            cidx = bsearch_i32(sdof + no, n - no, col);
+                            if (cidx >= 0) cidx += no;
+                        }
+                        if (cidx >= 0) stage[r][cidx] = val[p];
+                    }
+                } else if (l == 0) {
+                    stage[r][i] = 1.0;  // ghost row (not stored on this rank): identity
+                }
+            } else if (l == 0) {
+                stage[r][i] = 1.0;  // padding
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int bb = 0; bb < T; ++bb) A[a][bb] = stage[ty][tx + 16 * bb];
+        __syncthreads();
+    }
+    // ---- elimination ----
+    bool singular = false;
+#pragma unroll
+    for (int kb = 0; kb < T; ++kb) {
+        for (int kc = 0; kc < 16; ++kc) {
+            const int k = 16 * kb + kc;
+            if (k >= n) break;
+            const int buf = k & 1;
+            if (tx == kc) {
+#pragma unroll
+                for (int a = 0; a < T; ++a) colbuf[buf][ty + 16 * a] = A[a][kb];
+            }
+            if (ty == kc) {
+#pragma unroll
+                for (int bb = 0; bb < T; ++bb) rowbuf[buf][tx + 16 * bb] = A[kb][bb];
+            }
+            __syncthreads();
+            const double piv = rowbuf[buf][k];
+            singular = singular || !(fabs(piv) > 1e-300);
+            const double pinv = 1.0 / piv;
+            double cc[T], rr[T];
+#pragma unroll
+            for (int a = 0; a < T; ++a) cc[a] = colbuf[buf][ty + 16 * a];
+#pragma unroll
+            for (int bb = 0; bb < T; ++bb) rr[bb] = rowbuf[buf][tx + 16 * bb] * pinv;
+            if (ty == kc) {
+                cc[kb] = -1.0;
+#pragma unroll
+                for (int bb = 0; bb < T; ++bb) A[kb][bb] = 0.0;
+            }
+            if (tx == kc) {
+                rr[kb] = pinv;
+#pragma unroll
+                for (int a = 0; a < T; ++a) A[a][kb] = 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < T; ++a)
+#pragma unroll
+                for (int bb = 0; bb < T; ++bb) A[a][bb] = fma(-cc[a], rr[bb], A[a][bb]);
+        }
+    }
+    if (singular && tid == 0) bad[0] = 1;
+    // ---- needed rows of the inverse -> column-major slab [c][rp] ----
+    const int nrow = restricted ? no : n;
+    const int rp = roundup8(nrow);
+    double* __restrict__ slab = inv + inv_ptr[b];
+#pragma unroll
+    for (int a = 0; a < T; ++a) {
+        const int i = ty + 16 * a;
+        if (i >= rp) continue;
+#pragma unroll
+        for (int bb = 0; bb < T; ++bb) {
+            const int j = tx + 16 * bb;
+            if (j < n) slab[(int64_t)j * rp + i] = i < nrow ? A[a][bb] : 0.0;
+        }
+    }
+}
+
 // Extract A_i, invert it in place by Gauss-Jordan without pivoting (the local matrices are
 // unit rows for Dirichlet dofs plus an SPD free-free block, for which elimination in the natural
 // order is stable), write the needed rows of the inverse as a column-major slab [c][rp].
 // LDS = true: the matrix lives in LDS (n*ld*8 <= ~150 KB); else in a global workspace.
+// Fallback for subdomains with more than 128 dofs; smaller ones take k_invert_reg.
 template <bool LDS>
 __global__ __launch_bounds__(256) void k_invert(const int32_t* __restrict__ sub_n,
                                                 const int32_t* __restrict__ sub_nown,
@@ -207,12 +327,13 @@ __global__ __launch_bounds__(256) void k_invert(const int32_t* __restrict__ sub_
                                                 const double* __restrict__ val, int32_t n_rows, int restricted,
                                                 const int64_t* __restrict__ inv_ptr, double* __restrict__ inv,
                                                 double* __restrict__ work, int64_t work_stride, int lds_nmax,
-                                                int32_t* __restrict__ bad, int first_bin, int only_large) {
+                                                int32_t* __restrict__ bad, int first_bin, int only_large,
+                                                int n_skip) {
     extern __shared__ double sm[];
     __shared__ int32_t sdof[NMAX];
     const int b = first_bin + blockIdx.x, tid = threadIdx.x;
     const int n = sub_n[b];
-    if (n > NMAX) return;
+    if (n > NMAX || n <= n_skip) return;  // n <= n_skip: done by k_invert_reg
     // the LDS launch skips subdomains that do not fit; the global launch takes only those
     if (LDS && n > lds_nmax) return;
     if (!LDS && only_large && n <= lds_nmax) return;
@@ -424,27 +545,48 @@ int schwarz_setup(fedd_ctx* c) {
     FEDD_TRY(c->d_flags.ensure(16));
     int32_t* d_bad = c->d_flags.p + 1;
     FEDD_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), c->stream));
-    // largest n whose matrix (odd leading dimension) plus the two pivot buffers fits 150 KB of LDS
-    int lds_nmax = std::min(max_n, 134);
-    const size_t lds = ((size_t)lds_nmax * (lds_nmax | 1) + 2 * NMAX) * sizeof(double);
-    FEDD_HIP(hipFuncSetAttribute((const void*)k_invert<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_invert<true>, dim3((unsigned)nsub), blk, lds, c->stream, (const int32_t*)c->d_sub_n.p,
-                       (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const int32_t*)c->d_rowptr.p,
-                       (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, n_rows, restricted,
-                       (const int64_t*)c->d_inv_ptr.p, c->d_inv.p, (double*)nullptr, (int64_t)0, lds_nmax, d_bad, 0, 0);
-    if (max_n > lds_nmax) {
-        // subdomains too large for LDS: same algorithm on a global (L2-resident) workspace, in
-        // chunks of 1024 workgroups so that the workspace stays bounded
-        const int64_t stride = (int64_t)NMAX * (NMAX | 1) + 2 * NMAX;
-        const int chunk = 1024;
-        FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)stride * chunk, c->d_w.cap)));
-        for (int64_t first = 0; first < nsub; first += chunk) {
-            const int nb = (int)std::min<int64_t>(chunk, nsub - first);
-            hipLaunchKernelGGL(k_invert<false>, dim3(nb), blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
-                               (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
-                               (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p, (const double*)c->d_val.p,
-                               n_rows, restricted, (const int64_t*)c->d_inv_ptr.p, c->d_inv.p, c->d_w.p, stride,
-                               lds_nmax, d_bad, (int)first, 1);
+    // size classes of the register-tiled kernel (n <= 16 T); anything larger falls back below
+    {
+        const dim3 grid((unsigned)nsub);
+#define INV_REG(T, LO, HI)                                                                                     \
+    if (max_n > (LO))                                                                                          \
+        hipLaunchKernelGGL(k_invert_reg<T>, grid, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,             \
+                           (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,                   \
+                           (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p,                       \
+                           (const double*)c->d_val.p, n_rows, restricted, (const int64_t*)c->d_inv_ptr.p,      \
+                           c->d_inv.p, d_bad, (LO), (HI))
+        INV_REG(2, 0, 32);
+        INV_REG(4, 32, 64);
+        INV_REG(6, 64, 96);
+        INV_REG(7, 96, 112);
+        INV_REG(8, 112, 128);
+#undef INV_REG
+    }
+    const int n_skip = 128;
+    if (max_n > n_skip) {
+        // largest n whose matrix (odd leading dimension) plus the two pivot buffers fits 150 KB of LDS
+        int lds_nmax = std::min(max_n, 134);
+        const size_t lds = ((size_t)lds_nmax * (lds_nmax | 1) + 2 * NMAX) * sizeof(double);
+        FEDD_HIP(hipFuncSetAttribute((const void*)k_invert<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_invert<true>, dim3((unsigned)nsub), blk, lds, c->stream, (const int32_t*)c->d_sub_n.p,
+                           (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const int32_t*)c->d_rowptr.p,
+                           (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, n_rows, restricted,
+                           (const int64_t*)c->d_inv_ptr.p, c->d_inv.p, (double*)nullptr, (int64_t)0, lds_nmax, d_bad, 0, 0,
+                           n_skip);
+        if (max_n > lds_nmax) {
+            // too large for LDS: same algorithm on a global (L2-resident) workspace, in chunks of
+            // 1024 workgroups so that the workspace stays bounded
+            const int64_t stride = (int64_t)NMAX * (NMAX | 1) + 2 * NMAX;
+            const int chunk = 1024;
+            FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)stride * chunk, c->d_w.cap)));
+            for (int64_t first = 0; first < nsub; first += chunk) {
+                const int nb = (int)std::min<int64_t>(chunk, nsub - first);
+                hipLaunchKernelGGL(k_invert<false>, dim3(nb), blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
+                                   (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
+                                   (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p,
+                                   (const double*)c->d_val.p, n_rows, restricted, (const int64_t*)c->d_inv_ptr.p,
+                                   c->d_inv.p, c->d_w.p, stride, lds_nmax, d_bad, (int)first, 1, n_skip);
+            }
         }
     }
     int32_t bad = 0;

@@ -154,6 +154,9 @@ int fedd_schwarz_info(fedd_ctx* ctx, int64_t* n_subdomains, int64_t* max_size, i
 int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rtol, int max_it,
                int restart, int use_prec, int* its_out, double* relres_out);
 
+/* tuning knobs (A/B tests): "spmv_kind" 0 = CSR-stream (default), 1 = row-per-lane-group. */
+int fedd_set_option(fedd_ctx* ctx, const char* key, double value);
+
 /* device-time accounting (HIP events on the context's stream around each kernel class) */
 int fedd_timing_enable(fedd_ctx* ctx, int on);
 int fedd_timing_reset(fedd_ctx* ctx);
