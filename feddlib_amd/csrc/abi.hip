@@ -118,7 +118,8 @@ extern "C" void fedd_ctx_destroy(fedd_ctx* c) {
         fedd::DevBuf<int32_t>* ib[] = {&c->d_conn, &c->d_flag, &c->d_n2e_ptr, &c->d_n2e, &c->d_rowptr,
                                        &c->d_colind, &c->d_isdir, &c->d_node_bin, &c->d_bin_ptr,
                                        &c->d_bin_nodes, &c->d_sub_n, &c->d_sub_nown, &c->d_sub_dofs,
-                                       &c->d_itmp0, &c->d_itmp1, &c->d_itmp2, &c->d_flags, &c->halo.d_send_lid};
+                                       &c->d_itmp0, &c->d_itmp1, &c->d_itmp2, &c->d_flags, &c->d_spmv_rows,
+                                       &c->halo.d_send_lid, &c->halo.d_recv_lid};
         for (auto* b : ib) b->release();
         fedd::DevBuf<double>* db[] = {&c->d_xyz, &c->d_val, &c->d_rhs, &c->d_x, &c->d_xcol, &c->d_ycol,
                                       &c->d_inv, &c->d_mult, &c->d_V, &c->d_Z, &c->d_w, &c->d_part,

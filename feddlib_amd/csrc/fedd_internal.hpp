@@ -119,6 +119,8 @@ struct fedd_ctx {
     fedd::DevBuf<int32_t> d_isdir;              // [n_rows] 1 = Dirichlet row
     bool have_pattern = false;
     int spmv_kind = 0;                          // 0 = CSR-stream kernel, 1 = row-per-lane-group kernel
+    fedd::DevBuf<int32_t> d_spmv_rows;          // CSR-stream: first row of every nnz window
+    bool spmv_rows_ready = false;
 
     // ---- Schwarz ----
     int sw_target = 27;

@@ -30,30 +30,38 @@ __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ rowptr
 }
 
 // "CSR-stream": a workgroup owns the rows whose first entry lies in its SP_CHUNK-wide window of
-// the nonzero stream (found by two binary searches in rowptr, no precomputed schedule).  All 256
-// lanes stream (val, col) of the window fully coalesced, gather x, park the products in LDS; then
-// one lane per row adds its run.  No idle lanes for short rows, 8 independent loads per lane.
+// the nonzero stream (window -> first row is a table built once per pattern by k_spmv_block_rows).
+// All 256 lanes stream (val, col) of the window fully coalesced, gather x, park the products in
+// LDS; then one lane per row adds its run.  No idle lanes for short rows, 8 independent loads per
+// lane.  Workgroups are remapped so that each XCD (private L2) sweeps one contiguous eighth of
+// the rows: its share of x then stays in that L2 instead of all of x passing through all eight.
 constexpr int SP_CHUNK = 2048;
+
+__global__ void k_spmv_block_rows(const int32_t* __restrict__ rowptr, int32_t n_rows, int32_t nb,
+                                  int32_t* __restrict__ block_row) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    const int64_t target = (int64_t)b * SP_CHUNK;
+    int32_t lo = 0, hi = n_rows;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (rowptr[mid] < target) lo = mid + 1;
+        else hi = mid;
+    }
+    block_row[b] = lo;
+}
 
 __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ colind,
                                                      const double* __restrict__ val, const double* __restrict__ x,
-                                                     double* __restrict__ y, int32_t n_rows) {
+                                                     double* __restrict__ y, const int32_t* __restrict__ block_row,
+                                                     int32_t nb) {
     extern __shared__ double prod[];
-    __shared__ int32_t s_rows[2];
     const int tid = threadIdx.x;
-    if (tid < 2) {
-        const int64_t target = (int64_t)(blockIdx.x + tid) * SP_CHUNK;
-        int32_t lo = 0, hi = n_rows;
-        while (lo < hi) {
-            const int32_t mid = (lo + hi) >> 1;
-            if (rowptr[mid] < target) lo = mid + 1;
-            else hi = mid;
-        }
-        s_rows[tid] = lo;
-    }
-    __syncthreads();
-    const int32_t R0 = s_rows[0], R1 = s_rows[1];
+    // bijective XCD remap (blocks b and b+8 share an XCD): XCD k gets a contiguous range
+    const int32_t q = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int32_t lb = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
+    const int32_t R0 = block_row[lb], R1 = block_row[lb + 1];
     if (R0 >= R1) return;
     const int32_t base = rowptr[R0];
     const int32_t cnt = rowptr[R1] - base;
@@ -90,16 +98,24 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned) {
     }
     const double avg = c->n_rows ? (double)c->nnz / (double)c->n_rows : 1.0;
     const int32_t n = (int32_t)c->n_rows;
-    ScopedTimer t(c, FEDD_T_SPMV);
     if (c->spmv_kind == 0 && avg <= 64.0 && c->max_row_nnz <= 2048) {
         const size_t lds = (size_t)(SP_CHUNK + c->max_row_nnz) * sizeof(double);
-        const unsigned nb = (unsigned)(c->nnz / SP_CHUNK + 1);
-        hipLaunchKernelGGL(k_spmv_stream, dim3(nb), dim3(256), lds, c->stream, (const int32_t*)c->d_rowptr.p,
-                           (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, x, d_y_owned, n);
-        t.stop();
+        const int32_t nb = (int32_t)(c->nnz / SP_CHUNK + 1);
+        if (!c->spmv_rows_ready) {  // one-off per pattern: window -> first row table
+            FEDD_TRY(c->d_spmv_rows.ensure((size_t)nb + 1));
+            hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, c->stream,
+                               (const int32_t*)c->d_rowptr.p, n, nb, c->d_spmv_rows.p);
+            c->spmv_rows_ready = true;
+        }
+        ScopedTimer ts(c, FEDD_T_SPMV);
+        hipLaunchKernelGGL(k_spmv_stream, dim3((unsigned)nb), dim3(256), lds, c->stream, (const int32_t*)c->d_rowptr.p,
+                           (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, x, d_y_owned,
+                           (const int32_t*)c->d_spmv_rows.p, nb);
+        ts.stop();
         FEDD_HIP(hipGetLastError());
         return 0;
     }
+    ScopedTimer t(c, FEDD_T_SPMV);
 #define SPMV_LAUNCH(L)                                                                                        \
     hipLaunchKernelGGL(k_spmv<L>, dim3((unsigned)(((int64_t)n * L + 255) / 256)), dim3(256), 0, c->stream,      \
                        (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, \

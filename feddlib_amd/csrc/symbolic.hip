@@ -198,6 +198,7 @@ int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
     FEDD_HIP(hipGetLastError());
     c->have_pattern = true;
     c->have_schwarz = false;
+    c->spmv_rows_ready = false;
     return 0;
 }
 

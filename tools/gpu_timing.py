@@ -58,6 +58,14 @@ def main():
         out.append(rec)
         print(json.dumps(rec), flush=True)
     # kernel micro-timings on resident data
+    nr = m["gid_uni"].shape[0]
+    for kind in (1, 0):
+        c.set_option("spmv_kind", kind)
+        c.spmv_device(5); c.sync()
+        c.timing_reset()
+        c.spmv_device(50); c.sync()
+        tk = c.timing_get()["spmv"]
+        print(json.dumps({"spmv_kind": kind, "ms": tk[0] / tk[1], "GBs": (12 * nnz + 20 * nr) / (tk[0] / tk[1]) / 1e6}), flush=True)
     c.timing_reset()
     c.spmv_device(50); c.sync()
     if not a.noprec:
