@@ -69,5 +69,28 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_driver(verbose: bool = True) -> str:
+    """The C++ host-facade driver (mirrors feddlib/problems/tests/laplace/main.cpp), g++ against the C ABI."""
+    gxx = shutil.which("g++")
+    if gxx is None:
+        raise RuntimeError("g++ not found")
+    host = os.path.join(HERE, "host")
+    out = os.path.join(host, "bin", "laplace_driver")
+    src = os.path.join(host, "drivers", "laplace_main.cpp")
+    deps = [src, os.path.join(host, "feddlib", "fedd_facade.hpp"), os.path.join(host, "Teuchos_shim.hpp"), LIB]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [gxx, "-std=c++17", "-O2", "-I", host, src, "-o", out, "-L", LIBDIR, "-lfedd_hip",
+           "-Wl,-rpath,$ORIGIN/../../lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed:\n" + r.stdout + r.stderr)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_driver())

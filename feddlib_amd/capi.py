@@ -39,6 +39,7 @@ SIGNATURES = {
     "fedd_assemble": [C.c_void_p, C.c_int, _f64p],
     "fedd_assemble_rhs": [C.c_void_p, C.c_int, _f64p, C.c_int],
     "fedd_dirichlet": [C.c_void_p, C.c_int, _i32p, _i32p, _f64p],
+    "fedd_dirichlet_nodes": [C.c_void_p, C.c_int64, _i32p, _i32p, _f64p],
     "fedd_csr_sizes": [C.c_void_p, _i64p, _i64p, _i64p],
     "fedd_csr_get": [C.c_void_p, _i64p, _i32p, _f64p, _i64p],
     "fedd_rhs_get": [C.c_void_p, _f64p],
@@ -202,6 +203,12 @@ class Context:
         v = np.zeros(n * self.dofs) if values is None else np.ascontiguousarray(values, dtype=np.float64).ravel()
         m = None if comp_mask is None else np.ascontiguousarray(comp_mask, dtype=np.int32).ravel()
         _chk(self._L.fedd_dirichlet(self._h, n, _p(fl, _i32p), _p(m, _i32p), _p(v, _f64p)))
+
+    def dirichlet_nodes(self, nodes, values, comp_mask=None):
+        nd = np.ascontiguousarray(nodes, dtype=np.int32)
+        v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        m = None if comp_mask is None else np.ascontiguousarray(comp_mask, dtype=np.int32).ravel()
+        _chk(self._L.fedd_dirichlet_nodes(self._h, nd.shape[0], _p(nd, _i32p), _p(m, _i32p), _p(v, _f64p)))
 
     def csr_sizes(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()

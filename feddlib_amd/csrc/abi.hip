@@ -259,6 +259,15 @@ extern "C" int fedd_dirichlet(fedd_ctx* c, int n_bc, const int32_t* flags, const
     return apply_dirichlet(c, n_bc, flags, comp_mask, values);
 }
 
+extern "C" int fedd_dirichlet_nodes(fedd_ctx* c, int64_t n, const int32_t* owned_nodes, const int32_t* comp_mask,
+                                    const double* values) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_dirichlet_nodes: call fedd_pattern_build first");
+    FEDD_CHECK(n >= 0 && (n == 0 || (owned_nodes && values)), "fedd_dirichlet_nodes: null array");
+    FEDD_HIP(hipSetDevice(c->device));
+    return apply_dirichlet_nodes(c, n, owned_nodes, comp_mask, values);
+}
+
 extern "C" int fedd_csr_sizes(fedd_ctx* c, int64_t* n_rows, int64_t* n_cols, int64_t* nnz) {
     FEDD_CHECK(c && c->have_pattern, "fedd_csr_sizes: no pattern");
     if (n_rows) *n_rows = c->n_rows;

@@ -268,6 +268,23 @@ __global__ void k_dirichlet(BcArgs b, const int32_t* __restrict__ nflag, const i
     isdir[row] = 1;
 }
 
+// per-node variant: node list + per-dof mask/value (what BCBuilder::setRHS obtains by evaluating
+// the user's boundary function at every flagged unique node, BCBuilder_def.hpp:128-143)
+__global__ void k_dirichlet_nodes(const int32_t* __restrict__ nodes, const int32_t* __restrict__ mask,
+                                  const double* __restrict__ values, int32_t n, int dofs,
+                                  const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, double* val,
+                                  double* rhs, int32_t* isdir) {
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * dofs) return;
+    const int32_t k = t / dofs;
+    const int comp = t - k * dofs;
+    if (mask && !mask[t]) return;
+    const int32_t row = nodes[k] * dofs + comp;
+    for (int32_t p = rowptr[row]; p < rowptr[row + 1]; ++p) val[p] = colind[p] == row ? 1.0 : 0.0;
+    rhs[row] = values[t];
+    isdir[row] = 1;
+}
+
 template <int DIM, int NEN>
 int launch_assemble(fedd_ctx* c, int kform, const AsmArgs& a, int ntab) {
     const int rowcap = std::max(1, c->max_row_nnz);
@@ -363,6 +380,29 @@ int assemble_rhs(fedd_ctx* c, int dofs, const double* f_const, int extra_degree)
     else hipLaunchKernelGGL(k_rhs<3>, grid, block, 0, c->stream, a);
     t.stop();
     FEDD_HIP(hipGetLastError());
+    return 0;
+}
+
+int apply_dirichlet_nodes(fedd_ctx* c, int64_t n, const int32_t* nodes, const int32_t* comp_mask, const double* values) {
+    if (n == 0) return 0;
+    const int dofs = c->dofs;
+    for (int64_t k = 0; k < n; ++k)
+        FEDD_CHECK(nodes[k] >= 0 && nodes[k] < c->n_own, "fedd_dirichlet_nodes: node %d is not an owned node", nodes[k]);
+    FEDD_TRY(c->d_itmp0.ensure(std::max<size_t>((size_t)n * (1 + dofs), c->d_itmp0.cap)));
+    FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>((size_t)n * dofs, c->d_dtmp0.cap)));
+    int32_t* d_nodes = c->d_itmp0.p;
+    int32_t* d_mask = comp_mask ? c->d_itmp0.p + n : nullptr;
+    FEDD_HIP(hipMemcpyAsync(d_nodes, nodes, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (comp_mask) FEDD_HIP(hipMemcpyAsync(d_mask, comp_mask, (size_t)n * dofs * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    FEDD_HIP(hipMemcpyAsync(c->d_dtmp0.p, values, (size_t)n * dofs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ScopedTimer t(c, FEDD_T_DIRICHLET);
+    hipLaunchKernelGGL(k_dirichlet_nodes, dim3((unsigned)((n * dofs + 255) / 256)), dim3(256), 0, c->stream,
+                       (const int32_t*)d_nodes, (const int32_t*)d_mask, (const double*)c->d_dtmp0.p, (int32_t)n, dofs,
+                       (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p, c->d_val.p, c->d_rhs.p, c->d_isdir.p);
+    t.stop();
+    FEDD_HIP(hipGetLastError());
+    FEDD_HIP(hipStreamSynchronize(c->stream));  // host staging buffers are the caller's
+    c->have_schwarz = false;
     return 0;
 }
 

@@ -196,6 +196,8 @@ int assemble_matrix(fedd_ctx* c, int form, const double* params);
 int assemble_rhs(fedd_ctx* c, int dofs, const double* f_const, int extra_degree);
 int apply_dirichlet(fedd_ctx* c, int n_bc, const int32_t* flags, const int32_t* comp_mask,
                     const double* values);
+int apply_dirichlet_nodes(fedd_ctx* c, int64_t n, const int32_t* nodes, const int32_t* comp_mask,
+                          const double* values);
 
 // spmv.hip
 int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned);   // incl. ghost import

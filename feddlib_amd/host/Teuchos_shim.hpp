@@ -1,0 +1,193 @@
+// Minimal stand-ins for the Teuchos types that appear in FEDDLib's public interface, so that the
+// host facade (namespace FEDD) compiles without Trilinos.  With a real Trilinos installed, define
+// FEDD_HAVE_TRILINOS and include the real headers instead: the facade only uses the subset below.
+// API subset mirrored: Teuchos::RCP / rcp / null / rcp_const_cast, Teuchos::ParameterList (get,
+// sublist, set, setParameters, isParameter, isSublist), Teuchos::getParametersFromXmlFile,
+// Teuchos::Comm<int> (getRank/getSize/barrier), Teuchos::ArrayRCP / ArrayView (pointer + size),
+// TEUCHOS_TEST_FOR_EXCEPTION.
+#pragma once
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#define TEUCHOS_TEST_FOR_EXCEPTION(cond, exc, msg)                      \
+    do {                                                                \
+        if (cond) {                                                     \
+            std::ostringstream os__;                                    \
+            os__ << __FILE__ << ":" << __LINE__ << ": " << msg;         \
+            throw exc(os__.str());                                      \
+        }                                                               \
+    } while (0)
+
+namespace Teuchos {
+
+struct ENull { };
+static const ENull null = ENull();
+
+template <class T>
+class RCP {
+public:
+    RCP() {}
+    RCP(ENull) {}
+    explicit RCP(T* p) : p_(p) {}
+    RCP(const std::shared_ptr<T>& p) : p_(p) {}
+    template <class U>
+    RCP(const RCP<U>& o) : p_(o.shared()) {}
+    T* operator->() const { return p_.get(); }
+    T& operator*() const { return *p_; }
+    T* get() const { return p_.get(); }
+    bool is_null() const { return !p_; }
+    void reset(T* p = nullptr) { p_.reset(p); }
+    const std::shared_ptr<T>& shared() const { return p_; }
+    bool operator==(ENull) const { return !p_; }
+    bool operator!=(ENull) const { return (bool)p_; }
+private:
+    std::shared_ptr<T> p_;
+};
+
+template <class T>
+RCP<T> rcp(T* p) { return RCP<T>(p); }
+template <class T, class U>
+RCP<T> rcp_const_cast(const RCP<U>& p) { return RCP<T>(std::const_pointer_cast<T>(p.shared())); }
+template <class T, class U>
+RCP<T> rcp_dynamic_cast(const RCP<U>& p) { return RCP<T>(std::dynamic_pointer_cast<T>(p.shared())); }
+
+template <class T>
+class ArrayView {
+public:
+    ArrayView() {}
+    ArrayView(T* p, size_t n) : p_(p), n_(n) {}
+    T& operator[](size_t i) const { return p_[i]; }
+    size_t size() const { return n_; }
+    T* getRawPtr() const { return p_; }
+private:
+    T* p_ = nullptr;
+    size_t n_ = 0;
+};
+template <class T>
+using ArrayRCP = ArrayView<T>;
+
+template <class Ordinal>
+class Comm {
+public:
+    Comm(int rank = 0, int size = 1) : rank_(rank), size_(size) {}
+    int getRank() const { return rank_; }
+    int getSize() const { return size_; }
+    void barrier() const {}
+private:
+    int rank_, size_;
+};
+
+class ParameterList {
+public:
+    ParameterList(const std::string& name = "") : name_(name) {}
+    const std::string& name() const { return name_; }
+    ParameterList& sublist(const std::string& n) {
+        auto it = sub_.find(n);
+        if (it == sub_.end()) it = sub_.emplace(n, ParameterList(n)).first;
+        return it->second;
+    }
+    bool isSublist(const std::string& n) const { return sub_.count(n) > 0; }
+    bool isParameter(const std::string& n) const { return val_.count(n) > 0; }
+    template <class T>
+    ParameterList& set(const std::string& n, const T& v) {
+        std::ostringstream os;
+        os.precision(17);
+        os << v;
+        val_[n] = os.str();
+        return *this;
+    }
+    ParameterList& set(const std::string& n, const char* v) { val_[n] = v; return *this; }
+    ParameterList& set(const std::string& n, bool v) { val_[n] = v ? "true" : "false"; return *this; }
+    // get with default: like Teuchos, the default is stored when the entry is missing
+    int get(const std::string& n, int d) { return has(n) ? std::atoi(val_[n].c_str()) : (set(n, d), d); }
+    double get(const std::string& n, double d) { return has(n) ? std::atof(val_[n].c_str()) : (set(n, d), d); }
+    bool get(const std::string& n, bool d) {
+        if (!has(n)) { set(n, d); return d; }
+        const std::string& s = val_[n];
+        return s == "true" || s == "1" || s == "True";
+    }
+    std::string get(const std::string& n, const std::string& d) { return has(n) ? val_[n] : (val_[n] = d, d); }
+    std::string get(const std::string& n, const char* d) { return get(n, std::string(d)); }
+    // merge, entries of `o` win (Teuchos::ParameterList::setParameters)
+    ParameterList& setParameters(const ParameterList& o) {
+        for (auto& kv : o.val_) val_[kv.first] = kv.second;
+        for (auto& kv : o.sub_) sublist(kv.first).setParameters(kv.second);
+        return *this;
+    }
+    void print(std::ostream& os, int indent = 0) const {
+        for (auto& kv : val_) os << std::string(indent, ' ') << kv.first << " = " << kv.second << "\n";
+        for (auto& kv : sub_) {
+            os << std::string(indent, ' ') << kv.first << " ->\n";
+            kv.second.print(os, indent + 2);
+        }
+    }
+private:
+    bool has(const std::string& n) const { return val_.count(n) > 0; }
+    std::string name_;
+    std::map<std::string, std::string> val_;
+    std::map<std::string, ParameterList> sub_;
+};
+
+inline RCP<ParameterList> sublist(const RCP<ParameterList>& pl, const std::string& name) {
+    // aliasing pointer into the parent (keeps the parent alive)
+    return RCP<ParameterList>(std::shared_ptr<ParameterList>(pl.shared(), &pl->sublist(name)));
+}
+
+namespace detail {
+inline std::string attr(const std::string& tag, const std::string& key) {
+    const std::string k = key + "=\"";
+    size_t p = tag.find(k);
+    if (p == std::string::npos) return "";
+    p += k.size();
+    size_t e = tag.find('"', p);
+    return tag.substr(p, e - p);
+}
+}  // namespace detail
+
+// Reader for the Teuchos XML parameter-list dialect FEDDLib's drivers use
+// (<ParameterList name=..> <Parameter name=.. type=.. value=../> </ParameterList>, <!-- comments -->).
+inline RCP<ParameterList> getParametersFromXmlFile(const std::string& file) {
+    std::ifstream in(file);
+    TEUCHOS_TEST_FOR_EXCEPTION(!in, std::runtime_error, "cannot open parameter file " << file);
+    std::stringstream ss;
+    ss << in.rdbuf();
+    std::string s = ss.str();
+    for (size_t p; (p = s.find("<!--")) != std::string::npos;) {
+        size_t e = s.find("-->", p);
+        s.erase(p, e == std::string::npos ? std::string::npos : e + 3 - p);
+    }
+    RCP<ParameterList> root;
+    std::vector<ParameterList*> stack;
+    size_t pos = 0;
+    while ((pos = s.find('<', pos)) != std::string::npos) {
+        size_t e = s.find('>', pos);
+        TEUCHOS_TEST_FOR_EXCEPTION(e == std::string::npos, std::runtime_error, "malformed XML in " << file);
+        const std::string tag = s.substr(pos + 1, e - pos - 1);
+        pos = e + 1;
+        if (tag.compare(0, 14, "/ParameterList") == 0) {
+            if (!stack.empty()) stack.pop_back();
+        } else if (tag.compare(0, 13, "ParameterList") == 0) {
+            const std::string name = detail::attr(tag, "name");
+            if (stack.empty()) {
+                root = rcp(new ParameterList(name));
+                stack.push_back(root.get());
+            } else {
+                stack.push_back(&stack.back()->sublist(name));
+            }
+            if (!tag.empty() && tag.back() == '/') stack.pop_back();
+        } else if (tag.compare(0, 9, "Parameter") == 0) {
+            TEUCHOS_TEST_FOR_EXCEPTION(stack.empty(), std::runtime_error, "Parameter outside a ParameterList in " << file);
+            stack.back()->set(detail::attr(tag, "name"), detail::attr(tag, "value").c_str());
+        }
+    }
+    TEUCHOS_TEST_FOR_EXCEPTION(root.is_null(), std::runtime_error, "no ParameterList in " << file);
+    return root;
+}
+
+}  // namespace Teuchos

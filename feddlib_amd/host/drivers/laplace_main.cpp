@@ -1,0 +1,118 @@
+// Laplace driver on the MI355X path, written against the FEDD:: operator surface exactly the way
+// the reference's driver is (feddlib/problems/tests/laplace/main.cpp:56-228): same XML parameter
+// files, same call sequence  Domain::buildMesh -> BCBuilder::addBC -> Laplace(...) ->
+// addRhsFunction -> addBoundaries -> initializeProblem -> assemble -> setBoundaries -> solve.
+// Output: iteration count on stdout, solution as text (the reference writes HDF5/XDMF through
+// ExporterParaView, out of scope here).
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+
+#include "feddlib/core/FEDDCore.hpp"
+#include "feddlib/core/FE/Domain.hpp"
+#include "feddlib/core/General/BCBuilder.hpp"
+#include "feddlib/problems/specific/Laplace.hpp"
+
+void zeroBC(double* x, double* res, double t, const double* parameters) { res[0] = 0.; }
+void zeroBC2D(double* x, double* res, double t, const double* parameters) { res[0] = 0.; res[1] = 0.; }
+void zeroBC3D(double* x, double* res, double t, const double* parameters) { res[0] = 0.; res[1] = 0.; res[2] = 0.; }
+void oneFunc(double* x, double* res, double* parameters) { res[0] = 1.; }
+
+typedef default_sc SC;
+typedef default_lo LO;
+typedef default_go GO;
+typedef default_no NO;
+
+using namespace FEDD;
+
+int main(int argc, char* argv[]) {
+    std::string xmlProblemFile = "parametersProblem.xml", xmlPrecFile = "parametersPrec.xml", xmlSolverFile = "parametersSolver.xml";
+    std::string outFile = "solutionLaplace.txt";
+    double length = 4.;
+    bool vL = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a(argv[i]);
+        auto val = [&](const char* key, std::string& dst) {
+            const std::string k = std::string("--") + key + "=";
+            if (a.compare(0, k.size(), k) == 0) { dst = a.substr(k.size()); return true; }
+            return false;
+        };
+        std::string tmp;
+        if (val("problemfile", xmlProblemFile) || val("precfile", xmlPrecFile) || val("solverfile", xmlSolverFile) || val("out", outFile)) continue;
+        if (val("length", tmp)) { length = std::atof(tmp.c_str()); continue; }
+        if (a == "--vectorLaplace") { vL = true; continue; }
+        std::cerr << "unknown option " << a << std::endl;
+        return 2;
+    }
+    (void)length;
+    try {
+        Teuchos::RCP<const Teuchos::Comm<int> > comm = Teuchos::rcp(new Teuchos::Comm<int>(0, 1));
+        ParameterListPtr_Type parameterListProblem = Teuchos::getParametersFromXmlFile(xmlProblemFile);
+        ParameterListPtr_Type parameterListPrec = Teuchos::getParametersFromXmlFile(xmlPrecFile);
+        ParameterListPtr_Type parameterListSolver = Teuchos::getParametersFromXmlFile(xmlSolverFile);
+        ParameterListPtr_Type parameterListAll(new Teuchos::ParameterList(*parameterListProblem));
+        parameterListAll->setParameters(*parameterListPrec);
+        parameterListAll->setParameters(*parameterListSolver);
+
+        int dim = parameterListProblem->sublist("Parameter").get("Dimension", 2);
+        int m = parameterListProblem->sublist("Parameter").get("H/h", 5);
+        std::string FEType = parameterListProblem->sublist("Parameter").get("Discretization", "P1");
+        std::string meshType = parameterListProblem->sublist("Parameter").get("Mesh Type", "structured");
+        int numProcsCoarseSolve = parameterListProblem->sublist("General").get("Mpi Ranks Coarse", 0);
+        int size = comm->getSize() - numProcsCoarseSolve;
+
+        Teuchos::RCP<Domain<SC, LO, GO, NO> > domain;
+        TEUCHOS_TEST_FOR_EXCEPTION(meshType != "structured", std::logic_error, "this driver builds structured meshes");
+        int n;
+        if (dim == 2) {
+            n = (int)(std::pow(size, 1 / 2.) + 100. * 2.220446049250313e-16);
+            std::vector<double> x(2);
+            x[0] = 0.0; x[1] = 0.0;
+            domain = Teuchos::rcp(new Domain<SC, LO, GO, NO>(x, 1., 1., comm));
+            domain->buildMesh(1, "Square", dim, FEType, n, m, numProcsCoarseSolve);
+        } else {
+            n = (int)(std::pow(size, 1 / 3.) + 100. * 2.220446049250313e-16);
+            std::vector<double> x(3);
+            x[0] = 0.0; x[1] = 0.0; x[2] = 0.0;
+            domain = Teuchos::rcp(new Domain<SC, LO, GO, NO>(x, 1., 1., 1., comm));
+            domain->buildMesh(1, "Square", dim, FEType, n, m, numProcsCoarseSolve);
+        }
+
+        Teuchos::RCP<BCBuilder<SC, LO, GO, NO> > bcFactory(new BCBuilder<SC, LO, GO, NO>());
+        if (vL) {
+            BC_func_Type z = dim == 2 ? zeroBC2D : zeroBC3D;
+            bcFactory->addBC(z, 1, 0, domain, "Dirichlet", dim);
+            bcFactory->addBC(z, 2, 0, domain, "Dirichlet", dim);
+            bcFactory->addBC(z, 3, 0, domain, "Dirichlet", dim);
+        } else {
+            bcFactory->addBC(zeroBC, 1, 0, domain, "Dirichlet", 1);
+            bcFactory->addBC(zeroBC, 2, 0, domain, "Dirichlet", 1);
+            bcFactory->addBC(zeroBC, 3, 0, domain, "Dirichlet", 1);
+        }
+
+        Laplace<SC, LO, GO, NO> laplace(domain, FEType, parameterListAll, vL);
+        int its;
+        {
+            laplace.addRhsFunction(oneFunc);
+            laplace.addBoundaries(bcFactory);
+
+            laplace.initializeProblem();
+            laplace.assemble();
+            laplace.setBoundaries();
+            its = laplace.solve();
+        }
+        std::cout << "iterations " << its << " relres " << laplace.getLastRelativeResidual() << std::endl;
+
+        Teuchos::RCP<const MultiVector<SC, LO, GO, NO> > exportSolution = laplace.getSolution()->getBlock(0);
+        std::ofstream out(outFile);
+        out << std::setprecision(17);
+        auto map = exportSolution->getMap();
+        auto data = exportSolution->getData(0);
+        for (size_t i = 0; i < data.size(); ++i) out << map->getGlobalElement((LO)i) << " " << data[i] << "\n";
+    } catch (const std::exception& e) {
+        std::cerr << "exception: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

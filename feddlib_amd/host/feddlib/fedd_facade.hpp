@@ -1,0 +1,769 @@
+// Host-side mirror of the reference's operator surface for the assembly + solve hot path,
+// namespace FEDD, same class / method names, argument meaning and error behaviour (exceptions),
+// sitting on top of the C ABI of include/fedd_hip.h.  Header-only, C++17, no Trilinos needed
+// (Teuchos_shim.hpp).  Each class cites the reference declaration it mirrors.
+//
+//   Map                 feddlib/core/LinearAlgebra/Map_decl.hpp
+//   MultiVector         feddlib/core/LinearAlgebra/MultiVector_decl.hpp
+//   Matrix              feddlib/core/LinearAlgebra/Matrix_decl.hpp
+//   BlockMatrix / BlockMultiVector   feddlib/core/LinearAlgebra/Block*_decl.hpp
+//   Elements / FiniteElement         feddlib/core/FE/Elements.hpp, FiniteElement.hpp
+//   Domain              feddlib/core/FE/Domain_decl.hpp:66-203
+//   FE                  feddlib/core/FE/FE_decl.hpp:40-488
+//   BCBuilder           feddlib/core/General/BCBuilder_decl.hpp:36-84
+//   Problem             feddlib/problems/abstract/Problem_decl.hpp:38-229
+//   Laplace / LinElas   feddlib/problems/specific/{Laplace,LinElas}_decl.hpp
+//   LinearSolver        feddlib/problems/Solver/LinearSolver_decl.hpp
+//
+// Differences that are deliberate: SoA mesh storage behind the same accessors; the matrix lives on
+// the GPU (host copy pulled lazily by the row-view accessors); one process = one GPU = one rank.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../../include/fedd_hip.h"
+#include "../Teuchos_shim.hpp"
+
+typedef double default_sc;
+typedef int default_lo;
+typedef long long default_go;
+struct default_no { };
+typedef unsigned UN;
+
+namespace FEDD {
+
+typedef std::vector<double> vec_dbl_Type;
+typedef std::vector<int> vec_int_Type;
+typedef std::vector<std::vector<double>> vec2D_dbl_Type;
+typedef Teuchos::RCP<vec_dbl_Type> vec_dbl_ptr_Type;
+typedef Teuchos::RCP<vec_int_Type> vec_int_ptr_Type;
+typedef Teuchos::RCP<vec2D_dbl_Type> vec2D_dbl_ptr_Type;
+typedef Teuchos::RCP<Teuchos::ParameterList> ParameterListPtr_Type;
+// feddlib/core/FEDDCore.hpp:115-118 (boost::function there)
+typedef std::function<void(double* x, double* res, double* parameters)> RhsFunc_Type;
+typedef std::function<void(double* x, double* res, double t, const double* parameters)> BC_func_Type;
+
+inline void feddCheck(int rc, const char* what) {
+    TEUCHOS_TEST_FOR_EXCEPTION(rc != 0, std::runtime_error, what << ": " << fedd_last_error());
+}
+
+// One GPU context per Domain (mesh resident on the device); shared by the objects built on it.
+struct DeviceContext {
+    fedd_ctx* ctx = nullptr;
+    long generation = 0;      // bumped by every assembly into the context
+    explicit DeviceContext(int device) { feddCheck(fedd_ctx_create(&ctx, device, nullptr, 0, 1), "fedd_ctx_create"); }
+    ~DeviceContext() { if (ctx) fedd_ctx_destroy(ctx); }
+    DeviceContext(const DeviceContext&) = delete;
+    DeviceContext& operator=(const DeviceContext&) = delete;
+};
+typedef Teuchos::RCP<DeviceContext> DeviceContextPtr;
+
+template <class LO = default_lo, class GO = default_go, class NO = default_no>
+class Map {
+public:
+    typedef Teuchos::Comm<int> Comm_Type;
+    typedef Teuchos::RCP<const Comm_Type> CommConstPtr_Type;
+    Map(const std::vector<GO>& gids, CommConstPtr_Type comm) : gids_(gids), comm_(comm) {
+        for (size_t i = 0; i < gids_.size(); ++i) maxGid_ = std::max(maxGid_, gids_[i]);
+    }
+    LO getNodeNumElements() const { return (LO)gids_.size(); }
+    GO getGlobalNumElements() const { return maxGid_ + 1; }
+    GO getGlobalElement(LO i) const { return gids_.at(i); }
+    GO getMaxAllGlobalIndex() const { return maxGid_; }
+    LO getLocalElement(GO g) const {
+        auto it = std::find(gids_.begin(), gids_.end(), g);
+        return it == gids_.end() ? (LO)-1 : (LO)(it - gids_.begin());
+    }
+    CommConstPtr_Type getComm() const { return comm_; }
+    // vector-field map: dof = dim*node + d   (Map_def.hpp:95-107)
+    Teuchos::RCP<Map> buildVecFieldMap(UN dofs) const {
+        std::vector<GO> g(gids_.size() * dofs);
+        for (size_t i = 0; i < gids_.size(); ++i)
+            for (UN d = 0; d < dofs; ++d) g[i * dofs + d] = dofs * gids_[i] + d;
+        return Teuchos::rcp(new Map(g, comm_));
+    }
+    const std::vector<GO>& gids() const { return gids_; }
+private:
+    std::vector<GO> gids_;
+    GO maxGid_ = -1;
+    CommConstPtr_Type comm_;
+};
+
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class MultiVector {
+public:
+    typedef Map<LO, GO, NO> Map_Type;
+    typedef Teuchos::RCP<const Map_Type> MapConstPtr_Type;
+    MultiVector(MapConstPtr_Type map, UN nmbVectors = 1) : map_(map), data_(nmbVectors, std::vector<SC>(map->getNodeNumElements(), 0.)) {}
+    MapConstPtr_Type getMap() const { return map_; }
+    UN getNumVectors() const { return (UN)data_.size(); }
+    size_t getLocalLength() const { return data_[0].size(); }
+    Teuchos::ArrayRCP<SC> getDataNonConst(UN i) { return Teuchos::ArrayRCP<SC>(data_.at(i).data(), data_[i].size()); }
+    Teuchos::ArrayRCP<const SC> getData(UN i) const { return Teuchos::ArrayRCP<const SC>(data_.at(i).data(), data_[i].size()); }
+    void putScalar(const SC& v) { for (auto& c : data_) std::fill(c.begin(), c.end(), v); }
+    void update(const SC& alpha, const MultiVector& A, const SC& beta) {
+        for (size_t j = 0; j < data_.size(); ++j)
+            for (size_t i = 0; i < data_[j].size(); ++i) data_[j][i] = alpha * A.data_[j][i] + beta * data_[j][i];
+    }
+    SC norm2(UN j = 0) const { SC s = 0; for (SC v : data_.at(j)) s += v * v; return std::sqrt(s); }
+    std::vector<SC>& raw(UN j = 0) { return data_.at(j); }
+    const std::vector<SC>& raw(UN j = 0) const { return data_.at(j); }
+private:
+    MapConstPtr_Type map_;
+    std::vector<std::vector<SC>> data_;
+};
+
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class Matrix {
+public:
+    typedef Map<LO, GO, NO> Map_Type;
+    typedef Teuchos::RCP<Map_Type> MapPtr_Type;
+    typedef Teuchos::RCP<const Map_Type> MapConstPtr_Type;
+    typedef MultiVector<SC, LO, GO, NO> MultiVector_Type;
+    // row map = unique (vec-field) map, second argument = allocation hint only (Matrix_def.hpp:46-51)
+    Matrix(MapConstPtr_Type map, LO numEntries = 0) : map_(map) { (void)numEntries; }
+    MapConstPtr_Type getMap(std::string = "row") const { return map_; }
+    bool isFillComplete() const { return filled_; }
+    void fillComplete() { filled_ = true; }
+    void resumeFill() { filled_ = false; }
+    // binding to the device matrix the assembly produced
+    void bind(DeviceContextPtr dev, int dofs) { dev_ = dev; gen_ = dev->generation; dofs_ = dofs; hostValid_ = false; filled_ = true; }
+    bool isResident() const { return !dev_.is_null() && gen_ == dev_->generation; }
+    DeviceContextPtr device() const { return dev_; }
+    void invalidateHost() { hostValid_ = false; }
+    GO getGlobalNumEntries() { pull(); return (GO)val_.size(); }
+    LO getNumEntriesInLocalRow(LO row) { pull(); return (LO)(rowptr_.at(row + 1) - rowptr_.at(row)); }
+    // Matrix::getLocalRowView (local column indices; colGid() maps them to global dof ids)
+    void getLocalRowView(LO row, Teuchos::ArrayView<const LO>& indices, Teuchos::ArrayView<const SC>& values) {
+        pull();
+        const int64_t b = rowptr_.at(row), e = rowptr_.at(row + 1);
+        indices = Teuchos::ArrayView<const LO>(col_.data() + b, (size_t)(e - b));
+        values = Teuchos::ArrayView<const SC>(val_.data() + b, (size_t)(e - b));
+    }
+    GO colGid(LO localCol) { pull(); return (GO)colGid_.at(localCol); }
+    // y = A x on owned rows (Matrix::apply, Matrix_def.hpp:245-254)
+    void apply(const MultiVector_Type& X, MultiVector_Type& Y) {
+        TEUCHOS_TEST_FOR_EXCEPTION(!isResident(), std::runtime_error, "Matrix::apply: matrix is not the one resident on the device");
+        feddCheck(fedd_spmv(dev_->ctx, X.raw().data(), Y.raw().data()), "fedd_spmv");
+    }
+    void print() {
+        pull();
+        for (size_t r = 0; r + 1 < rowptr_.size(); ++r)
+            for (int64_t p = rowptr_[r]; p < rowptr_[r + 1]; ++p)
+                std::cout << map_->getGlobalElement((LO)r) << " " << colGid_[col_[p]] << " " << val_[p] << "\n";
+    }
+private:
+    void pull() {
+        if (hostValid_) return;
+        TEUCHOS_TEST_FOR_EXCEPTION(!isResident(), std::runtime_error, "Matrix: no assembled data");
+        int64_t nr, nc, nnz;
+        feddCheck(fedd_csr_sizes(dev_->ctx, &nr, &nc, &nnz), "fedd_csr_sizes");
+        rowptr_.resize(nr + 1); col_.resize(nnz); val_.resize(nnz); colGid_.resize(nc);
+        feddCheck(fedd_csr_get(dev_->ctx, rowptr_.data(), col_.data(), val_.data(), colGid_.data()), "fedd_csr_get");
+        hostValid_ = true;
+    }
+    MapConstPtr_Type map_;
+    DeviceContextPtr dev_;
+    long gen_ = -1;
+    int dofs_ = 1;
+    bool filled_ = false, hostValid_ = false;
+    std::vector<int64_t> rowptr_, colGid_;
+    std::vector<int32_t> col_;
+    std::vector<double> val_;
+};
+
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class BlockMatrix {
+public:
+    typedef Matrix<SC, LO, GO, NO> Matrix_Type;
+    typedef Teuchos::RCP<Matrix_Type> MatrixPtr_Type;
+    BlockMatrix(UN size) : n_(size), blocks_(size * size) {}
+    UN size() const { return n_; }
+    void addBlock(const MatrixPtr_Type& m, UN i, UN j) { blocks_.at(i * n_ + j) = m; }
+    bool blockExists(UN i, UN j) const { return !blocks_.at(i * n_ + j).is_null(); }
+    MatrixPtr_Type getBlock(UN i, UN j) const {
+        TEUCHOS_TEST_FOR_EXCEPTION(!blockExists(i, j), std::runtime_error, "Block does not exist.");
+        return blocks_[i * n_ + j];
+    }
+private:
+    UN n_;
+    std::vector<MatrixPtr_Type> blocks_;
+};
+
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class BlockMultiVector {
+public:
+    typedef MultiVector<SC, LO, GO, NO> MultiVector_Type;
+    typedef Teuchos::RCP<MultiVector_Type> MultiVectorPtr_Type;
+    BlockMultiVector(UN size) : blocks_(size) {}
+    UN size() const { return (UN)blocks_.size(); }
+    UN getNumVectors() const { return blocks_.empty() || blocks_[0].is_null() ? 0 : blocks_[0]->getNumVectors(); }
+    void addBlock(const MultiVectorPtr_Type& mv, UN i) { blocks_.at(i) = mv; }
+    Teuchos::RCP<const MultiVector_Type> getBlock(UN i) const { return blocks_.at(i); }
+    MultiVectorPtr_Type getBlockNonConst(UN i) { return blocks_.at(i); }
+    void putScalar(const SC& v) { for (auto& b : blocks_) if (!b.is_null()) b->putScalar(v); }
+    void update(const SC& a, const BlockMultiVector& A, const SC& b) {
+        for (size_t i = 0; i < blocks_.size(); ++i) blocks_[i]->update(a, *A.blocks_[i], b);
+    }
+private:
+    std::vector<MultiVectorPtr_Type> blocks_;
+};
+
+// FiniteElement / Elements: same accessors over a flat connectivity array (FiniteElement.hpp:17-100)
+class FiniteElement {
+public:
+    FiniteElement(const int32_t* nodes, int nen, int flag) : nodes_(nodes, nodes + nen), flag_(flag) {}
+    const vec_int_Type& getVectorNodeList() const { return nodes_; }
+    int getNode(int i) const { return nodes_.at(i); }
+    int getFlag() const { return flag_; }
+    int size() const { return (int)nodes_.size(); }
+private:
+    vec_int_Type nodes_;
+    int flag_;
+};
+class Elements {
+public:
+    Elements(const std::vector<int32_t>& conn, int nen) : conn_(&conn), nen_(nen) {}
+    UN numberElements() const { return (UN)(conn_->size() / nen_); }
+    FiniteElement getElement(UN T) const { return FiniteElement(conn_->data() + (size_t)T * nen_, nen_, 0); }
+    int nodesPerElement() const { return nen_; }
+private:
+    const std::vector<int32_t>* conn_;
+    int nen_;
+};
+typedef Teuchos::RCP<Elements> ElementsPtr_Type;
+
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class Domain {
+public:
+    typedef Map<LO, GO, NO> Map_Type;
+    typedef Teuchos::RCP<const Map_Type> MapConstPtr_Type;
+    typedef Teuchos::Comm<int> Comm_Type;
+    typedef Teuchos::RCP<const Comm_Type> CommConstPtr_Type;
+
+    Domain(CommConstPtr_Type comm, int dimension = 0) : comm_(comm), dim_(dimension) {}
+    Domain(vec_dbl_Type coor, double l, double h, CommConstPtr_Type comm) : comm_(comm), coorRec(coor), length(l), height(h) {}
+    Domain(vec_dbl_Type coor, double l, double w, double h, CommConstPtr_Type comm) : comm_(comm), coorRec(coor), length(l), width(w), height(h) {}
+
+    // Domain::buildMesh (Domain_def.hpp:201-265): structured square / cube, P1
+    void buildMesh(int flagsOption, std::string meshType, int dim, std::string FEType, int N, int M, int numProcsCoarseSolve = 0) {
+        TEUCHOS_TEST_FOR_EXCEPTION(meshType != "Square", std::logic_error,
+                                   "Select valid mesh. Structured types are 'structured' and 'structured_bfs'; only 'Square' (rectangle/box) is built here.");
+        TEUCHOS_TEST_FOR_EXCEPTION(dim != 2 && dim != 3, std::logic_error, "Select valid mesh dimension. 2 or 3 dimensional meshes can be constructed.");
+        TEUCHOS_TEST_FOR_EXCEPTION(FEType != "P1", std::logic_error, "Wrong FE-Type: the structured generator of this build makes P1 meshes.");
+        TEUCHOS_TEST_FOR_EXCEPTION(!(M >= 1), std::logic_error, "H/h is to small.");
+        TEUCHOS_TEST_FOR_EXCEPTION(numProcsCoarseSolve != 0, std::logic_error, "Mpi Ranks Coarse is not supported.");
+        dim_ = dim; FEType_ = FEType; n_ = N; m_ = M; flagsOption_ = flagsOption;
+        const int rank = comm_->getRank();
+        int dec[3] = {N, N, N}, cel[3] = {M, M, M};
+        int64_t ne, nr, nu, ng;
+        feddCheck(fedd_mesh_structured_sizes(dim, dec, cel, rank, 0, &ne, &nr, &nu, &ng), "fedd_mesh_structured_sizes");
+        conn_.resize(ne * (dim + 1)); xyz_.resize(nr * dim); flagRep_.resize(nr); flagUni_.resize(nu);
+        std::vector<int64_t> grep(nr), guni(nu);
+        double org[3] = {0, 0, 0}, sz[3] = {length, dim == 2 ? height : width, height};
+        for (size_t d = 0; d < coorRec.size() && d < 3; ++d) org[d] = coorRec[d];
+        feddCheck(fedd_mesh_structured_build(dim, dec, cel, rank, org, sz, flagsOption, 0, conn_.data(), xyz_.data(), grep.data(),
+                                             flagRep_.data(), guni.data(), flagUni_.data()), "fedd_mesh_structured_build");
+        finishMesh(grep, guni, dim + 1, ng);
+    }
+    // generic entry for externally built (e.g. unstructured, P2) meshes in the reference's data model
+    void setMesh(int dim, std::string FEType, int nen, const std::vector<int32_t>& conn, const std::vector<double>& xyz,
+                 const std::vector<int64_t>& gidRep, const std::vector<int64_t>& gidUni, const std::vector<int32_t>& flagUni) {
+        dim_ = dim; FEType_ = FEType; conn_ = conn; xyz_ = xyz; flagUni_ = flagUni; flagRep_.assign(gidRep.size(), 0);
+        int64_t ng = 0;
+        for (auto g : gidRep) ng = std::max<int64_t>(ng, g + 1);
+        finishMesh(gidRep, gidUni, nen, ng);
+    }
+
+    LO getApproxEntriesPerRow() const {      // Domain_def.hpp:176-198 (allocation hint only)
+        if (dim_ == 2) return FEType_ == "P1" ? 20 : 30;
+        return FEType_ == "P1" ? 50 : (FEType_ == "P2" ? 80 : 100);
+    }
+    UN getDimension() const { return (UN)dim_; }
+    std::string getFEType() const { return FEType_; }
+    CommConstPtr_Type getComm() const { return comm_; }
+    MapConstPtr_Type getMapUnique() const { return mapUnique_; }
+    MapConstPtr_Type getMapRepeated() const { return mapRepeated_; }
+    MapConstPtr_Type getMapVecFieldUnique() const { return mapUnique_->buildVecFieldMap(dim_); }
+    MapConstPtr_Type getMapVecFieldRepeated() const { return mapRepeated_->buildVecFieldMap(dim_); }
+    vec2D_dbl_ptr_Type getPointsRepeated() const { return points(xyz_, (size_t)mapRepeated_->getNodeNumElements(), nullptr); }
+    vec2D_dbl_ptr_Type getPointsUnique() const { return points(xyz_, (size_t)mapUnique_->getNodeNumElements(), &uniOfRep_); }
+    vec_int_ptr_Type getBCFlagUnique() const { return Teuchos::rcp(new vec_int_Type(flagUni_.begin(), flagUni_.end())); }
+    vec_int_ptr_Type getBCFlagRepeated() const { return Teuchos::rcp(new vec_int_Type(flagRep_.begin(), flagRep_.end())); }
+    ElementsPtr_Type getElementsC() const { return Teuchos::rcp(new Elements(conn_, nen_)); }
+    LO getNumElements() const { return (LO)(conn_.size() / nen_); }
+    GO getNumElementsGlobal() const { return (GO)(conn_.size() / nen_); }
+    LO getNumPoints(std::string type = "Unique") const { return type == "Unique" ? mapUnique_->getNodeNumElements() : mapRepeated_->getNodeNumElements(); }
+    void info() const {
+        if (comm_->getRank() == 0)
+            std::cout << "\t### Domain: dim " << dim_ << ", FE " << FEType_ << ", elements " << getNumElements() << ", nodes "
+                      << mapUnique_->getGlobalNumElements() << " ###" << std::endl;
+    }
+    // facade internals
+    DeviceContextPtr device() const { return dev_; }
+    int nodesPerElement() const { return nen_; }
+    const std::vector<double>& xyzRepeated() const { return xyz_; }
+    const std::vector<int32_t>& uniqueLocalOfRepeated() const { return uniOfRep_; }
+
+private:
+    void finishMesh(const std::vector<int64_t>& grep, const std::vector<int64_t>& guni, int nen, int64_t nGlobal) {
+        nen_ = nen;
+        std::vector<GO> gr(grep.begin(), grep.end()), gu(guni.begin(), guni.end());
+        mapRepeated_ = Teuchos::rcp(new Map_Type(gr, comm_));
+        mapUnique_ = Teuchos::rcp(new Map_Type(gu, comm_));
+        // repeated-local id of every unique node (for getPointsUnique)
+        uniOfRep_.assign(guni.size(), -1);
+        std::vector<std::pair<int64_t, int32_t>> s(grep.size());
+        for (size_t i = 0; i < grep.size(); ++i) s[i] = {grep[i], (int32_t)i};
+        std::sort(s.begin(), s.end());
+        for (size_t i = 0; i < guni.size(); ++i) {
+            auto it = std::lower_bound(s.begin(), s.end(), std::make_pair(guni[i], (int32_t)-1));
+            TEUCHOS_TEST_FOR_EXCEPTION(it == s.end() || it->first != guni[i], std::runtime_error, "unique node missing from repeated map");
+            uniOfRep_[i] = it->second;
+        }
+        (void)nGlobal;
+        const char* lr = std::getenv("LOCAL_RANK");
+        dev_ = Teuchos::rcp(new DeviceContext(lr ? std::atoi(lr) : 0));
+        feddCheck(fedd_mesh_set(dev_->ctx, dim_, nen_, (int64_t)(conn_.size() / nen_), conn_.data(), (int64_t)grep.size(), xyz_.data(),
+                                grep.data(), (int64_t)guni.size(), guni.data(), flagUni_.data()), "fedd_mesh_set");
+    }
+    vec2D_dbl_ptr_Type points(const std::vector<double>& xyz, size_t n, const std::vector<int32_t>* idx) const {
+        vec2D_dbl_ptr_Type p = Teuchos::rcp(new vec2D_dbl_Type(n, vec_dbl_Type(dim_, 0.)));
+        for (size_t i = 0; i < n; ++i) {
+            const size_t src = idx ? (size_t)(*idx)[i] : i;
+            for (int d = 0; d < dim_; ++d) (*p)[i][d] = xyz[src * dim_ + d];
+        }
+        return p;
+    }
+    CommConstPtr_Type comm_;
+    vec_dbl_Type coorRec;
+    double length = 1., width = 1., height = 1.;
+    int dim_ = 0, n_ = 0, m_ = 0, flagsOption_ = 0, nen_ = 0;
+    std::string FEType_;
+    std::vector<int32_t> conn_, flagRep_, flagUni_, uniOfRep_;
+    std::vector<double> xyz_;
+    Teuchos::RCP<Map_Type> mapRepeated_, mapUnique_;
+    DeviceContextPtr dev_;
+};
+
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class FE {
+public:
+    typedef Domain<SC, LO, GO, NO> Domain_Type;
+    typedef Teuchos::RCP<const Domain_Type> DomainConstPtr_Type;
+    typedef Matrix<SC, LO, GO, NO> Matrix_Type;
+    typedef Teuchos::RCP<Matrix_Type> MatrixPtr_Type;
+    typedef MultiVector<SC, LO, GO, NO> MultiVector_Type;
+    typedef Teuchos::RCP<MultiVector_Type> MultiVectorPtr_Type;
+
+    FE(bool saveAssembly = false) { (void)saveAssembly; }
+    void addFE(DomainConstPtr_Type domain) { domainVec_.push_back(domain); }
+    void doSetZeros(double eps = 10 * 2.220446049250313e-16) { setZeros_ = true; myeps_ = eps; }
+
+    // FE_def.hpp:6932-6953
+    UN checkFE(int dim, std::string FEType) const {
+        for (UN i = 0; i < domainVec_.size(); ++i)
+            if ((int)domainVec_[i]->getDimension() == dim && domainVec_[i]->getFEType() == FEType) return i;
+        TEUCHOS_TEST_FOR_EXCEPTION(true, std::runtime_error, "Wrong FEType or dimension. No assembly possible.");
+        return 0;
+    }
+    void assemblyLaplace(int dim, std::string FEType, int degree, MatrixPtr_Type& A, bool callFillComplete = true, int FELocExternal = -1) {
+        TEUCHOS_TEST_FOR_EXCEPTION(FEType == "P0", std::logic_error, "Not implemented for P0");
+        (void)degree;
+        assembleInto(FELocExternal < 0 ? checkFE(dim, FEType) : (UN)FELocExternal, 1, FEDD_BLOCK_SCALAR, FEDD_FORM_LAPLACE, nullptr, A, callFillComplete);
+    }
+    void assemblyLaplaceVecField(int dim, std::string FEType, int degree, MatrixPtr_Type& A, bool callFillComplete = true) {
+        TEUCHOS_TEST_FOR_EXCEPTION(FEType == "P1-disc" || FEType == "P0", std::logic_error, "Not implemented for P0 or P1-disc");
+        (void)degree;
+        TEUCHOS_TEST_FOR_EXCEPTION(setZeros_, std::logic_error, "doSetZeros thresholding is not built into the device assembly");
+        assembleInto(checkFE(dim, FEType), dim, FEDD_BLOCK_DIAG, FEDD_FORM_LAPLACE_VEC, nullptr, A, callFillComplete);
+    }
+    void assemblyMass(int dim, std::string FEType, std::string fieldType, MatrixPtr_Type& A, bool callFillComplete = true) {
+        TEUCHOS_TEST_FOR_EXCEPTION(FEType == "P0", std::logic_error, "Not implemented for P0");
+        if (fieldType == "Scalar") assembleInto(checkFE(dim, FEType), 1, FEDD_BLOCK_SCALAR, FEDD_FORM_MASS, nullptr, A, callFillComplete);
+        else if (fieldType == "Vector") assembleInto(checkFE(dim, FEType), dim, FEDD_BLOCK_DIAG, FEDD_FORM_MASS_VEC, nullptr, A, callFillComplete);
+        else TEUCHOS_TEST_FOR_EXCEPTION(true, std::logic_error, "Specify valid vieldType for assembly of mass matrix.");
+    }
+    void assemblyLinElasXDim(int dim, std::string FEType, MatrixPtr_Type& A, double lambda, double mu, bool callFillComplete = true) {
+        TEUCHOS_TEST_FOR_EXCEPTION(FEType == "P0", std::logic_error, "Not implemented for P0");
+        const double p[2] = {lambda, mu};
+        assembleInto(checkFE(dim, FEType), dim, FEDD_BLOCK_FULL, FEDD_FORM_LINELAS, p, A, callFillComplete);
+    }
+    // FE::assemblyRHS (FE_def.hpp:4694-4766): f evaluated once (constant); a lives on the REPEATED
+    // map in the reference and is then export-added; here the owned entries are produced directly,
+    // `a` must live on the unique (vec-field) map.
+    void assemblyRHS(int dim, std::string FEType, MultiVectorPtr_Type a, std::string fieldType, RhsFunc_Type func, std::vector<SC>& funcParameter) {
+        TEUCHOS_TEST_FOR_EXCEPTION(FEType == "P0", std::logic_error, "Not implemented for P0");
+        TEUCHOS_TEST_FOR_EXCEPTION(a.is_null(), std::runtime_error, "MultiVector in assemblyConstRHS is null.");
+        TEUCHOS_TEST_FOR_EXCEPTION(a->getNumVectors() > 1, std::logic_error, "Implement for numberMV > 1 .");
+        const UN loc = checkFE(dim, FEType);
+        const int dofs = fieldType == "Scalar" ? 1 : (fieldType == "Vector" ? dim : 0);
+        TEUCHOS_TEST_FOR_EXCEPTION(dofs == 0, std::logic_error, "Invalid field type.");
+        const int degFunc = (int)(funcParameter[funcParameter.size() - 1] + 1.e-14);
+        double x = 0., f[3] = {0, 0, 0};
+        func(&x, f, funcParameter.data());            // "for now just const!" (FE_def.hpp:4731-4736)
+        fedd_ctx* ctx = domainVec_[loc]->device()->ctx;
+        int64_t nr = 0, nc = 0, nnz = 0;
+        if (fedd_csr_sizes(ctx, &nr, &nc, &nnz) != 0 || nr != (int64_t)a->getLocalLength()) {
+            int64_t dummy;                             // rhs before any matrix: build the matching pattern
+            feddCheck(fedd_pattern_build(ctx, dofs, dofs == 1 ? FEDD_BLOCK_SCALAR : FEDD_BLOCK_DIAG, &dummy), "fedd_pattern_build");
+            domainVec_[loc]->device()->generation++;
+        }
+        feddCheck(fedd_assemble_rhs(ctx, dofs, f, degFunc), "fedd_assemble_rhs");
+        feddCheck(fedd_rhs_get(ctx, a->raw().data()), "fedd_rhs_get");
+    }
+private:
+    void assembleInto(UN loc, int dofs, int mode, int form, const double* params, MatrixPtr_Type& A, bool callFillComplete) {
+        TEUCHOS_TEST_FOR_EXCEPTION(A.is_null(), std::runtime_error, "Matrix is null.");
+        auto dom = domainVec_.at(loc);
+        TEUCHOS_TEST_FOR_EXCEPTION((size_t)A->getMap()->getNodeNumElements() != (size_t)dom->getMapUnique()->getNodeNumElements() * dofs,
+                                   std::logic_error, "Matrix row map does not match the unique map of the domain.");
+        fedd_ctx* ctx = dom->device()->ctx;
+        int64_t nnz;
+        feddCheck(fedd_pattern_build(ctx, dofs, mode, &nnz), "fedd_pattern_build");
+        feddCheck(fedd_assemble(ctx, form, params), "fedd_assemble");
+        dom->device()->generation++;
+        A->bind(dom->device(), dofs);
+        if (!callFillComplete) A->resumeFill();
+    }
+    std::vector<DomainConstPtr_Type> domainVec_;
+    bool setZeros_ = false;
+    double myeps_ = 0.;
+};
+
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class BCBuilder {
+public:
+    typedef Domain<SC, LO, GO, NO> Domain_Type;
+    typedef Teuchos::RCP<Domain_Type> DomainPtr_Type;
+    typedef Teuchos::RCP<const Domain_Type> DomainConstPtr_Type;
+    typedef BlockMatrix<SC, LO, GO, NO> BlockMatrix_Type;
+    typedef Teuchos::RCP<BlockMatrix_Type> BlockMatrixPtr_Type;
+    typedef BlockMultiVector<SC, LO, GO, NO> BlockMultiVector_Type;
+    typedef Teuchos::RCP<BlockMultiVector_Type> BlockMultiVectorPtr_Type;
+
+    BCBuilder() {}
+    void addBC(BC_func_Type funcBC, int flag, int block, const DomainPtr_Type& domain, std::string type, int dofs) {
+        vec_dbl_Type dummy(1, 0.);
+        addBC(funcBC, flag, block, domain, type, dofs, dummy);
+    }
+    void addBC(BC_func_Type funcBC, int flag, int block, const DomainPtr_Type& domain, std::string type, int dofs, vec_dbl_Type& parameter_vec) {
+        vecBC_func_.push_back(funcBC); vecFlag_.push_back(flag); vecBlockID_.push_back(block); vecDomain_.push_back(domain);
+        vecBCType_.push_back(type); vecDofs_.push_back(dofs); vecBC_Parameters_.push_back(parameter_vec);
+    }
+    bool findFlag(LO flag, int block, int& loc) const {   // BCBuilder_def.hpp findFlag
+        for (size_t i = 0; i < vecFlag_.size(); ++i)
+            if (vecFlag_[i] == flag && vecBlockID_[i] == block) { loc = (int)i; return true; }
+        return false;
+    }
+    bool blockHasDirichletBC(int block) const { int l; return blockHasDirichletBC(block, l); }
+    bool blockHasDirichletBC(int block, int& loc) const {
+        for (size_t i = 0; i < vecBlockID_.size(); ++i)
+            if (vecBlockID_[i] == block && vecBCType_[i].compare(0, 9, "Dirichlet") == 0) { loc = (int)i; return true; }
+        return false;
+    }
+    // BCBuilder::set = setSystem + setRHS (BCBuilder_def.hpp:84-90).  The device call does both for
+    // the diagonal block; the host evaluates the user function at every flagged unique node.
+    void set(const BlockMatrixPtr_Type& blockMatrix, const BlockMultiVectorPtr_Type& blockMV, double t = 0.) const {
+        TEUCHOS_TEST_FOR_EXCEPTION(blockMV->getNumVectors() > 1, std::runtime_error, "BCBuilder::setRHS() only for getNumVectors == 1.");
+        for (UN block = 0; block < blockMatrix->size(); ++block) {
+            int loc0;
+            if (!blockHasDirichletBC((int)block, loc0)) continue;
+            TEUCHOS_TEST_FOR_EXCEPTION(blockMatrix->size() > 1, std::logic_error, "block systems: Dirichlet rows of off-diagonal blocks are not built yet");
+            auto A = blockMatrix->getBlock(block, block);
+            TEUCHOS_TEST_FOR_EXCEPTION(!A->isResident(), std::runtime_error, "BCBuilder: the matrix block is not resident on the device");
+            auto dom = vecDomain_.at(loc0);
+            const int dofs = vecDofs_.at(loc0), dim = (int)dom->getDimension();
+            vec_int_ptr_Type flags = dom->getBCFlagUnique();
+            vec2D_dbl_ptr_Type pts = dom->getPointsUnique();
+            std::vector<int32_t> nodes, mask;
+            std::vector<double> values;
+            vec_dbl_Type result(dofs, 0.), point(dim, 0.);
+            for (size_t i = 0; i < flags->size(); ++i) {
+                int loc;
+                if (!findFlag((*flags)[i], (int)block, loc)) continue;
+                const std::string& ty = vecBCType_[loc];
+                if (ty.compare(0, 9, "Dirichlet") != 0) continue;
+                for (int d = 0; d < dim; ++d) point[d] = (*pts)[i][d];
+                for (int d = 0; d < dofs; ++d) result[d] = d < dim ? (*pts)[i][d] : 0.;   // :136-138
+                vecBC_func_[loc](point.data(), result.data(), t, vecBC_Parameters_[loc].data());
+                nodes.push_back((int32_t)i);
+                for (int d = 0; d < dofs; ++d) {
+                    const bool on = ty == "Dirichlet" || (ty == "Dirichlet_X" && d == 0) || (ty == "Dirichlet_Y" && d == 1) ||
+                                    (ty == "Dirichlet_Z" && d == 2) || (ty == "Dirichlet_X_Y" && d != 2) ||
+                                    (ty == "Dirichlet_X_Z" && d != 1) || (ty == "Dirichlet_Y_Z" && d != 0);
+                    mask.push_back(on ? 1 : 0);
+                    values.push_back(result[d]);
+                }
+            }
+            fedd_ctx* ctx = A->device()->ctx;
+            // push the current rhs, apply rows + rhs on the device, pull the rhs back
+            feddCheck(fedd_rhs_set(ctx, blockMV->getBlockNonConst(block)->raw().data()), "fedd_rhs_set");
+            feddCheck(fedd_dirichlet_nodes(ctx, (int64_t)nodes.size(), nodes.data(), mask.data(), values.data()), "fedd_dirichlet_nodes");
+            feddCheck(fedd_rhs_get(ctx, blockMV->getBlockNonConst(block)->raw().data()), "fedd_rhs_get");
+            A->invalidateHost();
+        }
+    }
+private:
+    std::vector<BC_func_Type> vecBC_func_;
+    std::vector<int> vecFlag_, vecBlockID_, vecDofs_;
+    std::vector<DomainPtr_Type> vecDomain_;
+    std::vector<std::string> vecBCType_;
+    std::vector<vec_dbl_Type> vecBC_Parameters_;
+};
+
+template <class SC, class LO, class GO, class NO>
+class Problem;
+
+// LinearSolver::solve -> solveMonolithic (LinearSolver_def.hpp:23-135): GMRES + one-level Schwarz on
+// the device, configured from the same ParameterList entries the reference hands to Stratimikos.
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class LinearSolver {
+public:
+    typedef Problem<SC, LO, GO, NO> Problem_Type;
+    typedef BlockMultiVector<SC, LO, GO, NO> BlockMultiVector_Type;
+    typedef Teuchos::RCP<BlockMultiVector_Type> BlockMultiVectorPtr_Type;
+    int solve(Problem_Type* problem, BlockMultiVectorPtr_Type rhs, std::string type = "Monolithic");
+    double lastRelativeResidual = 0.;
+};
+
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class Problem {
+public:
+    typedef Domain<SC, LO, GO, NO> Domain_Type;
+    typedef Teuchos::RCP<const Domain_Type> DomainConstPtr_Type;
+    typedef std::vector<DomainConstPtr_Type> DomainConstPtr_vec_Type;
+    typedef Matrix<SC, LO, GO, NO> Matrix_Type;
+    typedef Teuchos::RCP<Matrix_Type> MatrixPtr_Type;
+    typedef BlockMatrix<SC, LO, GO, NO> BlockMatrix_Type;
+    typedef Teuchos::RCP<BlockMatrix_Type> BlockMatrixPtr_Type;
+    typedef MultiVector<SC, LO, GO, NO> MultiVector_Type;
+    typedef Teuchos::RCP<MultiVector_Type> MultiVectorPtr_Type;
+    typedef BlockMultiVector<SC, LO, GO, NO> BlockMultiVector_Type;
+    typedef Teuchos::RCP<BlockMultiVector_Type> BlockMultiVectorPtr_Type;
+    typedef BCBuilder<SC, LO, GO, NO> BC_Type;
+    typedef Teuchos::RCP<const BC_Type> BCConstPtr_Type;
+    typedef FE<SC, LO, GO, NO> FEFac_Type;
+    typedef Teuchos::RCP<FEFac_Type> FEFacPtr_Type;
+    typedef Teuchos::Comm<int> Comm_Type;
+    typedef Teuchos::RCP<const Comm_Type> CommConstPtr_Type;
+
+    Problem(ParameterListPtr_Type& parameterList, CommConstPtr_Type comm)
+        : dim_(-1), comm_(comm), verbose_(comm->getRank() == 0), parameterList_(parameterList), feFactory_(new FEFac_Type()) {}
+    virtual ~Problem() {}
+    virtual void info() = 0;
+    void infoProblem() {
+        if (verbose_) {
+            std::cout << "\t ### Problem Information ###" << std::endl;
+            for (size_t i = 0; i < domainPtr_vec_.size(); ++i)
+                std::cout << "\t ### Variable " << variableName_vec_[i] << ": dofs/node " << dofsPerNode_vec_[i] << ", FE " << domain_FEType_vec_[i] << std::endl;
+        }
+    }
+    void addVariable(const DomainConstPtr_Type& domain, std::string FEType, std::string name, int dofsPerNode) {
+        domainPtr_vec_.push_back(domain); domain_FEType_vec_.push_back(FEType); variableName_vec_.push_back(name);
+        dofsPerNode_vec_.push_back(dofsPerNode); feFactory_->addFE(domain);
+    }
+    void addRhsFunction(RhsFunc_Type func) { rhsFuncVec_.push_back(func); }
+    RhsFunc_Type& getRhsFunction(int i) { return rhsFuncVec_.at(i); }
+    virtual void assemble(std::string type = "") const = 0;
+
+    void assembleSourceTerm(double time = 0.) const {                 // Problem_def.hpp:170-181
+        TEUCHOS_TEST_FOR_EXCEPTION(sourceTerm_.is_null(), std::runtime_error, "Initialize source term before you assemble it - sourceTerm pointer is null");
+        sourceTerm_->putScalar(0.);
+        std::string sourceType = parameterList_->sublist("Parameter").get("Source Type", "volume");
+        TEUCHOS_TEST_FOR_EXCEPTION(sourceType != "volume", std::logic_error, "only volume source terms are built");
+        assembleVolumeTerm(time);
+    }
+    void assembleVolumeTerm(double time) const {                      // Problem_def.hpp:184-216
+        for (UN i = 0; i < sourceTerm_->size(); ++i) {
+            if (i < rhsFuncVec_.size() && rhsFuncVec_[i]) {
+                vec_dbl_Type funcParameter(1, 0.);
+                funcParameter[0] = time;
+                for (double p : parasSourceFunc_) funcParameter.push_back(p);
+                const std::string type = getDofsPerNode((int)i) > 1 ? "Vector" : "Scalar";
+                feFactory_->assemblyRHS(dim_, domain_FEType_vec_.at(i), sourceTerm_->getBlockNonConst(i), type, rhsFuncVec_[i], funcParameter);
+            }
+        }
+    }
+    bool hasSourceTerm() const { return !sourceTerm_.is_null(); }
+    int solve(BlockMultiVectorPtr_Type rhs = Teuchos::null) {         // Problem_def.hpp:257-295
+        if (verbose_) std::cout << "-- Solve System ..." << std::endl;
+        LinearSolver<SC, LO, GO, NO> linSolver;
+        std::string type = parameterList_->sublist("General").get("Preconditioner Method", "Monolithic");
+        int its = linSolver.solve(this, rhs, type);
+        lastRelativeResidual_ = linSolver.lastRelativeResidual;
+        if (verbose_) std::cout << " done. -- " << its << " iterations, relative residual " << lastRelativeResidual_ << std::endl;
+        return its;
+    }
+    void addBoundaries(const BCConstPtr_Type& bcFactory) { bcFactory_ = bcFactory; }
+    void setBoundaries(double time = .0) const {                      // Problem_def.hpp:298-304
+        TEUCHOS_TEST_FOR_EXCEPTION(bcFactory_.is_null(), std::runtime_error, "No boundary conditions added.");
+        bcFactory_->set(system_, rhs_, time);
+    }
+    void initializeProblem(int nmbVectors = 1) {                      // Problem_def.hpp:134-139
+        system_.reset(new BlockMatrix_Type((UN)domainPtr_vec_.size()));
+        initializeVectors(nmbVectors);
+    }
+    void initializeVectors(int nmbVectors = 1) {                      // Problem_def.hpp:332-360
+        const UN size = (UN)domainPtr_vec_.size();
+        solution_.reset(new BlockMultiVector_Type(size));
+        rhs_.reset(new BlockMultiVector_Type(size));
+        sourceTerm_.reset(new BlockMultiVector_Type(size));
+        for (UN i = 0; i < size; ++i) {
+            auto map = dofsPerNode_vec_[i] > 1 ? domainPtr_vec_[i]->getMapVecFieldUnique() : domainPtr_vec_[i]->getMapUnique();
+            solution_->addBlock(Teuchos::rcp(new MultiVector_Type(map, nmbVectors)), i);
+            rhs_->addBlock(Teuchos::rcp(new MultiVector_Type(map, nmbVectors)), i);
+            sourceTerm_->addBlock(Teuchos::rcp(new MultiVector_Type(map, nmbVectors)), i);
+        }
+    }
+    BlockMultiVectorPtr_Type getRhs() const { return rhs_; }
+    BlockMultiVectorPtr_Type getSolution() { return solution_; }
+    BlockMatrixPtr_Type getSystem() const { return system_; }
+    bool getVerbose() const { return verbose_; }
+    DomainConstPtr_Type getDomain(int i) const { return domainPtr_vec_.at(i); }
+    std::string getFEType(int i) const { return domain_FEType_vec_.at(i); }
+    std::string getVariableName(int i) const { return variableName_vec_.at(i); }
+    int getDofsPerNode(int i) const { return dofsPerNode_vec_.at(i); }
+    ParameterListPtr_Type getParameterList() const { return parameterList_; }
+    void addToRhs(BlockMultiVectorPtr_Type x) const { rhs_->update(1., *x, 1.); }   // Problem_def.hpp:450-454
+    BlockMultiVectorPtr_Type getSourceTerm() { return sourceTerm_; }
+    CommConstPtr_Type getComm() const { return comm_; }
+    void addParemeterRhs(double para) { parasSourceFunc_.push_back(para); }
+    double getLastRelativeResidual() const { return lastRelativeResidual_; }
+
+    int dim_;
+    mutable CommConstPtr_Type comm_;
+    mutable BlockMatrixPtr_Type system_;
+    mutable BlockMultiVectorPtr_Type rhs_;
+    mutable BlockMultiVectorPtr_Type solution_;
+    bool verbose_;
+protected:
+    mutable ParameterListPtr_Type parameterList_;
+    mutable DomainConstPtr_vec_Type domainPtr_vec_;
+    std::vector<std::string> domain_FEType_vec_, variableName_vec_;
+    mutable BCConstPtr_Type bcFactory_;
+    FEFacPtr_Type feFactory_;
+    std::vector<int> dofsPerNode_vec_;
+    mutable BlockMultiVectorPtr_Type sourceTerm_;
+    std::vector<RhsFunc_Type> rhsFuncVec_;
+    vec_dbl_Type parasSourceFunc_;
+    double lastRelativeResidual_ = 0.;
+};
+
+template <class SC, class LO, class GO, class NO>
+int LinearSolver<SC, LO, GO, NO>::solve(Problem_Type* problem, BlockMultiVectorPtr_Type rhs, std::string type) {
+    TEUCHOS_TEST_FOR_EXCEPTION(type != "Monolithic" && type != "MonolithicConstPrec", std::logic_error,
+                               "Unknown solver type; only the monolithic path (LinearSolver_def.hpp:72-135) is built.");
+    auto system = problem->getSystem();
+    TEUCHOS_TEST_FOR_EXCEPTION(system->size() != 1, std::logic_error, "block systems need BlockMatrix::merge (not built yet)");
+    auto A = system->getBlock(0, 0);
+    TEUCHOS_TEST_FOR_EXCEPTION(!A->isResident(), std::runtime_error, "solve: the system matrix is not resident on the device");
+    fedd_ctx* ctx = A->device()->ctx;
+    auto pl = problem->getParameterList();
+    // same keys the reference's XML files use (laplace/parametersSolver.xml, parametersPrec.xml)
+    auto& belos = pl->sublist("ThyraSolver").sublist("Linear Solver Types").sublist("Belos");
+    const std::string solverType = belos.get("Solver Type", "Block GMRES");
+    auto& gm = belos.sublist("Solver Types").sublist(solverType);
+    const double tol = gm.get("Convergence Tolerance", 1e-8);
+    const int maxIt = gm.get("Maximum Iterations", 100);
+    const int numBlocks = gm.get("Num Blocks", 100);
+    auto& frosch = pl->sublist("ThyraPreconditioner").sublist("Preconditioner Types").sublist("FROSch");
+    const std::string precType = pl->sublist("ThyraPreconditioner").get("Preconditioner Type", "FROSch");
+    const int overlap = frosch.get("Overlap", 1);
+    auto& ovl = frosch.sublist("AlgebraicOverlappingOperator");
+    std::string combine = ovl.get("Combine Values in Overlap", "");
+    if (combine.empty()) combine = ovl.get("Overlapping Operator Combination", "Restricted");
+    const int cmb = combine == "Averaging" ? FEDD_COMBINE_AVERAGING : (combine == "Full" ? FEDD_COMBINE_FULL : FEDD_COMBINE_RESTRICTED);
+    const bool usePrec = precType != "None";
+    if (usePrec && type != "MonolithicConstPrec") {
+        // TwoLevel (GDSW) requests run one-level here; say so instead of silently ignoring it
+        if (frosch.get("TwoLevel", false) && problem->getVerbose())
+            std::cout << "-- note: the GDSW coarse level is not built yet, running one-level Schwarz --" << std::endl;
+        const int target = frosch.get("Subdomain Nodes", 27);
+        feddCheck(fedd_schwarz_set_target(ctx, target, 1.0), "fedd_schwarz_set_target");
+        feddCheck(fedd_schwarz_setup(ctx, overlap, cmb, 0, 0), "fedd_schwarz_setup");
+    }
+    auto b = rhs.is_null() ? problem->getRhs() : rhs;
+    auto x = problem->getSolution();
+    int its = 0;
+    double rel = 0.;
+    feddCheck(fedd_gmres(ctx, b->getBlock(0)->raw().data(), x->getBlockNonConst(0)->raw().data(), tol, maxIt, numBlocks,
+                         usePrec ? 1 : 0, &its, &rel), "fedd_gmres");
+    lastRelativeResidual = rel;
+    return its;
+}
+
+// Laplace (feddlib/problems/specific/Laplace_def.hpp:16-60)
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class Laplace : public Problem<SC, LO, GO, NO> {
+public:
+    typedef Problem<SC, LO, GO, NO> Problem_Type;
+    typedef typename Problem_Type::DomainConstPtr_Type DomainConstPtr_Type;
+    typedef typename Problem_Type::Matrix_Type Matrix_Type;
+    typedef typename Problem_Type::MatrixPtr_Type MatrixPtr_Type;
+    Laplace(const DomainConstPtr_Type& domain, std::string FEType, ParameterListPtr_Type parameterList, bool vectorLaplace = false)
+        : Problem_Type(parameterList, domain->getComm()), vectorLaplace_(vectorLaplace) {
+        this->addVariable(domain, FEType, "u", vectorLaplace ? (int)domain->getDimension() : 1);
+        this->dim_ = (int)this->getDomain(0)->getDimension();
+    }
+    void info() override { this->infoProblem(); }
+    void assemble(std::string type = "") const override {
+        (void)type;
+        if (this->verbose_) std::cout << "-- Assembly Laplace ... " << std::flush;
+        MatrixPtr_Type A;
+        if (vectorLaplace_) {
+            A = Teuchos::rcp(new Matrix_Type(this->domainPtr_vec_.at(0)->getMapVecFieldUnique(), this->getDomain(0)->getApproxEntriesPerRow()));
+            this->feFactory_->assemblyLaplaceVecField(this->dim_, this->domain_FEType_vec_.at(0), 2, A);
+        } else {
+            A = Teuchos::rcp(new Matrix_Type(this->domainPtr_vec_.at(0)->getMapUnique(), this->getDomain(0)->getApproxEntriesPerRow()));
+            this->feFactory_->assemblyLaplace(this->dim_, this->domain_FEType_vec_.at(0), 2, A);
+        }
+        this->system_->addBlock(A, 0, 0);
+        this->assembleSourceTerm(0.);
+        this->addToRhs(this->sourceTerm_);
+        if (this->verbose_) std::cout << "done -- " << std::endl;
+    }
+    MatrixPtr_Type getMassMatrix() const {
+        MatrixPtr_Type A = Teuchos::rcp(new Matrix_Type(this->domainPtr_vec_.at(0)->getMapUnique(), this->getDomain(0)->getApproxEntriesPerRow()));
+        this->feFactory_->assemblyMass(this->dim_, this->domain_FEType_vec_.at(0), "Scalar", A);
+        return A;
+    }
+private:
+    bool vectorLaplace_;
+};
+
+// LinElas (feddlib/problems/specific/LinElas_def.hpp:64-99): lambda, E from mu, nu at :76-77
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class LinElas : public Problem<SC, LO, GO, NO> {
+public:
+    typedef Problem<SC, LO, GO, NO> Problem_Type;
+    typedef typename Problem_Type::DomainConstPtr_Type DomainConstPtr_Type;
+    typedef typename Problem_Type::Matrix_Type Matrix_Type;
+    typedef typename Problem_Type::MatrixPtr_Type MatrixPtr_Type;
+    LinElas(const DomainConstPtr_Type& domain, std::string FEType, ParameterListPtr_Type parameterList)
+        : Problem_Type(parameterList, domain->getComm()) {
+        this->addVariable(domain, FEType, "d_s", (int)domain->getDimension());
+        this->dim_ = (int)this->getDomain(0)->getDimension();
+    }
+    void info() override { this->infoProblem(); }
+    void assemble(std::string type = "") const override {
+        (void)type;
+        if (this->verbose_) std::cout << "-- Assembly linear elasticity ... " << std::flush;
+        const double mu = this->parameterList_->sublist("Parameter").get("Mu", 2.0e6);
+        const double nu = this->parameterList_->sublist("Parameter").get("Poisson Ratio", 0.4);
+        const double E = mu * 2. * (1. + nu);
+        const double lambda = nu * E / ((1. + nu) * (1. - 2. * nu));
+        MatrixPtr_Type K = Teuchos::rcp(new Matrix_Type(this->getDomain(0)->getMapVecFieldUnique(), this->getDomain(0)->getApproxEntriesPerRow()));
+        this->feFactory_->assemblyLinElasXDim(this->dim_, this->getDomain(0)->getFEType(), K, lambda, mu);
+        this->system_->addBlock(K, 0, 0);
+        this->assembleSourceTerm(0.);
+        this->addToRhs(this->sourceTerm_);
+        if (this->verbose_) std::cout << "done -- " << std::endl;
+    }
+};
+
+}  // namespace FEDD

@@ -122,6 +122,12 @@ int fedd_assemble_rhs(fedd_ctx* ctx, int dofs_per_node, const double* f_const, i
 int fedd_dirichlet(fedd_ctx* ctx, int n_bc, const int32_t* flags, const int32_t* comp_mask,
                    const double* values);
 
+/* same, for boundary values that depend on the node (the host evaluates the user's BC function at
+ * every flagged unique node, BCBuilder_def.hpp:128-143, and passes the results): owned_nodes[n]
+ * local unique-map node ids, comp_mask[n*dofs] (nullable), values[n*dofs]. */
+int fedd_dirichlet_nodes(fedd_ctx* ctx, int64_t n, const int32_t* owned_nodes, const int32_t* comp_mask,
+                         const double* values);
+
 /* read-back for Tpetra::CrsMatrix fill / parity (Matrix::getLocalRowView analog). col_gid maps
  * a local column index to its global dof id. */
 int fedd_csr_sizes(fedd_ctx* ctx, int64_t* n_rows, int64_t* n_cols, int64_t* nnz);
