@@ -293,6 +293,27 @@ static double dot(const double* a, const double* b, int64_t n) {
     return s;
 }
 
+/* h[c] = V_c . w for c <= j, one sweep over row blocks (memory-bound like the GPU multi-dot) */
+static void multidot(const double* V, const double* w, int64_t n, int ncols, double* h) {
+    for (int c = 0; c < ncols; ++c) h[c] = 0.0;
+    #pragma omp parallel
+    {
+        double loc[1024];
+        for (int c = 0; c < ncols; ++c) loc[c] = 0.0;
+        #pragma omp for schedule(static) nowait
+        for (int64_t blk = 0; blk < (n + 2047) / 2048; ++blk) {
+            const int64_t i0 = blk * 2048, i1 = i0 + 2048 < n ? i0 + 2048 : n;
+            for (int c = 0; c < ncols; ++c) {
+                const double* v = V + (size_t)c * n; double s = 0.0;
+                for (int64_t i = i0; i < i1; ++i) s += v[i] * w[i];
+                loc[c] += s;
+            }
+        }
+        #pragma omp critical
+        for (int c = 0; c < ncols; ++c) h[c] += loc[c];
+    }
+}
+
 /* right-preconditioned GMRES(m), CGS + DGKS second pass, Givens; returns iterations */
 static int gmres(const Problem* P, const Ras* R, const double* b, double* x, double rtol, int max_it, int restart, double* relres_out) {
     const int64_t n = P->n; const int m = restart < max_it ? restart : max_it;
@@ -311,12 +332,12 @@ static int gmres(const Problem* P, const Ras* R, const double* b, double* x, dou
             const double* vj = V + (size_t)j * n;
             if (R) { ras_apply(R, vj, z); spmv(P, z, w); } else spmv(P, vj, w);
             const double n0 = dot(w, w, n);
-            for (int c = 0; c <= j; ++c) h[c] = dot(V + (size_t)c * n, w, n);
+            multidot(V, w, n, j + 1, h);
             #pragma omp parallel for schedule(static)
             for (int64_t i = 0; i < n; ++i) { double v = w[i]; for (int c = 0; c <= j; ++c) v -= h[c] * V[(size_t)c * n + i]; w[i] = v; }
             double n1 = dot(w, w, n);
             if (n1 < 0.5 * n0) {                                             /* DGKS */
-                for (int c = 0; c <= j; ++c) h2[c] = dot(V + (size_t)c * n, w, n);
+                multidot(V, w, n, j + 1, h2);
                 #pragma omp parallel for schedule(static)
                 for (int64_t i = 0; i < n; ++i) { double v = w[i]; for (int c = 0; c <= j; ++c) v -= h2[c] * V[(size_t)c * n + i]; w[i] = v; }
                 for (int c = 0; c <= j; ++c) h[c] += h2[c];
@@ -356,6 +377,9 @@ int oracle_laplace3d(int M, int target, double rtol, int restart, int max_it, in
                      double* relres, int* threads, int64_t* nnz_out, int64_t* nsub_out, int* max_n_out, double* x,
                      int64_t* rowptr, int32_t* col, double* val, double* rhs) {
     Problem P; Ras R; memset(&R, 0, sizeof(R));
+#ifdef _OPENMP
+    if (*threads > 0) omp_set_num_threads(*threads);
+#endif
     build_problem(M, &P, times);
     double t0 = now();
     if (use_prec) ras_setup(&P, target, &R);

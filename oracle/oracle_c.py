@@ -51,13 +51,13 @@ def _load():
     return _lib
 
 
-def run_laplace3d(M, target=27, rtol=1e-8, restart=100, max_it=2000, use_prec=True, want_system=False):
+def run_laplace3d(M, target=27, rtol=1e-8, restart=100, max_it=2000, use_prec=True, want_system=False, threads=0):
     """Whole laplace driver on the CPU.  Returns timings (s), iteration count, threads, and -- with
     want_system -- the Dirichlet-modified CSR matrix, rhs and solution."""
     L = _load()
     n = (M + 1) ** 3
     times = np.zeros(8)
-    its, thr, maxn = C.c_int(), C.c_int(), C.c_int()
+    its, thr, maxn = C.c_int(), C.c_int(int(threads)), C.c_int()
     rel = C.c_double()
     nnz, nsub = C.c_int64(), C.c_int64()
     dp = C.POINTER(C.c_double)
