@@ -64,7 +64,11 @@ SIGNATURES = {
     "fedd_halo_requests_get": [C.c_void_p, _i64p],
     "fedd_halo_requests_set": [C.c_void_p, _i64p, _i64p],
     "fedd_halo_exchange_setup": [C.c_void_p],
+    "fedd_comm_set_host_callbacks": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
 }
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _i32p, _i64p, _f64p, _i64p, _f64p, C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _f64p, C.c_int)
 
 _lib = None
 
@@ -312,6 +316,69 @@ class Context:
         cnt = np.ascontiguousarray(count_from_rank, dtype=np.int64)
         g = np.ascontiguousarray(gids, dtype=np.int64)
         _chk(self._L.fedd_halo_requests_set(self._h, _p(cnt, _i64p), _p(g, _i64p)))
+
+    def comm_set_torch_dist(self, dist):
+        """Host-staged transport over an initialised torch.distributed group (gloo): functional
+        tests of the N > 1 path where RCCL cannot run.  Also finalises the halo plan over it."""
+        import torch
+
+        def exchange(user, n_peers, peers, send_ptr, send_buf, recv_ptr, recv_buf, dofs):
+            try:
+                reqs, keep = [], []
+                for k in range(n_peers):
+                    s0, s1 = send_ptr[k] * dofs, send_ptr[k + 1] * dofs
+                    r0, r1 = recv_ptr[k] * dofs, recv_ptr[k + 1] * dofs
+                    if s1 > s0:
+                        t = torch.from_numpy(np.ctypeslib.as_array(send_buf, shape=(send_ptr[n_peers] * dofs,))[s0:s1].copy())
+                        keep.append(t)
+                        reqs.append(dist.isend(t, int(peers[k])))
+                    if r1 > r0:
+                        t = torch.zeros(r1 - r0, dtype=torch.float64)
+                        keep.append((t, r0, r1))
+                        reqs.append(dist.irecv(t, int(peers[k])))
+                for r in reqs:
+                    r.wait()
+                out = np.ctypeslib.as_array(recv_buf, shape=(max(1, recv_ptr[n_peers] * dofs),))
+                for item in keep:
+                    if isinstance(item, tuple):
+                        out[item[1]:item[2]] = item[0].numpy()
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("exchange callback failed:", e, flush=True)
+                return 1
+
+        def allreduce(user, buf, n):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(n,))
+                t = torch.from_numpy(a.copy())
+                dist.all_reduce(t)
+                a[:] = t.numpy()
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("allreduce callback failed:", e, flush=True)
+                return 1
+
+        self._cb = (EXCHANGE_FN(exchange), ALLREDUCE_FN(allreduce))     # keep alive
+        _chk(self._L.fedd_comm_set_host_callbacks(self._h, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None))
+        # halo plan over the same group
+        cnt, gids = self.halo_requests()
+        world = self.nranks
+        cnt_all = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(cnt_all, torch.from_numpy(cnt.copy()))
+        from_me = np.array([int(cnt_all[p][self.rank]) for p in range(world)], dtype=np.int64)
+        recv = [torch.zeros(int(n), dtype=torch.int64) for n in from_me]
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        reqs = []
+        for p in range(world):
+            if p == self.rank:
+                continue
+            if cnt[p] > 0:
+                reqs.append(dist.isend(torch.from_numpy(gids[off[p]:off[p + 1]].copy()), p))
+            if from_me[p] > 0:
+                reqs.append(dist.irecv(recv[p], p))
+        for r in reqs:
+            r.wait()
+        self.halo_requests_set(from_me, np.concatenate([t.numpy() for t in recv]) if from_me.sum() else np.zeros(0, np.int64))
 
     def halo_exchange_setup(self):
         _chk(self._L.fedd_halo_exchange_setup(self._h))

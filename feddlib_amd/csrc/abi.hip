@@ -86,12 +86,7 @@ extern "C" int fedd_ctx_create(fedd_ctx** out, int device, const void* nccl_uniq
             delete c;
             return 1;
         }
-        if (nranks > 1) {
-            if (!nccl_unique_id) {
-                set_error("fedd_ctx_create: nranks > 1 needs the shared ncclUniqueId");
-                delete c;
-                return 1;
-            }
+        if (nranks > 1 && nccl_unique_id) {  // without an id: host-callback transport (tests only)
             ncclUniqueId id;
             memcpy(&id, nccl_unique_id, 128);
             ncclComm_t comm;
@@ -413,6 +408,14 @@ extern "C" int fedd_gmres(fedd_ctx* c, const double* b_owned, double* x_owned, d
         FEDD_HIP(hipMemcpyAsync(x_owned, c->d_x.p, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         FEDD_HIP(hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+extern "C" int fedd_comm_set_host_callbacks(fedd_ctx* c, fedd_exchange_fn exchange, fedd_allreduce_fn allreduce, void* user) {
+    FEDD_CHECK(c, "fedd_comm_set_host_callbacks: null context");
+    c->cb_exchange = exchange;
+    c->cb_allreduce = allreduce;
+    c->cb_user = user;
     return 0;
 }
 

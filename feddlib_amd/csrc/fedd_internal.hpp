@@ -92,6 +92,11 @@ struct fedd_ctx {
     int rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     ncclComm* comm = nullptr;
+    // host-staged transport (functional testing of the N > 1 path without RCCL, e.g. over gloo)
+    fedd_exchange_fn cb_exchange = nullptr;
+    fedd_allreduce_fn cb_allreduce = nullptr;
+    void* cb_user = nullptr;
+    std::vector<double> h_send, h_recv;
 
     // ---- mesh (column-local numbering: owned nodes [0,n_own) in unique-map order, then ghosts
     //      sorted by global id) ----

@@ -37,11 +37,28 @@ __global__ void k_unpack(double* __restrict__ x, const int32_t* __restrict__ lid
 int halo_import(fedd_ctx* c, double* d_xcol, int dofs) {
     if (c->nranks == 1 || c->n_node == c->n_own) return 0;
     HaloPlan& h = c->halo;
-    FEDD_CHECK(h.ready && c->comm, "halo import: no exchange plan; call fedd_halo_exchange_setup after fedd_mesh_set");
+    FEDD_CHECK(h.ready && (c->comm || c->cb_exchange),
+               "halo import: no exchange plan / transport; call fedd_halo_exchange_setup after fedd_mesh_set");
     const int64_t ns = (int64_t)h.send_lid.size(), nr = (int64_t)h.recv_lid.size();
     if (ns > 0)
         hipLaunchKernelGGL(k_pack, dim3((unsigned)((ns * dofs + 255) / 256)), dim3(256), 0, c->stream, (const double*)d_xcol,
                            (const int32_t*)h.d_send_lid.p, ns, dofs, h.d_send_buf.p);
+    if (c->cb_exchange) {  // host-staged transport (functional tests): same kernels, caller moves the bytes
+        c->h_send.resize((size_t)ns * dofs + 1);
+        c->h_recv.resize((size_t)nr * dofs + 1);
+        if (ns > 0) FEDD_HIP(hipMemcpyAsync(c->h_send.data(), h.d_send_buf.p, (size_t)ns * dofs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        const int rc = c->cb_exchange(c->cb_user, (int)h.peers.size(), h.peers.data(), h.send_ptr.data(), c->h_send.data(),
+                                      h.recv_ptr.data(), c->h_recv.data(), dofs);
+        FEDD_CHECK(rc == 0, "halo import: the host exchange callback failed (%d)", rc);
+        if (nr > 0) {
+            FEDD_HIP(hipMemcpyAsync(h.d_recv_buf.p, c->h_recv.data(), (size_t)nr * dofs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_unpack, dim3((unsigned)((nr * dofs + 255) / 256)), dim3(256), 0, c->stream, d_xcol,
+                               (const int32_t*)h.d_recv_lid.p, nr, dofs, (const double*)h.d_recv_buf.p);
+            FEDD_HIP(hipStreamSynchronize(c->stream));
+        }
+        return 0;
+    }
     ncclComm_t comm = (ncclComm_t)c->comm;
     ncclGroupStart();
     for (size_t k = 0; k < h.peers.size(); ++k) {

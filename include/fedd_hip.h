@@ -176,6 +176,16 @@ int fedd_timing_get(fedd_ctx* ctx, int timer, double* total_ms, int64_t* launche
  * or, transport-agnostic (used by the gloo CPU tests): fedd_halo_requests_sizes/_get on every
  * rank, all-to-all of the lists by the caller, fedd_halo_requests_set.
  * fedd_mesh_structured_owner: owner of structured-grid nodes under the lowest-rank rule. */
+/* Host-staged transport for functional tests of the N > 1 path where RCCL cannot run (several ranks
+ * on one GPU, CPU-side harnesses): the same plan, pack / unpack kernels and solver flow, with the
+ * two communication steps handed to the caller.  exchange: send_buf / recv_buf are host buffers laid
+ * out by send_ptr / recv_ptr (in nodes; multiply by dofs).  With callbacks set, fedd_ctx_create may
+ * be given nranks > 1 and a NULL ncclUniqueId.  Production runs use RCCL (no callbacks). */
+typedef int (*fedd_exchange_fn)(void* user, int n_peers, const int32_t* peers, const int64_t* send_ptr,
+                                const double* send_buf, const int64_t* recv_ptr, double* recv_buf, int dofs);
+typedef int (*fedd_allreduce_fn)(void* user, double* buf, int n);
+int fedd_comm_set_host_callbacks(fedd_ctx* ctx, fedd_exchange_fn exchange, fedd_allreduce_fn allreduce, void* user);
+
 int fedd_mesh_structured_owner(int dim, const int* decomp, const int* cells, int64_t n,
                                const int64_t* gid, int32_t* owner_rank);
 int fedd_halo_set_owners(fedd_ctx* ctx, int64_t n_rep, const int64_t* gid_rep, const int32_t* owner_rep);

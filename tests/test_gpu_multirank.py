@@ -1,0 +1,94 @@
+"""The N > 1 path end to end on ONE GPU: 2 and 4 ranks (each its own process and fedd_ctx on
+device 0), ghost-element meshes, halo plan, distributed assembly / SpMV / Schwarz / GMRES.  RCCL
+refuses several ranks on one device, so the two communication steps go through the library's
+host-staged transport hook over gloo; plan, pack/unpack kernels and solver flow are the production
+ones.  The gathered solution must match a direct solve of the single-domain oracle system."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import fedd_oracle as fo
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dec, M, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from feddlib_amd import capi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = capi.structured_mesh(3, dec, [M] * 3, rank, ghosts=True)
+        c = capi.Context(device=0, rank=rank, nranks=world, nccl_id=None)
+        c.mesh_set_dict(m)
+        c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, [M] * 3, m["gid_rep"]))
+        c.comm_set_torch_dist(dist)
+        c.pattern_build(1, capi.BLOCK_SCALAR)
+        c.assemble(capi.FORM_LAPLACE)
+        c.assemble_rhs([1.0])
+        c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+        # distributed SpMV against the global vector
+        rng = np.random.default_rng(11)
+        xg = rng.standard_normal(m["n_global"])
+        y = c.spmv(xg[m["gid_uni"]])
+        c.schwarz_set_target(27, 1.0)
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+        x, its, rel = c.gmres(None, rtol=1e-13, max_it=600, restart=100, use_prec=True)
+        rowptr, col, val, gid = c.csr_get()
+        q.put((rank, m["gid_uni"], x, y, its, rel, rowptr, col, val, gid, c.rhs_get()))
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dec,M", [((1, 1, 2), 6), ((1, 2, 2), 5)])
+def test_multirank_solve_on_one_gpu(fedd_lib, dec, M):
+    import scipy.sparse as sp
+    import torch.multiprocessing as mp
+    world = int(np.prod(dec))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dec, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = fedd_lib.structured_mesh(3, (1, 1, 1), [d * M for d in dec], 0)
+    om = fo.Mesh(dim=3, fe="P1", conn=ref["conn"], xyz=ref["xyz"], gid_rep=ref["gid_rep"], flag_rep=ref["flag_rep"],
+                 gid_uni=ref["gid_uni"], flag_uni=ref["flag_uni"], xyz_uni=None, n_global=ref["n_global"])
+    A_bc, rhs_bc, _, _, _ = fo.laplace_problem(om)
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    xg = np.random.default_rng(11).standard_normal(ref["n_global"])
+    yref = A_bc @ xg
+    xx = np.zeros_like(xd)
+    its_all = set()
+    for rank, gu, x, y, its, rel, rowptr, col, val, gid, rhs in res:
+        xx[gu] = x
+        its_all.add(its)
+        assert rel <= 1e-13
+        np.testing.assert_allclose(y, yref[gu], rtol=0, atol=1e-10 * np.abs(yref).max())
+        # owned rows of the distributed matrix == the same rows of the global oracle matrix
+        nr = rowptr.shape[0] - 1
+        rows = np.repeat(np.arange(nr), np.diff(rowptr))
+        Aloc = sp.csr_matrix((val, (gu[rows], gid[col])), shape=A_bc.shape)
+        assert abs(Aloc[gu] - A_bc[gu]).max() <= 1e-10 * abs(A_bc).max()
+        np.testing.assert_allclose(rhs, rhs_bc[gu], rtol=0, atol=1e-14)
+    assert len(its_all) == 1                      # every rank took the same convergence decision
+    np.testing.assert_allclose(xx, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
