@@ -423,6 +423,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     FEDD_CHECK(c && key, "fedd_set_option: null");
     const std::string k(key);
     if (k == "spmv_kind") c->spmv_kind = (int)value;
+    else if (k == "asm_kind") c->asm_kind = (int)value;
     else FEDD_CHECK(false, "fedd_set_option: unknown key '%s'", key);
     return 0;
 }

@@ -57,24 +57,28 @@ __device__ __forceinline__ double affine(const double (&X)[DIM + 1][DIM], double
 #pragma unroll
         for (int i = 0; i < DIM; ++i) B[i][j] = X[j + 1][i] - X[0][i];
     if constexpr (DIM == 2) {
+        // one f64 division (the reference divides each adjugate entry by det; multiplying by the
+        // correctly rounded reciprocal differs by <= 1 ulp per entry, far inside the 1e-10 bar)
         const double det = B[0][0] * B[1][1] - B[1][0] * B[0][1];
-        Binv[0][0] = B[1][1] / det;
-        Binv[0][1] = (-B[0][1]) / det;
-        Binv[1][0] = (-B[1][0]) / det;
-        Binv[1][1] = B[0][0] / det;
+        const double rdet = 1.0 / det;
+        Binv[0][0] = B[1][1] * rdet;
+        Binv[0][1] = (-B[0][1]) * rdet;
+        Binv[1][0] = (-B[1][0]) * rdet;
+        Binv[1][1] = B[0][0] * rdet;
         return det;
     } else {
         const double det = B[0][0] * B[1][1] * B[2][2] + B[0][1] * B[1][2] * B[2][0] + B[0][2] * B[1][0] * B[2][1] -
                            B[2][0] * B[1][1] * B[0][2] - B[2][1] * B[1][2] * B[0][0] - B[2][2] * B[1][0] * B[0][1];
-        Binv[0][0] = (B[1][1] * B[2][2] - B[1][2] * B[2][1]) / det;
-        Binv[0][1] = (B[0][2] * B[2][1] - B[0][1] * B[2][2]) / det;
-        Binv[0][2] = (B[0][1] * B[1][2] - B[0][2] * B[1][1]) / det;
-        Binv[1][0] = (B[1][2] * B[2][0] - B[1][0] * B[2][2]) / det;
-        Binv[1][1] = (B[0][0] * B[2][2] - B[0][2] * B[2][0]) / det;
-        Binv[1][2] = (B[0][2] * B[1][0] - B[0][0] * B[1][2]) / det;
-        Binv[2][0] = (B[1][0] * B[2][1] - B[1][1] * B[2][0]) / det;
-        Binv[2][1] = (B[0][1] * B[2][0] - B[0][0] * B[2][1]) / det;
-        Binv[2][2] = (B[0][0] * B[1][1] - B[0][1] * B[1][0]) / det;
+        const double rdet = 1.0 / det;
+        Binv[0][0] = (B[1][1] * B[2][2] - B[1][2] * B[2][1]) * rdet;
+        Binv[0][1] = (B[0][2] * B[2][1] - B[0][1] * B[2][2]) * rdet;
+        Binv[0][2] = (B[0][1] * B[1][2] - B[0][2] * B[1][1]) * rdet;
+        Binv[1][0] = (B[1][2] * B[2][0] - B[1][0] * B[2][2]) * rdet;
+        Binv[1][1] = (B[0][0] * B[2][2] - B[0][2] * B[2][0]) * rdet;
+        Binv[1][2] = (B[0][2] * B[1][0] - B[0][0] * B[1][2]) * rdet;
+        Binv[2][0] = (B[1][0] * B[2][1] - B[1][1] * B[2][0]) * rdet;
+        Binv[2][1] = (B[0][1] * B[2][0] - B[0][0] * B[2][1]) * rdet;
+        Binv[2][2] = (B[0][0] * B[1][1] - B[0][1] * B[1][0]) * rdet;
         return det;
     }
 }
@@ -209,6 +213,188 @@ __global__ void k_assemble(AsmArgs a) {
     for (int s = 0; s < rn; ++s) a.val[rs + s] = acc[s * BS + tid];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pair-parallel variant (default).  A workgroup owns R consecutive dof rows.
+//   phase 1: one lane per (row, incident element) pair evaluates that row of the element matrix
+//            and parks (column id, value) in LDS -- all global-memory latency (adjacency, element
+//            nodes, coordinates) is overlapped across ~24x more lanes than rows;
+//   phase 2: `tpr` lanes per row, lane s owns CSR slot s: it sweeps the row's parked
+//            contributions in their fixed order and adds those whose column id is its own
+//            (LDS broadcast reads, no search, no atomics), then the workgroup's CSR range
+//            is written as one contiguous coalesced stream.
+// Summation order is fixed by the sorted adjacency list => bitwise reproducible.
+// ---------------------------------------------------------------------------------------------
+template <int DIM, int NEN, int FORM>
+struct PairCfg {
+    static constexpr int CPP = FORM == F_LINELAS ? NEN * DIM : NEN;  // contributions per pair
+};
+
+template <int DIM, int NEN, int FORM>
+__device__ __forceinline__ void eval_pair(const AsmArgs& a, const double* __restrict__ s_w,
+                                          const double* __restrict__ s_phi, const double* __restrict__ s_dphi, int nq,
+                                          int32_t e, int li, int comp, int dofs,
+                                          int32_t (&cols)[PairCfg<DIM, NEN, FORM>::CPP],
+                                          double (&vals)[PairCfg<DIM, NEN, FORM>::CPP]) {
+    int32_t nd[NEN];
+#pragma unroll
+    for (int j = 0; j < NEN; ++j) nd[j] = a.conn[(int64_t)e * NEN + j];
+    double X[DIM + 1][DIM];
+#pragma unroll
+    for (int v = 0; v <= DIM; ++v)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) X[v][d] = a.xyz[(int64_t)nd[v] * DIM + d];
+    if constexpr (FORM == F_MASS) {
+        const double absdet = fabs(affine_det<DIM>(X));
+#pragma unroll
+        for (int j = 0; j < NEN; ++j) {
+            double v = 0.0;
+            for (int q = 0; q < nq; ++q) v += s_w[q] * s_phi[q * NEN + li] * s_phi[q * NEN + j];
+            cols[j] = nd[j] * dofs + comp;
+            vals[j] = v * absdet;
+        }
+    } else {
+        double Binv[DIM][DIM];
+        const double absdet = fabs(affine<DIM>(X, Binv));
+        if constexpr (FORM == F_LAPLACE) {
+#pragma unroll
+            for (int j = 0; j < NEN; ++j) {
+                double v = 0.0;
+                for (int q = 0; q < nq; ++q) {
+                    double gi[DIM], gj[DIM];
+                    grad_t<DIM, NEN>(s_dphi, q, li, Binv, gi);
+                    grad_t<DIM, NEN>(s_dphi, q, j, Binv, gj);
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) v += s_w[q] * gi[d] * gj[d];
+                }
+                cols[j] = nd[j] * dofs + comp;
+                vals[j] = v * absdet;
+            }
+        } else {
+            const double lam = a.p0, mu = a.p1;
+#pragma unroll
+            for (int j = 0; j < NEN; ++j) {
+                double vb[DIM];
+#pragma unroll
+                for (int b = 0; b < DIM; ++b) vb[b] = 0.0;
+                for (int q = 0; q < nq; ++q) {
+                    double gi[DIM], gj[DIM];
+                    grad_t<DIM, NEN>(s_dphi, q, li, Binv, gi);
+                    grad_t<DIM, NEN>(s_dphi, q, j, Binv, gj);
+                    double dot = 0.0, gia = 0.0, gja = 0.0;
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) {
+                        dot += gi[d] * gj[d];
+                        gia = d == comp ? gi[d] : gia;
+                        gja = d == comp ? gj[d] : gja;
+                    }
+#pragma unroll
+                    for (int b = 0; b < DIM; ++b)
+                        vb[b] += s_w[q] * (mu * ((b == comp ? dot : 0.0) + gi[b] * gja) + lam * gia * gj[b]);
+                }
+#pragma unroll
+                for (int b = 0; b < DIM; ++b) {
+                    cols[j * DIM + b] = nd[j] * dofs + b;
+                    vals[j * DIM + b] = absdet * vb[b];
+                }
+            }
+        }
+    }
+}
+
+template <int DIM, int NEN, int FORM>
+__global__ __launch_bounds__(256) void k_assemble_pairs(AsmArgs a, int R, int tpr_log2, int cap_contrib) {
+    constexpr int CPP = PairCfg<DIM, NEN, FORM>::CPP;
+    extern __shared__ double sm[];
+    const int nq = a.nq;
+    const int ntab = nq * (1 + NEN + NEN * DIM);
+    double* s_w = sm;
+    double* s_phi = s_w + nq;
+    double* s_dphi = s_phi + nq * NEN;
+    double* cval = sm + ntab;
+    int32_t* ccol = reinterpret_cast<int32_t*>(cval + cap_contrib);
+    int32_t* off = ccol + cap_contrib;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ntab; i += 256) sm[i] = a.tab[i];
+    const int dofs = a.dofs;
+    const int32_t r0 = blockIdx.x * R;
+    const int nrows = min(R, a.n_rows - r0);
+    // exclusive prefix of the rows' pair counts: first wave, one lane per row (R <= 64), DPP scan
+    if (tid < 64) {
+        int deg = 0;
+        if (tid < nrows) {
+            const int32_t node = (r0 + tid) / dofs;
+            deg = a.n2e_ptr[node + 1] - a.n2e_ptr[node];
+        }
+        int incl = deg;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (tid >= d) incl += t;
+        }
+        if (tid <= nrows) off[tid] = incl - deg;
+    }
+    __syncthreads();
+    const int npairs = off[nrows];
+    // the contributions of local row r start at (off[r]*CPP + r*PAD): the odd-ish shift keeps the
+    // rows that one wave sweeps together in phase 2 on different LDS banks
+    constexpr int PAD = 2;
+    for (int i = tid; i < npairs; i += 256) {
+        int lo = 0, hi = nrows - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (off[mid] <= i) lo = mid;
+            else hi = mid - 1;
+        }
+        const int32_t row = r0 + lo;
+        const int32_t node = row / dofs;
+        const int comp = row - node * dofs;
+        const int32_t idx = a.n2e[a.n2e_ptr[node] + (i - off[lo])];
+        const int32_t e = idx / NEN;
+        const int li = idx - e * NEN;
+        int32_t cols[CPP];
+        double vals[CPP];
+        eval_pair<DIM, NEN, FORM>(a, s_w, s_phi, s_dphi, nq, e, li, comp, dofs, cols, vals);
+        const int base = i * CPP + lo * PAD;
+#pragma unroll
+        for (int c = 0; c < CPP; ++c) {
+            ccol[base + c] = cols[c];
+            cval[base + c] = vals[c];
+        }
+    }
+    __syncthreads();
+    const int tpr = 1 << tpr_log2;
+    for (int item = tid; item < (nrows << tpr_log2); item += 256) {
+        const int rl = item >> tpr_log2, s0 = item & (tpr - 1);
+        const int32_t rs = a.rowptr[r0 + rl];
+        const int rn = a.rowptr[r0 + rl + 1] - rs;
+        const int cb = off[rl] * CPP + rl * PAD, ce = off[rl + 1] * CPP + rl * PAD;
+        for (int s = s0; s < rn; s += tpr) {
+            const int32_t mycol = a.colind[rs + s];
+            double acc = 0.0;
+            int c = cb;
+            // 8 contributions per trip, all 16 LDS reads issued before the first use (a
+            // data-dependent read of cval would serialise two LDS latencies per contribution)
+            for (; c + 8 <= ce; c += 8) {
+                int32_t cc[8];
+                double vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    cc[u] = ccol[c + u];
+                    vv[u] = cval[c + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += cc[u] == mycol ? vv[u] : 0.0;
+            }
+            for (; c < ce; ++c) {
+                const int32_t cc = ccol[c];
+                const double vv = cval[c];
+                acc += cc == mycol ? vv : 0.0;
+            }
+            a.val[rs + s] = acc;
+        }
+    }
+}
+
 struct RhsArgs {
     const int32_t* conn;
     const int32_t* n2e_ptr;
@@ -285,8 +471,36 @@ __global__ void k_dirichlet_nodes(const int32_t* __restrict__ nodes, const int32
     isdir[row] = 1;
 }
 
+template <int DIM, int NEN, int FORM>
+int launch_pairs(fedd_ctx* c, const AsmArgs& a, int ntab) {
+    constexpr int CPP = PairCfg<DIM, NEN, FORM>::CPP;
+    const int maxdeg = std::max(1, c->max_deg);
+    const size_t per_row = (size_t)maxdeg * CPP * 12;  // f64 value + i32 column per contribution
+    int R = (int)std::min<size_t>(63, (40 * 1024) / per_row);  // <= 63: one wave scans the row offsets
+    if (R < 1) R = 1;
+    const int cap = R * maxdeg * CPP + R * 2;                   // + the per-row bank-shift padding
+    const size_t lds = (size_t)ntab * 8 + (size_t)cap * 12 + (size_t)(R + 1) * 4 + 16;
+    FEDD_CHECK(lds <= 160 * 1024, "assembly: a node with %d incident elements does not fit the LDS contribution buffer", maxdeg);
+    int tl = 0;
+    while ((1 << tl) < std::min(64, std::max(1, c->max_row_nnz))) ++tl;
+    auto kern = k_assemble_pairs<DIM, NEN, FORM>;
+    if (lds > 64 * 1024)
+        FEDD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid((unsigned)((c->n_rows + R - 1) / R)), block(256);
+    ScopedTimer t(c, FEDD_T_ASSEMBLE);
+    hipLaunchKernelGGL(kern, grid, block, lds, c->stream, a, R, tl, cap);
+    t.stop();
+    FEDD_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int DIM, int NEN>
 int launch_assemble(fedd_ctx* c, int kform, const AsmArgs& a, int ntab) {
+    if (c->asm_kind == 0) {
+        if (kform == F_LAPLACE) return launch_pairs<DIM, NEN, F_LAPLACE>(c, a, ntab);
+        if (kform == F_MASS) return launch_pairs<DIM, NEN, F_MASS>(c, a, ntab);
+        return launch_pairs<DIM, NEN, F_LINELAS>(c, a, ntab);
+    }
     const int rowcap = std::max(1, c->max_row_nnz);
     int bs = 256;
     auto need = [&](int b) { return ((size_t)ntab + (size_t)rowcap * b) * sizeof(double); };

@@ -124,6 +124,7 @@ struct fedd_ctx {
     fedd::DevBuf<int32_t> d_isdir;              // [n_rows] 1 = Dirichlet row
     bool have_pattern = false;
     int spmv_kind = 0;                          // 0 = CSR-stream kernel, 1 = row-per-lane-group kernel
+    int asm_kind = 0;                           // 0 = pair-parallel assembly, 1 = lane-per-row gather
     fedd::DevBuf<int32_t> d_spmv_rows;          // CSR-stream: first row of every nnz window
     bool spmv_rows_ready = false;
 

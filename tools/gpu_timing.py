@@ -58,6 +58,18 @@ def main():
         out.append(rec)
         print(json.dumps(rec), flush=True)
     # kernel micro-timings on resident data
+    for kind in (1, 0):
+        c.set_option("asm_kind", kind)
+        c.pattern_build(1, capi.BLOCK_SCALAR)
+        c.assemble(capi.FORM_LAPLACE); c.sync()
+        c.timing_reset()
+        for _ in range(5):
+            c.assemble(capi.FORM_LAPLACE)
+        c.sync()
+        tk = c.timing_get()["assemble"]
+        ab = 4.0 * m["conn"].size + 24.0 * m["xyz"].shape[0] + 12.0 * nnz + 4.0 * (m["gid_uni"].shape[0] + 1)
+        print(json.dumps({"asm_kind": kind, "ms": tk[0] / tk[1], "GBs": ab / (tk[0] / tk[1]) / 1e6}), flush=True)
+    c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
     nr = m["gid_uni"].shape[0]
     for kind in (1, 0):
         c.set_option("spmv_kind", kind)
