@@ -141,36 +141,49 @@ struct Off {
 };
 
 // after pass 1: decide DGKS re-orthogonalisation.  nrm[0] = w.w before, nrm[1] = after pass 1.
-__global__ void k_dgks_gate(const double* __restrict__ nrm, int32_t* __restrict__ gate) {
-    gate[0] = nrm[1] < 0.5 * nrm[0] ? 1 : 0;
+__global__ void k_dgks_gate(const double* __restrict__ before, const double* __restrict__ after,
+                            int32_t* __restrict__ gate) {
+    gate[0] = after[0] < 0.5 * before[0] ? 1 : 0;
 }
 
 // Finish column j of the Hessenberg matrix: h = h1 (+ h2), h_{j+1,j} = ||w||; apply the previous
 // rotations, create the new one, update g.  misc[0] = |g_{j+1}|, misc[1] = 1/h_{j+1,j}.
-__global__ void k_givens(double* __restrict__ S, Off o, int j, int m, const int32_t* __restrict__ gate) {
-    double* H = S + o.H + (int64_t)j * (m + 1);
-    const double* h1 = S + o.h1;
-    const double* h2 = S + o.h2;
+// One workgroup: all lanes stage the column and the stored rotations in LDS (independent loads),
+// lane 0 then runs the inherently sequential rotation chain out of LDS instead of a chain of
+// dependent global loads.
+__global__ __launch_bounds__(256) void k_givens(double* __restrict__ S, Off o, int j, int m,
+                                                const int32_t* __restrict__ gate) {
+    extern __shared__ double gs[];  // hcol[m+2] | cs[m] | sn[m]
+    double* hc = gs;
+    double* lcs = hc + (m + 2);
+    double* lsn = lcs + m;
     const bool two = gate[0] != 0;
-    for (int i = 0; i <= j; ++i) H[i] = h1[i] + (two ? h2[i] : 0.0);
-    const double hn = sqrt(two ? S[o.nrm + 2] : S[o.nrm + 1]);
-    H[j + 1] = hn;
-    double* cs = S + o.cs;
-    double* sn = S + o.sn;
-    double* g = S + o.g;
-    for (int i = 0; i < j; ++i) {
-        const double t = cs[i] * H[i] + sn[i] * H[i + 1];
-        H[i + 1] = -sn[i] * H[i] + cs[i] * H[i + 1];
-        H[i] = t;
+    for (int i = threadIdx.x; i <= j; i += blockDim.x) hc[i] = S[o.h1 + i] + (two ? S[o.h2 + i] : 0.0);
+    for (int i = threadIdx.x; i < j; i += blockDim.x) {
+        lcs[i] = S[o.cs + i];
+        lsn[i] = S[o.sn + i];
     }
-    const double d = hypot(H[j], H[j + 1]);
-    cs[j] = d > 0 ? H[j] / d : 1.0;
-    sn[j] = d > 0 ? H[j + 1] / d : 0.0;
-    H[j] = d;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double hn = sqrt(two ? S[o.nrm + 2] : S[o.nrm + 1]);
+    hc[j + 1] = hn;
+    for (int i = 0; i < j; ++i) {
+        const double t = lcs[i] * hc[i] + lsn[i] * hc[i + 1];
+        hc[i + 1] = -lsn[i] * hc[i] + lcs[i] * hc[i + 1];
+        hc[i] = t;
+    }
+    const double d = hypot(hc[j], hc[j + 1]);
+    const double cj = d > 0 ? hc[j] / d : 1.0, sj = d > 0 ? hc[j + 1] / d : 0.0;
+    S[o.cs + j] = cj;
+    S[o.sn + j] = sj;
+    hc[j] = d;
+    double* H = S + o.H + (int64_t)j * (m + 1);
+    for (int i = 0; i <= j; ++i) H[i] = hc[i];
     H[j + 1] = 0.0;
-    g[j + 1] = -sn[j] * g[j];
-    g[j] = cs[j] * g[j];
-    S[o.misc + 0] = fabs(g[j + 1]);
+    const double gj = S[o.g + j];
+    S[o.g + j + 1] = -sj * gj;
+    S[o.g + j] = cj * gj;
+    S[o.misc + 0] = fabs(sj * gj);
     S[o.misc + 1] = hn > 0 ? 1.0 / hn : 0.0;
     S[o.misc + 2] = hn;
 }
@@ -191,14 +204,19 @@ __global__ void k_cycle_init(double* __restrict__ S, Off o, int m, const double*
 }
 
 // y = R^-1 g for the k x k upper triangle (column-major H with leading dimension m+1)
-__global__ void k_backsolve(double* __restrict__ S, Off o, int k, int m) {
-    double* y = S + o.y;
-    const double* g = S + o.g;
+// Column-oriented back substitution by one workgroup: y_i = t_i / R_ii, then every lane r < i
+// updates t_r -= R_ri y_i (column i of H is contiguous).  Fixed order => reproducible.
+__global__ __launch_bounds__(256) void k_backsolve(double* __restrict__ S, Off o, int k, int m) {
+    extern __shared__ double t[];  // [k]
     const double* H = S + o.H;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) t[i] = S[o.g + i];
+    __syncthreads();
     for (int i = k - 1; i >= 0; --i) {
-        double s = g[i];
-        for (int c = i + 1; c < k; ++c) s -= H[(int64_t)c * (m + 1) + i] * y[c];
-        y[i] = s / H[(int64_t)i * (m + 1) + i];
+        const double yi = t[i] / H[(int64_t)i * (m + 1) + i];
+        __syncthreads();
+        if (threadIdx.x == 0) S[o.y + i] = yi;
+        for (int r = threadIdx.x; r < i; r += blockDim.x) t[r] -= H[(int64_t)i * (m + 1) + r] * yi;
+        __syncthreads();
     }
 }
 
@@ -312,14 +330,14 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
                 hipLaunchKernelGGL(k_reduce_cols, dim3(j + 2), blk, 0, st, (const double*)c->d_part.p, S + o.h1, nblk,
                                    (const int32_t*)nullptr);
                 FEDD_TRY(allreduce_sum(c, S + o.h1, j + 2));
-                // h1[j+1] holds w.w -> move to nrm[0] is implicit: k_dgks_gate reads nrm[], so copy
-                FEDD_HIP(hipMemcpyAsync(S + o.nrm, S + o.h1 + j + 1, sizeof(double), hipMemcpyDeviceToDevice, st));
+                // h1[j+1] now holds w.w (read in place by k_dgks_gate)
                 hipLaunchKernelGGL(k_multiaxpy, dim3(nblk2), blk, 0, st, (const double*)V, ldv, n, j + 1,
                                    (const double*)(S + o.h1), w, c->d_part.p, (const int32_t*)nullptr);
                 hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, S + o.nrm + 1, nblk2,
                                    (const int32_t*)nullptr);
                 FEDD_TRY(allreduce_sum(c, S + o.nrm + 1, 1));
-                hipLaunchKernelGGL(k_dgks_gate, dim3(1), dim3(1), 0, st, (const double*)(S + o.nrm), gate);
+                hipLaunchKernelGGL(k_dgks_gate, dim3(1), dim3(1), 0, st, (const double*)(S + o.h1 + j + 1),
+                                   (const double*)(S + o.nrm + 1), gate);
                 // pass 2 (gated on the device; on several ranks the gate is identical everywhere
                 // because it is computed from all-reduced numbers, so the collectives stay matched)
                 hipLaunchKernelGGL(k_multidot, dim3(nblk, (j + 2 + MD_CG - 1) / MD_CG), blk, 0, st, (const double*)V, ldv, n,
@@ -334,7 +352,8 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
                 FEDD_TRY(allreduce_sum(c, S + o.nrm + 2, 1));
                 t.stop();
             }
-            hipLaunchKernelGGL(k_givens, dim3(1), dim3(1), 0, st, S, o, j, m, (const int32_t*)gate);
+            hipLaunchKernelGGL(k_givens, dim3(1), dim3(256), (size_t)(3 * m + 2) * sizeof(double), st, S, o, j, m,
+                               (const int32_t*)gate);
             hipLaunchKernelGGL(k_scale_to, gn, blk, 0, st, (const double*)w, (const double*)(S + o.misc + 1),
                                V + (int64_t)(j + 1) * ldv, n);
             FEDD_HIP(hipMemcpyAsync(c->h_pinned, S + o.misc, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -349,7 +368,7 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
             }
         }
         // x += M^-1 (V y)
-        hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(1), 0, st, S, o, k, m);
+        hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(k + 1) * sizeof(double), st, S, o, k, m);
         hipLaunchKernelGGL(k_combine, gn, blk, 0, st, (const double*)V, ldv, n, k, (const double*)(S + o.y), r);
         if (use_prec) {
             FEDD_TRY(schwarz_apply(c, r, z));
