@@ -935,8 +935,15 @@ def gmres_right(A, b, M=None, rtol=1e-8, max_it=100, restart=100, x0=None):
     return x, its, hist
 
 
-def direct_solve(A: sp.csr_matrix, b: np.ndarray) -> np.ndarray:
-    return spla.splu(A.tocsc()).solve(b)
+def direct_solve(A: sp.csr_matrix, b: np.ndarray, refine: int = 2) -> np.ndarray:
+    """Sparse LU + a few steps of iterative refinement (badly scaled systems, e.g. elasticity with
+    unit Dirichlet rows next to 1e6-sized entries, otherwise keep O(1e-16) absolute noise at the
+    Dirichlet dofs, which is above 1e-10 relative to max|x|)."""
+    lu = spla.splu(A.tocsc())
+    x = lu.solve(b)
+    for _ in range(refine):
+        x = x + lu.solve(b - A @ x)
+    return x
 
 
 def spmv(A: sp.csr_matrix, x: np.ndarray) -> np.ndarray:

@@ -249,3 +249,35 @@ def test_full_size_properties(fedd_lib, ctx):
     assert np.linalg.norm(b - Abc @ x) / np.linalg.norm(b) < 1e-7
     # the discrete solution of -lap u = 1, u = 0 on the boundary peaks at the centre: 0.0562 (series value)
     assert abs(x[c] - 0.05621) < 2e-4
+
+
+@pytest.mark.parametrize("dim,M,target", [(3, 6, 8), (2, 12, 9)])
+def test_linear_elasticity_solve(fedd_lib, ctx, dim, M, target):
+    """steadyLinElas_Perf sequence (LinElas_def.hpp:64-99; parameters steadyLinElas_Perf/parametersProblem.xml:5-11):
+    3 (2) dofs per node, full blocks, Dirichlet on flag 2, one-level Restricted Schwarz + GMRES."""
+    m = fedd_lib.structured_mesh(dim, 1, M)
+    om = oracle_mesh(m)
+    mu, nu = 2.0e6, 0.4
+    E = mu * 2.0 * (1.0 + nu)
+    lam = nu * E / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    f = [0.0, 1.0, 0.0][:dim]
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(dim, fedd_lib.BLOCK_FULL)
+    ctx.assemble(fedd_lib.FORM_LINELAS, [lam, mu])
+    ctx.assemble_rhs(f)
+    ctx.dirichlet([2], np.zeros(dim))
+    A_bc, rhs_bc, _, _, _ = fo.linelas_problem(om, mu, nu, f=f, bc_flags=(2,))
+    ctx.schwarz_set_target(target, 1.0)
+    ctx.schwarz_setup(overlap=1, combine=fedd_lib.COMBINE_RESTRICTED)
+    info = ctx.schwarz_info()
+    assert info["max_size"] <= 256
+    x, its, rel = ctx.gmres(None, rtol=1e-13, max_it=800, restart=200, use_prec=True)
+    assert rel <= 1e-13
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    np.testing.assert_allclose(x, xd, rtol=0, atol=RTOL * np.abs(xd).max())
+    # the same preconditioner definition in the oracle (dofs = dim) gives the same iteration count
+    node_bin, nb, g = fo.schwarz_bins(m["xyz"], target)
+    ras = fo.RAS(A_bc, node_bin, nb, dofs=dim)
+    assert info["n_subdomains"] == nb and info["max_size"] == ras.max_size
+    xo, its_o, hist = fo.gmres_right(A_bc, rhs_bc, ras.apply, rtol=1e-13, max_it=800, restart=200)
+    assert abs(its - its_o) <= 2, (its, its_o)
