@@ -33,6 +33,11 @@ SIGNATURES = {
     "fedd_mesh_structured_build": [C.c_int, _ip, _ip, C.c_int, _f64p, _f64p, C.c_int, C.c_int, _i32p, _f64p,
                                    _i64p, _i32p, _i64p, _i32p],
     "fedd_mesh_structured_owner": [C.c_int, _ip, _ip, C.c_int64, _i64p, _i32p],
+    "fedd_mesh_read_sizes": [C.c_char_p, C.c_int, _i64p, _i64p, _i64p],
+    "fedd_mesh_read": [C.c_char_p, C.c_int, _f64p, _i32p, _i32p, _i32p, _i32p, _i32p],
+    "fedd_mesh_p2_sizes": [C.c_int, C.c_int64, _i32p, _i64p],
+    "fedd_mesh_p2_build": [C.c_int, C.c_int64, C.c_int64, _i32p, _f64p, _i32p, C.c_int64, _i32p, _i32p, C.c_int,
+                           _i32p, _f64p, _i32p],
     "fedd_mesh_set": [C.c_void_p, C.c_int, C.c_int, C.c_int64, _i32p, C.c_int64, _f64p, _i64p, C.c_int64,
                       _i64p, _i32p],
     "fedd_pattern_build": [C.c_void_p, C.c_int, C.c_int, _i64p],
@@ -131,6 +136,43 @@ def structured_mesh(dim, N, M, rank=0, origin=None, size=None, flags_option=1, g
                                       _p(flag_rep, _i32p), _p(gid_uni, _i64p), _p(flag_uni, _i32p)))
     return dict(dim=dim, nen=dim + 1, conn=conn, xyz=xyz, gid_rep=gid_rep, flag_rep=flag_rep, gid_uni=gid_uni,
                 flag_uni=flag_uni, n_global=ng.value, decomp=dec, cells=cel, rank=rank)
+
+
+def read_mesh(path, dim):
+    """INRIA .mesh file -> one-rank P1 mesh dict (repeated = unique = identity numbering)."""
+    L = lib()
+    nv, ne, ns = C.c_int64(), C.c_int64(), C.c_int64()
+    _chk(L.fedd_mesh_read_sizes(path.encode(), dim, C.byref(nv), C.byref(ne), C.byref(ns)))
+    xyz = np.zeros((nv.value, dim)); vflag = np.zeros(nv.value, dtype=np.int32)
+    conn = np.zeros((ne.value, dim + 1), dtype=np.int32); eflag = np.zeros(ne.value, dtype=np.int32)
+    surf = np.zeros((ns.value, dim), dtype=np.int32); sflag = np.zeros(ns.value, dtype=np.int32)
+    _chk(L.fedd_mesh_read(path.encode(), dim, _p(xyz, _f64p), _p(vflag, _i32p), _p(conn, _i32p), _p(eflag, _i32p),
+                          _p(surf, _i32p), _p(sflag, _i32p)))
+    gid = np.arange(nv.value, dtype=np.int64)
+    return dict(dim=dim, nen=dim + 1, conn=conn, xyz=xyz, gid_rep=gid, flag_rep=vflag, gid_uni=gid.copy(),
+                flag_uni=vflag.copy(), n_global=nv.value, elem_flag=eflag, surf=surf, surf_flag=sflag)
+
+
+def p2_of_p1(m, volume_id=10):
+    """P2 mesh dict from a one-rank P1 mesh dict (edge mid-points)."""
+    L = lib()
+    dim = m["dim"]
+    conn = np.ascontiguousarray(m["conn"], dtype=np.int32)
+    ned = C.c_int64()
+    _chk(L.fedd_mesh_p2_sizes(dim, conn.shape[0], _p(conn, _i32p), C.byref(ned)))
+    nv = m["xyz"].shape[0]
+    nen2 = 10 if dim == 3 else 6
+    conn2 = np.zeros((conn.shape[0], nen2), dtype=np.int32)
+    xyz2 = np.zeros((nv + ned.value, dim)); flag2 = np.zeros(nv + ned.value, dtype=np.int32)
+    xyz = np.ascontiguousarray(m["xyz"], dtype=np.float64); vf = np.ascontiguousarray(m["flag_rep"], dtype=np.int32)
+    surf = np.ascontiguousarray(m.get("surf", np.zeros((0, dim), np.int32)), dtype=np.int32)
+    sflag = np.ascontiguousarray(m.get("surf_flag", np.zeros(0, np.int32)), dtype=np.int32)
+    _chk(L.fedd_mesh_p2_build(dim, nv, conn.shape[0], _p(conn, _i32p), _p(xyz, _f64p), _p(vf, _i32p), surf.shape[0],
+                              _p(surf, _i32p), _p(sflag, _i32p), volume_id, _p(conn2, _i32p), _p(xyz2, _f64p),
+                              _p(flag2, _i32p)))
+    gid = np.arange(nv + ned.value, dtype=np.int64)
+    return dict(dim=dim, nen=nen2, conn=conn2, xyz=xyz2, gid_rep=gid, flag_rep=flag2, gid_uni=gid.copy(),
+                flag_uni=flag2.copy(), n_global=nv + ned.value, n_p1=nv, elem_flag=m.get("elem_flag"))
 
 
 def structured_owner(dim, N, M, gids):

@@ -94,6 +94,22 @@ int fedd_mesh_structured_build(int dim, const int* decomp, const int* cells, int
                                int64_t* gid_uni /*[n_uni]*/, int32_t* flag_uni /*[n_uni]*/);
 
 /* ------------------------------------------------------------------------------------------------
+ * unstructured input, host side, one rank: INRIA/medit ".mesh" reader (MeshFileReader.cpp:16-106,
+ * MeshFileReader.hpp:35-127, 1-based ids converted as MeshUnstructured_def.hpp:1181-1190) and the
+ * P2-from-P1 construction (MeshUnstructured::buildP2ofP1MeshEdge, MeshUnstructured_def.hpp:129-410;
+ * edge ids = rank in the sorted (min,max) list, EdgeElements.cpp:105-155; mid node id = n_vert + edge id;
+ * slots (0,1)->4 (1,2)->5 (0,2)->6 (0,3)->7 (1,3)->8 (2,3)->9, :755-772; flags :806-900).
+ * surf = boundary entities (Edges in 2D, Triangles in 3D), dim nodes each.
+ * ---------------------------------------------------------------------------------------------- */
+int fedd_mesh_read_sizes(const char* path, int dim, int64_t* n_vert, int64_t* n_elem, int64_t* n_surf);
+int fedd_mesh_read(const char* path, int dim, double* xyz, int32_t* vflag, int32_t* conn, int32_t* eflag,
+                   int32_t* surf, int32_t* sflag);
+int fedd_mesh_p2_sizes(int dim, int64_t n_elem, const int32_t* conn_p1, int64_t* n_edges);
+int fedd_mesh_p2_build(int dim, int64_t n_vert, int64_t n_elem, const int32_t* conn_p1, const double* xyz_p1,
+                       const int32_t* vflag_p1, int64_t n_surf, const int32_t* surf, const int32_t* sflag,
+                       int volume_id, int32_t* conn_p2, double* xyz_p2, int32_t* flag_p2);
+
+/* ------------------------------------------------------------------------------------------------
  * mesh upload: what FE::assemblyXxx reads through domainVec_[FEloc]->getElementsC(),
  * getPointsRepeated(), getMapRepeated() (feddlib/core/FE/FE_def.hpp:617-621) and what BCBuilder
  * reads through getBCFlagUnique()/getMapUnique() (feddlib/core/General/BCBuilder_def.hpp:625-626).

@@ -426,7 +426,7 @@ def read_mesh_file(path: str, dim: int, volume_id: int = 10) -> Mesh:
     gid = np.arange(n, dtype=np.int64)
     return Mesh(dim=dim, fe="P1", conn=elems, xyz=verts, gid_rep=gid, flag_rep=vflag.copy(),
                 gid_uni=gid.copy(), flag_uni=vflag.copy(), xyz_uni=verts.copy(), n_global=n,
-                elem_flag=eflag, extra={"surf": surf, "surf_flag": sflag})
+                elem_flag=eflag, extra={"surf": surf, "surf_flag": sflag, "volume_id": volume_id})
 
 
 # local edge order used to create P2 mid-edge nodes
@@ -463,9 +463,25 @@ def build_p2_of_p1(m: Mesh) -> Mesh:
     conn[:, :m.dim + 1] = m.conn
     for k, pr in enumerate(pairs):
         conn[:, slots[pr]] = n_p1 + inv[:, k]
+    # determineFlagP2 (MeshUnstructured_def.hpp:806-900): interior if an end node is interior, else
+    # the lowest flag of the boundary entities (Edges in 2D, Triangles in 3D) that contain both end
+    # nodes, interior (volume id) if there is none
+    interior = int(m.extra.get("volume_id", 10))
     fl, fh = m.flag_rep[lo], m.flag_rep[hi]
-    interior = 10
-    mflag = np.where((fl != interior) & (fh != interior), np.minimum(fl, fh), interior).astype(np.int32)
+    mflag = np.full(lo.shape[0], interior, dtype=np.int32)
+    surf, sflag = m.extra.get("surf"), m.extra.get("surf_flag")
+    if surf is not None and len(surf):
+        pair_flag = {}
+        d = surf.shape[1]
+        for a in range(d):
+            for b in range(a + 1, d):
+                u = np.minimum(surf[:, a], surf[:, b]); v = np.maximum(surf[:, a], surf[:, b])
+                for uu, vv, ff in zip(u.tolist(), v.tolist(), sflag.tolist()):
+                    k = (uu, vv)
+                    pair_flag[k] = min(pair_flag.get(k, ff), ff)
+        both = (fl != interior) & (fh != interior)
+        for i in np.nonzero(both)[0]:
+            mflag[i] = pair_flag.get((int(lo[i]), int(hi[i])), interior)
     flag = np.concatenate([m.flag_rep, mflag])
     gid = np.concatenate([m.gid_rep, off + np.arange(uniq.shape[0], dtype=np.int64)])
     return Mesh(dim=m.dim, fe="P2", conn=conn, xyz=xyz, gid_rep=gid, flag_rep=flag, gid_uni=gid.copy(),

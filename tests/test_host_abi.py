@@ -67,6 +67,42 @@ def test_structured_generator_matches_oracle(fedd_lib, dim, N, M):
                                       fo.structured_owner(dim, N, M, o.gid_rep))
 
 
+@pytest.mark.parametrize("name,dim,vol", [("square.mesh", 2, 10), ("tetrahedron.mesh", 3, 10), ("DFG3DCylinder_1k.mesh", 3, 0)])
+def test_mesh_reader_and_p2_build_match_oracle(fedd_lib, name, dim, vol):
+    path = os.path.join(ROOT, "tests", "golden", name)
+    m = fedd_lib.read_mesh(path, dim)
+    o = fo.read_mesh_file(path, dim, volume_id=int(np.bincount(m["elem_flag"]).argmax()))
+    np.testing.assert_array_equal(m["conn"], o.conn)
+    np.testing.assert_array_equal(m["xyz"], o.xyz)
+    np.testing.assert_array_equal(m["flag_uni"], o.flag_uni)
+    np.testing.assert_array_equal(m["surf"], o.extra["surf"])
+    np.testing.assert_array_equal(m["surf_flag"], o.extra["surf_flag"])
+    o.extra["volume_id"] = vol
+    m2 = fedd_lib.p2_of_p1(m, volume_id=vol)
+    o2 = fo.build_p2_of_p1(o)
+    np.testing.assert_array_equal(m2["conn"], o2.conn)
+    np.testing.assert_array_equal(m2["xyz"], o2.xyz)
+    np.testing.assert_array_equal(m2["flag_uni"], o2.flag_uni)
+    # mid nodes sit at edge mid-points in the slot order (0,1)->nv.. of the reference
+    nv = m["xyz"].shape[0]
+    slots = {(0, 1): dim + 1, (1, 2): dim + 2, (0, 2): dim + 3}
+    if dim == 3:
+        slots.update({(0, 3): 7, (1, 3): 8, (2, 3): 9})
+    for (a, b), s in slots.items():
+        mid = 0.5 * (m2["xyz"][m2["conn"][:, a]] + m2["xyz"][m2["conn"][:, b]])
+        np.testing.assert_allclose(m2["xyz"][m2["conn"][:, s]], mid, atol=1e-15)
+    assert (m2["conn"][:, dim + 1:] >= nv).all()
+
+
+def test_mesh_reader_errors(fedd_lib, tmp_path):
+    with pytest.raises(fedd_lib.FeddError, match="cannot open"):
+        fedd_lib.read_mesh(str(tmp_path / "nope.mesh"), 2)
+    bad = tmp_path / "bad.mesh"
+    bad.write_text("MeshVersionFormatted 1\nDimension 2\nVertices\n2\n0 0 0 1\n1 0 0 1\n")
+    with pytest.raises(fedd_lib.FeddError, match="no Triangles"):
+        fedd_lib.read_mesh(str(bad), 2)
+
+
 def test_structured_generator_errors(fedd_lib):
     with pytest.raises(fedd_lib.FeddError, match="H/h"):
         fedd_lib.structured_mesh(3, 1, 0)
