@@ -45,6 +45,13 @@ SIGNATURES = {
     "fedd_assemble_rhs": [C.c_void_p, C.c_int, _f64p, C.c_int],
     "fedd_dirichlet": [C.c_void_p, C.c_int, _i32p, _i32p, _f64p],
     "fedd_dirichlet_nodes": [C.c_void_p, C.c_int64, _i32p, _i32p, _f64p],
+    "fedd_dirichlet_rows": [C.c_void_p, C.c_int64, _i32p, _f64p],
+    "fedd_matrix_store": [C.c_void_p, C.c_int],
+    "fedd_matrix_scale": [C.c_void_p, C.c_int, C.c_double],
+    "fedd_assemble_div": [C.c_void_p, C.c_int64, C.c_int, C.c_int],
+    "fedd_block_merge": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],
+    "fedd_matrix_sizes": [C.c_void_p, C.c_int, _i64p, _i64p, _i64p],
+    "fedd_matrix_get": [C.c_void_p, C.c_int, _i64p, _i32p, _f64p],
     "fedd_csr_sizes": [C.c_void_p, _i64p, _i64p, _i64p],
     "fedd_csr_get": [C.c_void_p, _i64p, _i32p, _f64p, _i64p],
     "fedd_rhs_get": [C.c_void_p, _f64p],
@@ -255,6 +262,34 @@ class Context:
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
         m = None if comp_mask is None else np.ascontiguousarray(comp_mask, dtype=np.int32).ravel()
         _chk(self._L.fedd_dirichlet_nodes(self._h, nd.shape[0], _p(nd, _i32p), _p(m, _i32p), _p(v, _f64p)))
+
+    def dirichlet_rows(self, rows, values):
+        r = np.ascontiguousarray(rows, dtype=np.int32)
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        _chk(self._L.fedd_dirichlet_rows(self._h, r.shape[0], _p(r, _i32p), _p(v, _f64p)))
+
+    def matrix_store(self, slot):
+        _chk(self._L.fedd_matrix_store(self._h, slot))
+
+    def matrix_scale(self, slot, alpha):
+        _chk(self._L.fedd_matrix_scale(self._h, slot, float(alpha)))
+
+    def assemble_div(self, n_pressure_nodes, slot_b, slot_bt):
+        _chk(self._L.fedd_assemble_div(self._h, n_pressure_nodes, slot_b, slot_bt))
+
+    def block_merge(self, slot_a, slot_bt, slot_b, slot_c=-1):
+        _chk(self._L.fedd_block_merge(self._h, slot_a, slot_bt, slot_b, slot_c))
+        self.dofs = 1
+
+    def matrix_get(self, slot):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _chk(self._L.fedd_matrix_sizes(self._h, slot, C.byref(a), C.byref(b), C.byref(c)))
+        rowptr = np.zeros(a.value + 1, dtype=np.int64)
+        col = np.zeros(c.value, dtype=np.int32)
+        val = np.zeros(c.value, dtype=np.float64)
+        _chk(self._L.fedd_matrix_get(self._h, slot, _p(rowptr, _i64p), _p(col, _i32p), _p(val, _f64p)))
+        import scipy.sparse as sp
+        return sp.csr_matrix((val, col, rowptr), shape=(a.value, b.value))
 
     def csr_sizes(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()

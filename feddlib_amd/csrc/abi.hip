@@ -121,6 +121,12 @@ extern "C" void fedd_ctx_destroy(fedd_ctx* c) {
                                       &c->d_small, &c->d_dtmp0, &c->halo.d_send_buf, &c->halo.d_recv_buf};
         for (auto* b : db) b->release();
         c->d_inv_ptr.release();
+        c->d_dof_node.release();
+        for (auto& m : c->aux) {
+            m.rowptr.release();
+            m.colind.release();
+            m.val.release();
+        }
         for (auto& b : c->d_scan) b.release();
         if (c->h_pinned) (void)hipHostFree(c->h_pinned);
         (void)hipStreamDestroy(c->stream);
@@ -263,6 +269,83 @@ extern "C" int fedd_dirichlet_nodes(fedd_ctx* c, int64_t n, const int32_t* owned
     return apply_dirichlet_nodes(c, n, owned_nodes, comp_mask, values);
 }
 
+extern "C" int fedd_dirichlet_rows(fedd_ctx* c, int64_t n, const int32_t* rows, const double* values) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_dirichlet_rows: no system matrix");
+    FEDD_CHECK(n >= 0 && (n == 0 || (rows && values)), "fedd_dirichlet_rows: null array");
+    FEDD_HIP(hipSetDevice(c->device));
+    return apply_dirichlet_rows(c, n, rows, values);
+}
+
+#define CHECK_SLOT(s) FEDD_CHECK((s) >= 0 && (s) < fedd::MAX_AUX, "matrix slot %d out of range", (s))
+
+extern "C" int fedd_matrix_store(fedd_ctx* c, int slot) {
+    NEED_DEVICE(c);
+    CHECK_SLOT(slot);
+    FEDD_CHECK(c->have_pattern, "fedd_matrix_store: no system matrix");
+    FEDD_HIP(hipSetDevice(c->device));
+    return matrix_store(c, slot);
+}
+
+extern "C" int fedd_matrix_scale(fedd_ctx* c, int slot, double alpha) {
+    NEED_DEVICE(c);
+    if (slot >= 0) {
+        CHECK_SLOT(slot);
+        FEDD_CHECK(c->aux[slot].valid, "fedd_matrix_scale: slot %d is empty", slot);
+    } else {
+        FEDD_CHECK(c->have_pattern, "fedd_matrix_scale: no system matrix");
+    }
+    FEDD_HIP(hipSetDevice(c->device));
+    return matrix_scale(c, slot, alpha);
+}
+
+extern "C" int fedd_assemble_div(fedd_ctx* c, int64_t n_pressure_nodes, int slot_b, int slot_bt) {
+    NEED_DEVICE(c);
+    CHECK_SLOT(slot_b);
+    CHECK_SLOT(slot_bt);
+    FEDD_CHECK(slot_b != slot_bt, "fedd_assemble_div: B and B^T need different slots");
+    FEDD_CHECK(c->n_node > 0, "fedd_assemble_div: call fedd_mesh_set first");
+    FEDD_HIP(hipSetDevice(c->device));
+    return assemble_div(c, n_pressure_nodes, slot_b, slot_bt);
+}
+
+extern "C" int fedd_block_merge(fedd_ctx* c, int slot_a, int slot_bt, int slot_b, int slot_c) {
+    NEED_DEVICE(c);
+    CHECK_SLOT(slot_a);
+    FEDD_CHECK(slot_bt < fedd::MAX_AUX && slot_b < fedd::MAX_AUX && slot_c < fedd::MAX_AUX, "fedd_block_merge: slot out of range");
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_TRY(block_merge(c, slot_a, slot_bt, slot_b, slot_c));
+    c->have_pattern = true;
+    return 0;
+}
+
+extern "C" int fedd_matrix_sizes(fedd_ctx* c, int slot, int64_t* n_rows, int64_t* n_cols, int64_t* nnz) {
+    FEDD_CHECK(c, "null context");
+    CHECK_SLOT(slot);
+    FEDD_CHECK(c->aux[slot].valid, "fedd_matrix_sizes: slot %d is empty", slot);
+    if (n_rows) *n_rows = c->aux[slot].n_rows;
+    if (n_cols) *n_cols = c->aux[slot].n_cols;
+    if (nnz) *nnz = c->aux[slot].nnz;
+    return 0;
+}
+
+extern "C" int fedd_matrix_get(fedd_ctx* c, int slot, int64_t* rowptr, int32_t* colind, double* val) {
+    NEED_DEVICE(c);
+    CHECK_SLOT(slot);
+    const fedd::DevCsr& m = c->aux[slot];
+    FEDD_CHECK(m.valid, "fedd_matrix_get: slot %d is empty", slot);
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    if (rowptr) {
+        std::vector<int32_t> rp((size_t)m.n_rows + 1);
+        FEDD_HIP(hipMemcpy(rp.data(), m.rowptr.p, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < rp.size(); ++i) rowptr[i] = rp[i];
+    }
+    if (colind) FEDD_HIP(hipMemcpy(colind, m.colind.p, (size_t)m.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (val) FEDD_HIP(hipMemcpy(val, m.val.p, (size_t)m.nnz * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int fedd_csr_sizes(fedd_ctx* c, int64_t* n_rows, int64_t* n_cols, int64_t* nnz) {
     FEDD_CHECK(c && c->have_pattern, "fedd_csr_sizes: no pattern");
     if (n_rows) *n_rows = c->n_rows;
@@ -283,7 +366,15 @@ extern "C" int fedd_csr_get(fedd_ctx* c, int64_t* rowptr, int32_t* colind, doubl
     }
     if (colind) FEDD_HIP(hipMemcpy(colind, c->d_colind.p, (size_t)c->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (val) FEDD_HIP(hipMemcpy(val, c->d_val.p, (size_t)c->nnz * sizeof(double), hipMemcpyDeviceToHost));
-    if (col_gid)
+    if (col_gid && c->merged) {
+        // BlockMap::merge: block-local global id + cumulated (maxAllGlobalIndex + 1) of the blocks before
+        const int da = c->merged_dofsA;
+        int64_t mx = -1;
+        for (int64_t n = 0; n < c->n_own; ++n) mx = std::max(mx, c->h_node_gid[n]);
+        const int64_t off = (mx + 1) * da;
+        for (int64_t r = 0; r < c->merged_nA; ++r) col_gid[r] = c->h_node_gid[r / da] * da + r % da;
+        for (int64_t r = c->merged_nA; r < c->n_rows; ++r) col_gid[r] = off + c->h_node_gid[r - c->merged_nA];
+    } else if (col_gid)
         for (int64_t n = 0; n < c->n_node; ++n)
             for (int d = 0; d < c->dofs; ++d) col_gid[n * c->dofs + d] = c->h_node_gid[n] * c->dofs + d;
     return 0;
@@ -355,6 +446,7 @@ extern "C" int fedd_schwarz_setup(fedd_ctx* c, int overlap, int combine, int two
     FEDD_CHECK(overlap >= 0 && overlap <= 4, "fedd_schwarz_setup: overlap %d", overlap);
     FEDD_CHECK(combine >= 0 && combine <= 2, "fedd_schwarz_setup: combine mode %d", combine);
     FEDD_CHECK(two_level == 0, "fedd_schwarz_setup: the GDSW coarse level (coarse_kind %d) is not built yet", coarse_kind);
+    FEDD_CHECK(!c->merged, "fedd_schwarz_setup: Schwarz subdomains for merged block systems are not built yet");
     FEDD_HIP(hipSetDevice(c->device));
     c->sw_overlap = overlap;
     c->sw_combine = combine;

@@ -21,7 +21,10 @@
 namespace fedd {
 namespace {
 
-enum { F_LAPLACE = 0, F_MASS = 1, F_LINELAS = 2 };
+// F_DIV / F_DIVT: FE::assemblyDivAndDivT (feddlib/core/FE/FE_def.hpp:1932-2057), pressure = P1 on
+// the element's vertices.  F_DIV rows = pressure nodes, columns = DIM*velocity node + d;
+// F_DIVT rows = velocity dofs, columns = pressure nodes.
+enum { F_LAPLACE = 0, F_MASS = 1, F_LINELAS = 2, F_DIV = 3, F_DIVT = 4 };
 
 struct AsmArgs {
     const int32_t* conn;
@@ -31,7 +34,7 @@ struct AsmArgs {
     const int32_t* colind;
     const double* xyz;
     double* val;
-    const double* tab;  // w[nq] | phi[nq*nen] | dphi[nq*nen*dim]
+    const double* tab;  // w[nq] | phi[nq*nen] | dphi[nq*nen*dim] | psi[nq*(dim+1)] (P1 pressure basis)
     int nq;
     int32_t n_rows;
     int dofs;
@@ -226,7 +229,8 @@ __global__ void k_assemble(AsmArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <int DIM, int NEN, int FORM>
 struct PairCfg {
-    static constexpr int CPP = FORM == F_LINELAS ? NEN * DIM : NEN;  // contributions per pair
+    // contributions per (row, element) pair
+    static constexpr int CPP = (FORM == F_LINELAS || FORM == F_DIV) ? NEN * DIM : (FORM == F_DIVT ? DIM + 1 : NEN);
 };
 
 template <int DIM, int NEN, int FORM>
@@ -269,6 +273,47 @@ __device__ __forceinline__ void eval_pair(const AsmArgs& a, const double* __rest
                 cols[j] = nd[j] * dofs + comp;
                 vals[j] = v * absdet;
             }
+        } else if constexpr (FORM == F_DIV) {
+            // row = pressure node (vertex li): B_{i,(j,d)} = |detB| sum_q w_q psi_qi dphi_qjd  (FE_def.hpp:1992-2004)
+            const double* __restrict__ s_psi = s_dphi + nq * NEN * DIM;
+#pragma unroll
+            for (int j = 0; j < NEN; ++j) {
+                double vd[DIM];
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) vd[d] = 0.0;
+                for (int q = 0; q < nq; ++q) {
+                    double gj[DIM];
+                    grad_t<DIM, NEN>(s_dphi, q, j, Binv, gj);
+                    const double wp = s_w[q] * s_psi[q * (DIM + 1) + li];
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) vd[d] += wp * gj[d];
+                }
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) {
+                    cols[j * DIM + d] = nd[j] * DIM + d;
+                    vals[j * DIM + d] = absdet * vd[d];
+                }
+            }
+        } else if constexpr (FORM == F_DIVT) {
+            // row = velocity dof (node li, component comp): B^T_{(i,d),j} = |detB| sum_q w_q psi_qj dphi_qid  (:2022-2046)
+            const double* __restrict__ s_psi = s_dphi + nq * NEN * DIM;
+            double vj[DIM + 1];
+#pragma unroll
+            for (int j = 0; j <= DIM; ++j) vj[j] = 0.0;
+            for (int q = 0; q < nq; ++q) {
+                double gi[DIM];
+                grad_t<DIM, NEN>(s_dphi, q, li, Binv, gi);
+                double gc = 0.0;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) gc = d == comp ? gi[d] : gc;
+#pragma unroll
+                for (int j = 0; j <= DIM; ++j) vj[j] += s_w[q] * s_psi[q * (DIM + 1) + j] * gc;
+            }
+#pragma unroll
+            for (int j = 0; j <= DIM; ++j) {
+                cols[j] = nd[j];
+                vals[j] = absdet * vj[j];
+            }
         } else {
             const double lam = a.p0, mu = a.p1;
 #pragma unroll
@@ -306,7 +351,7 @@ __global__ __launch_bounds__(256) void k_assemble_pairs(AsmArgs a, int R, int tp
     constexpr int CPP = PairCfg<DIM, NEN, FORM>::CPP;
     extern __shared__ double sm[];
     const int nq = a.nq;
-    const int ntab = nq * (1 + NEN + NEN * DIM);
+    const int ntab = nq * (1 + NEN + NEN * DIM + DIM + 1);
     double* s_w = sm;
     double* s_phi = s_w + nq;
     double* s_dphi = s_phi + nq * NEN;
@@ -472,7 +517,7 @@ __global__ void k_dirichlet_nodes(const int32_t* __restrict__ nodes, const int32
 }
 
 template <int DIM, int NEN, int FORM>
-int launch_pairs(fedd_ctx* c, const AsmArgs& a, int ntab) {
+int launch_pairs(fedd_ctx* c, const AsmArgs& a, int ntab, int64_t n_rows, int rowcap) {
     constexpr int CPP = PairCfg<DIM, NEN, FORM>::CPP;
     const int maxdeg = std::max(1, c->max_deg);
     const size_t per_row = (size_t)maxdeg * CPP * 12;  // f64 value + i32 column per contribution
@@ -482,11 +527,11 @@ int launch_pairs(fedd_ctx* c, const AsmArgs& a, int ntab) {
     const size_t lds = (size_t)ntab * 8 + (size_t)cap * 12 + (size_t)(R + 1) * 4 + 16;
     FEDD_CHECK(lds <= 160 * 1024, "assembly: a node with %d incident elements does not fit the LDS contribution buffer", maxdeg);
     int tl = 0;
-    while ((1 << tl) < std::min(64, std::max(1, c->max_row_nnz))) ++tl;
+    while ((1 << tl) < std::min(64, std::max(1, rowcap))) ++tl;
     auto kern = k_assemble_pairs<DIM, NEN, FORM>;
     if (lds > 64 * 1024)
         FEDD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const dim3 grid((unsigned)((c->n_rows + R - 1) / R)), block(256);
+    const dim3 grid((unsigned)((n_rows + R - 1) / R)), block(256);
     ScopedTimer t(c, FEDD_T_ASSEMBLE);
     hipLaunchKernelGGL(kern, grid, block, lds, c->stream, a, R, tl, cap);
     t.stop();
@@ -497,9 +542,9 @@ int launch_pairs(fedd_ctx* c, const AsmArgs& a, int ntab) {
 template <int DIM, int NEN>
 int launch_assemble(fedd_ctx* c, int kform, const AsmArgs& a, int ntab) {
     if (c->asm_kind == 0) {
-        if (kform == F_LAPLACE) return launch_pairs<DIM, NEN, F_LAPLACE>(c, a, ntab);
-        if (kform == F_MASS) return launch_pairs<DIM, NEN, F_MASS>(c, a, ntab);
-        return launch_pairs<DIM, NEN, F_LINELAS>(c, a, ntab);
+        if (kform == F_LAPLACE) return launch_pairs<DIM, NEN, F_LAPLACE>(c, a, ntab, c->n_rows, c->max_row_nnz);
+        if (kform == F_MASS) return launch_pairs<DIM, NEN, F_MASS>(c, a, ntab, c->n_rows, c->max_row_nnz);
+        return launch_pairs<DIM, NEN, F_LINELAS>(c, a, ntab, c->n_rows, c->max_row_nnz);
     }
     const int rowcap = std::max(1, c->max_row_nnz);
     int bs = 256;
@@ -522,7 +567,141 @@ int launch_assemble(fedd_ctx* c, int kform, const AsmArgs& a, int ntab) {
     return go(k_assemble<DIM, NEN, F_LINELAS>);
 }
 
+// quadrature weights, basis values / gradients of the mesh's element and the P1 (pressure) basis at
+// the same points -> d_dtmp0, layout w | phi | dphi | psi
+int upload_tables(fedd_ctx* c, int degree, int& nq, int& ntab) {
+    const int dim = c->dim, nen = c->nen;
+    FeTables tb, tp;
+    FEDD_TRY(fe_tables(dim, nen, degree, tb));
+    FEDD_TRY(fe_tables(dim, dim + 1, degree, tp));
+    nq = tb.nq;
+    ntab = nq * (1 + nen + nen * dim + dim + 1);
+    std::vector<double> host(ntab);
+    std::copy(tb.w.begin(), tb.w.end(), host.begin());
+    std::copy(tb.phi.begin(), tb.phi.end(), host.begin() + nq);
+    std::copy(tb.dphi.begin(), tb.dphi.end(), host.begin() + nq + nq * nen);
+    std::copy(tp.phi.begin(), tp.phi.end(), host.begin() + nq + nq * nen + nq * nen * dim);
+    FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>(ntab, c->d_dtmp0.cap)));
+    FEDD_HIP(hipMemcpyAsync(c->d_dtmp0.p, host.data(), ntab * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));  // `host` is a local
+    return 0;
+}
+
+// B pattern from the scalar node pattern: pressure node i (< n_p) couples to all dim components of
+// every velocity node of its elements.
+__global__ void k_div_pattern(const int32_t* __restrict__ nptr, const int32_t* __restrict__ ncol, int32_t n_p, int dim,
+                              int32_t* __restrict__ rowptr, int32_t* __restrict__ colind) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_p) return;
+    rowptr[i] = nptr[i] * dim;
+    if (i == n_p) return;
+    const int32_t b = nptr[i], nn = nptr[i + 1] - b;
+    for (int32_t s = 0; s < nn; ++s)
+        for (int d = 0; d < dim; ++d) colind[(b + s) * dim + d] = ncol[b + s] * dim + d;
+}
+
+// B^T: velocity node j couples to the vertices (< n_p) of its elements
+__global__ void k_divt_count(const int32_t* __restrict__ nptr, const int32_t* __restrict__ ncol, int32_t n_v, int32_t n_p,
+                             int32_t* __restrict__ cnt) {
+    const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_v) return;
+    int32_t k = 0;
+    for (int32_t p = nptr[j]; p < nptr[j + 1]; ++p) k += ncol[p] < n_p ? 1 : 0;
+    cnt[j] = k;
+}
+
+__global__ void k_divt_fill(const int32_t* __restrict__ nptr, const int32_t* __restrict__ ncol, int32_t n_v, int32_t n_p,
+                            int dim, const int32_t* __restrict__ cptr, int32_t* __restrict__ rowptr,
+                            int32_t* __restrict__ colind) {
+    const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n_v) return;
+    if (j == n_v) {
+        rowptr[(int64_t)n_v * dim] = cptr[n_v] * dim;
+        return;
+    }
+    const int32_t nn = cptr[j + 1] - cptr[j];
+    for (int d = 0; d < dim; ++d) {
+        const int32_t start = cptr[j] * dim + d * nn;
+        rowptr[(int64_t)j * dim + d] = start;
+        int32_t k = 0;
+        for (int32_t p = nptr[j]; p < nptr[j + 1]; ++p)
+            if (ncol[p] < n_p) colind[start + k++] = ncol[p];
+    }
+}
+
 }  // namespace
+
+// FE::assemblyDivAndDivT (feddlib/core/FE/FE_def.hpp:1932-2057) for velocity = the mesh's element
+// (P2 or P1) and pressure = P1 on the vertices; the P1 nodes are the first n_p node ids (that is how
+// the P2 mesh is built from the P1 mesh).  Unscaled; Stokes::assemble applies the -1 afterwards.
+// Uses (and overwrites) the system slot for the scalar node pattern, so blocks that must survive
+// have to be stored first.
+int assemble_div(fedd_ctx* c, int64_t n_p, int slot_b, int slot_bt) {
+    FEDD_CHECK(c->nranks == 1, "assemblyDivAndDivT: one rank only for now");
+    FEDD_CHECK(n_p > 0 && n_p <= c->n_own, "assemblyDivAndDivT: %lld pressure nodes of %lld nodes", (long long)n_p, (long long)c->n_own);
+    const int dim = c->dim, nen = c->nen;
+    const int32_t n_v = (int32_t)c->n_own;
+    if (!c->have_adj) FEDD_TRY(build_adjacency(c));
+    FEDD_TRY(build_pattern(c, 1, FEDD_BLOCK_SCALAR));  // scalar node pattern -> system slot
+    const int32_t* nptr = c->d_rowptr.p;
+    const int32_t* ncol = c->d_colind.p;
+    const int node_rowcap = c->max_row_nnz;
+    DevCsr& B = c->aux[slot_b];
+    DevCsr& BT = c->aux[slot_bt];
+    // ---- patterns ----
+    int32_t h_np = 0;
+    FEDD_HIP(hipMemcpyAsync(&h_np, nptr + n_p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    B.n_rows = n_p; B.n_cols = (int64_t)n_v * dim; B.nnz = (int64_t)h_np * dim; B.max_row_nnz = node_rowcap * dim;
+    FEDD_TRY(B.rowptr.ensure((size_t)n_p + 1));
+    FEDD_TRY(B.colind.ensure((size_t)B.nnz));
+    FEDD_TRY(B.val.ensure((size_t)B.nnz));
+    const dim3 blk(256);
+    hipLaunchKernelGGL(k_div_pattern, dim3((unsigned)((n_p + 1 + 255) / 256)), blk, 0, c->stream, nptr, ncol, (int32_t)n_p, dim,
+                       B.rowptr.p, B.colind.p);
+    FEDD_TRY(c->d_itmp1.ensure(std::max<size_t>((size_t)n_v + 1, c->d_itmp1.cap)));
+    int32_t* cptr = c->d_itmp1.p;
+    hipLaunchKernelGGL(k_divt_count, dim3((unsigned)((n_v + 255) / 256)), blk, 0, c->stream, nptr, ncol, n_v, (int32_t)n_p, cptr);
+    int32_t mx = 0;
+    FEDD_TRY(reduce_max_i32(c, cptr, n_v, &mx));
+    int64_t tot = 0;
+    FEDD_TRY(exclusive_scan_i32(c, cptr, cptr, n_v, &tot));
+    BT.n_rows = (int64_t)n_v * dim; BT.n_cols = n_p; BT.nnz = tot * dim; BT.max_row_nnz = mx;
+    FEDD_TRY(BT.rowptr.ensure((size_t)BT.n_rows + 1));
+    FEDD_TRY(BT.colind.ensure((size_t)BT.nnz));
+    FEDD_TRY(BT.val.ensure((size_t)BT.nnz));
+    hipLaunchKernelGGL(k_divt_fill, dim3((unsigned)((n_v + 1 + 255) / 256)), blk, 0, c->stream, nptr, ncol, n_v, (int32_t)n_p, dim,
+                       (const int32_t*)cptr, BT.rowptr.p, BT.colind.p);
+    FEDD_HIP(hipGetLastError());
+    // ---- values: determineDegree(dim, FE1, FE2, Grad, Std) (FE_def.hpp:1962) ----
+    int degree = fe_degree(nen, dim, true) + 1;
+    if (degree == 0) degree = 1;
+    int nq = 0, ntab = 0;
+    FEDD_TRY(upload_tables(c, degree, nq, ntab));
+    AsmArgs a;
+    a.conn = c->d_conn.p; a.n2e_ptr = c->d_n2e_ptr.p; a.n2e = c->d_n2e.p; a.xyz = c->d_xyz.p; a.tab = c->d_dtmp0.p;
+    a.nq = nq; a.p0 = a.p1 = 0.0;
+    AsmArgs ab = a, at = a;
+    ab.rowptr = B.rowptr.p; ab.colind = B.colind.p; ab.val = B.val.p; ab.n_rows = (int32_t)n_p; ab.dofs = 1;
+    at.rowptr = BT.rowptr.p; at.colind = BT.colind.p; at.val = BT.val.p; at.n_rows = (int32_t)BT.n_rows; at.dofs = dim;
+#define DIV_LAUNCH(D, N)                                                                               \
+    do {                                                                                               \
+        FEDD_TRY((launch_pairs<D, N, F_DIV>(c, ab, ntab, n_p, B.max_row_nnz)));                        \
+        FEDD_TRY((launch_pairs<D, N, F_DIVT>(c, at, ntab, BT.n_rows, BT.max_row_nnz)));                \
+    } while (0)
+    if (dim == 2 && nen == 3) DIV_LAUNCH(2, 3);
+    else if (dim == 2 && nen == 6) DIV_LAUNCH(2, 6);
+    else if (dim == 3 && nen == 4) DIV_LAUNCH(3, 4);
+    else DIV_LAUNCH(3, 10);
+#undef DIV_LAUNCH
+    B.valid = BT.valid = true;
+    c->have_pattern = false;  // the system slot only holds the scratch node pattern now
+    c->have_schwarz = false;
+    return 0;
+}
+
+namespace {
+}
 
 int assemble_matrix(fedd_ctx* c, int form, const double* params) {
     const int dim = c->dim, nen = c->nen;
@@ -549,19 +728,12 @@ int assemble_matrix(fedd_ctx* c, int form, const double* params) {
             FEDD_CHECK(false, "fedd_assemble: unknown form %d", form);
     }
     if (degree == 0) degree = 1;  // FE::determineDegree, FE_def.hpp:5508-5509
-    FeTables tb;
-    FEDD_TRY(fe_tables(dim, nen, degree, tb));
-    const int ntab = tb.nq * (1 + nen + nen * dim);
-    std::vector<double> host(ntab);
-    std::copy(tb.w.begin(), tb.w.end(), host.begin());
-    std::copy(tb.phi.begin(), tb.phi.end(), host.begin() + tb.nq);
-    std::copy(tb.dphi.begin(), tb.dphi.end(), host.begin() + tb.nq + tb.nq * nen);
-    FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>(ntab, c->d_dtmp0.cap)));
-    FEDD_HIP(hipMemcpyAsync(c->d_dtmp0.p, host.data(), ntab * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int nq = 0, ntab = 0;
+    FEDD_TRY(upload_tables(c, degree, nq, ntab));
     AsmArgs a;
     a.conn = c->d_conn.p; a.n2e_ptr = c->d_n2e_ptr.p; a.n2e = c->d_n2e.p; a.rowptr = c->d_rowptr.p;
     a.colind = c->d_colind.p; a.xyz = c->d_xyz.p; a.val = c->d_val.p; a.tab = c->d_dtmp0.p;
-    a.nq = tb.nq; a.n_rows = (int32_t)c->n_rows; a.dofs = c->dofs;
+    a.nq = nq; a.n_rows = (int32_t)c->n_rows; a.dofs = c->dofs;
     a.p0 = params ? params[0] : 0.0;
     a.p1 = params ? params[1] : 0.0;
     c->have_schwarz = false;
@@ -616,6 +788,29 @@ int apply_dirichlet_nodes(fedd_ctx* c, int64_t n, const int32_t* nodes, const in
     t.stop();
     FEDD_HIP(hipGetLastError());
     FEDD_HIP(hipStreamSynchronize(c->stream));  // host staging buffers are the caller's
+    c->have_schwarz = false;
+    return 0;
+}
+
+// generic variant on system rows (merged block systems): row <- unit row, rhs <- value.  On a merged
+// matrix this equals setLocalRowOne on the diagonal block + setLocalRowZero on the off-diagonal
+// blocks of that block row (BCBuilder_def.hpp:589-707) applied before the merge.
+int apply_dirichlet_rows(fedd_ctx* c, int64_t n, const int32_t* rows, const double* values) {
+    if (n == 0) return 0;
+    for (int64_t k = 0; k < n; ++k)
+        FEDD_CHECK(rows[k] >= 0 && rows[k] < c->n_rows, "fedd_dirichlet_rows: row %d out of range", rows[k]);
+    FEDD_TRY(c->d_itmp0.ensure(std::max<size_t>((size_t)n, c->d_itmp0.cap)));
+    FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>((size_t)n, c->d_dtmp0.cap)));
+    FEDD_HIP(hipMemcpyAsync(c->d_itmp0.p, rows, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    FEDD_HIP(hipMemcpyAsync(c->d_dtmp0.p, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // reuse the node kernel with one dof per "node": row ids are the node ids
+    ScopedTimer t(c, FEDD_T_DIRICHLET);
+    hipLaunchKernelGGL(k_dirichlet_nodes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       (const int32_t*)c->d_itmp0.p, (const int32_t*)nullptr, (const double*)c->d_dtmp0.p, (int32_t)n, 1,
+                       (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p, c->d_val.p, c->d_rhs.p, c->d_isdir.p);
+    t.stop();
+    FEDD_HIP(hipGetLastError());
+    FEDD_HIP(hipStreamSynchronize(c->stream));
     c->have_schwarz = false;
     return 0;
 }

@@ -79,6 +79,16 @@ struct HaloPlan {
     bool ready = false;
 };
 
+// a device CSR matrix held beside the system matrix (blocks of a mixed problem before the merge)
+struct DevCsr {
+    DevBuf<int32_t> rowptr, colind;
+    DevBuf<double> val;
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int max_row_nnz = 0;
+    bool valid = false;
+};
+constexpr int MAX_AUX = 4;
+
 struct TimerSlot {
     double total_ms = 0.0;
     int64_t launches = 0;
@@ -127,6 +137,11 @@ struct fedd_ctx {
     int asm_kind = 0;                           // 0 = pair-parallel assembly, 1 = lane-per-row gather
     fedd::DevBuf<int32_t> d_spmv_rows;          // CSR-stream: first row of every nnz window
     bool spmv_rows_ready = false;
+    fedd::DevCsr aux[fedd::MAX_AUX];            // stored blocks (A, B, B^T, C) of a mixed problem
+    bool merged = false;                        // system matrix = merged blocks (dof -> node map below)
+    int64_t merged_nA = 0;                      // rows of block row 0
+    int merged_dofsA = 1;                       // dofs per node of block row 0
+    fedd::DevBuf<int32_t> d_dof_node;           // [n_rows] node whose coordinates place the dof (merged systems)
 
     // ---- Schwarz ----
     int sw_target = 27;
@@ -204,6 +219,13 @@ int apply_dirichlet(fedd_ctx* c, int n_bc, const int32_t* flags, const int32_t* 
                     const double* values);
 int apply_dirichlet_nodes(fedd_ctx* c, int64_t n, const int32_t* nodes, const int32_t* comp_mask,
                           const double* values);
+int apply_dirichlet_rows(fedd_ctx* c, int64_t n, const int32_t* rows, const double* values);
+int assemble_div(fedd_ctx* c, int64_t n_pressure_nodes, int slot_b, int slot_bt);
+
+// blocks.hip
+int matrix_store(fedd_ctx* c, int slot);
+int matrix_scale(fedd_ctx* c, int slot, double alpha);
+int block_merge(fedd_ctx* c, int slot_a, int slot_bt, int slot_b, int slot_c);
 
 // spmv.hip
 int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned);   // incl. ghost import

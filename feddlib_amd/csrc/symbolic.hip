@@ -199,6 +199,7 @@ int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
     c->have_pattern = true;
     c->have_schwarz = false;
     c->spmv_rows_ready = false;
+    c->merged = false;
     return 0;
 }
 

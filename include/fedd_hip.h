@@ -144,6 +144,29 @@ int fedd_dirichlet(fedd_ctx* ctx, int n_bc, const int32_t* flags, const int32_t*
 int fedd_dirichlet_nodes(fedd_ctx* ctx, int64_t n, const int32_t* owned_nodes, const int32_t* comp_mask,
                          const double* values);
 
+/* unit rows on arbitrary system rows (merged block systems): what setLocalRowOne on the diagonal
+ * block + setLocalRowZero on the off-diagonal blocks (BCBuilder_def.hpp:653-707) leave in that row. */
+int fedd_dirichlet_rows(fedd_ctx* ctx, int64_t n, const int32_t* rows, const double* values);
+
+/* ------------------------------------------------------------------------------------------------
+ * mixed / block problems (one rank for now).  Blocks live in numbered slots beside the system matrix.
+ *   fedd_matrix_store     copy the system matrix into `slot` (0..3)
+ *   fedd_matrix_scale     Matrix::scale (Stokes_def.hpp:83-85,102); slot < 0 = system matrix
+ *   fedd_assemble_div     FE::assemblyDivAndDivT (FE_def.hpp:1932-2057): velocity = the mesh's element,
+ *                         pressure = P1 on the vertices = the first n_pressure_nodes node ids; B -> slot_b
+ *                         (n_p x dim*n_v), B^T -> slot_bt.  Overwrites the system slot (scratch).
+ *   fedd_block_merge      BlockMatrix::merge + BlockMap::merge (BlockMatrix_def.hpp:119-148,212-287;
+ *                         BlockMap_def.hpp:55-80): system <- [A B^T; B C] (slot < 0 = empty block); merged
+ *                         global ids = block-local gid + cumulated (maxAllGlobalIndex + 1).
+ *   fedd_matrix_sizes/get read a stored block back (local column ids).
+ * ---------------------------------------------------------------------------------------------- */
+int fedd_matrix_store(fedd_ctx* ctx, int slot);
+int fedd_matrix_scale(fedd_ctx* ctx, int slot, double alpha);
+int fedd_assemble_div(fedd_ctx* ctx, int64_t n_pressure_nodes, int slot_b, int slot_bt);
+int fedd_block_merge(fedd_ctx* ctx, int slot_a, int slot_bt, int slot_b, int slot_c);
+int fedd_matrix_sizes(fedd_ctx* ctx, int slot, int64_t* n_rows, int64_t* n_cols, int64_t* nnz);
+int fedd_matrix_get(fedd_ctx* ctx, int slot, int64_t* rowptr, int32_t* colind, double* val);
+
 /* read-back for Tpetra::CrsMatrix fill / parity (Matrix::getLocalRowView analog). col_gid maps
  * a local column index to its global dof id. */
 int fedd_csr_sizes(fedd_ctx* ctx, int64_t* n_rows, int64_t* n_cols, int64_t* nnz);

@@ -693,6 +693,30 @@ def assembly_div_and_divt(mv: Mesh, mp: Mesh):
     return B, BT
 
 
+def stokes_blocks(mv: Mesh, mp: Mesh, nu: float = 1.0):
+    """Stokes::assemble (feddlib/problems/specific/Stokes_def.hpp:47-138): A = nu * vector Laplacian,
+    B and B^T from assemblyDivAndDivT scaled by -1 (:79-89).  Returns (A, BT, B)."""
+    A = assembly_laplace_vecfield(mv) * nu
+    B, BT = assembly_div_and_divt(mv, mp)
+    return A, BT * (-1.0), B * (-1.0)
+
+
+def block_merge(A, BT, B, C=None) -> sp.csr_matrix:
+    """BlockMatrix::merge + BlockMap::merge (BlockMatrix_def.hpp:119-148,212-287; BlockMap_def.hpp:55-80):
+    monolithic [A B^T; B C], ids of block 1 shifted by (maxAllGlobalIndex + 1) of block 0; every stored
+    entry (also structural zeros) is re-inserted."""
+    def coo(Mx, ro, co):
+        Mx = Mx.tocoo()
+        return Mx.row + ro, Mx.col + co, Mx.data
+    n0, n1 = A.shape[0], B.shape[0]
+    parts = [coo(A, 0, 0), coo(BT, 0, n0), coo(B, n0, 0)]
+    if C is not None:
+        parts.append(coo(C, n0, n0))
+    r = np.concatenate([p[0] for p in parts]); c = np.concatenate([p[1] for p in parts])
+    v = np.concatenate([p[2] for p in parts])
+    return fill_complete(r, c, v, n0 + n1)
+
+
 # literal loop nests for small cases ----------------------------------------------------
 def assembly_laplace_loops(m: Mesh) -> sp.csr_matrix:
     """Line-by-line restatement of FE::assemblyLaplace's loop nest (FE_def.hpp:637-662) for small

@@ -1,0 +1,135 @@
+"""cfg 4 pieces on the GPU: P2 elements, mixed P2/P1 block assembly (FE::assemblyDivAndDivT,
+FE_def.hpp:1932-2057), Stokes::assemble's scaling (Stokes_def.hpp:79-89), BlockMatrix::merge
+(BlockMatrix_def.hpp:119-148), all against the oracle on the reference's DFG cylinder mesh; and a
+small Stokes solve against a direct solve."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import fedd_oracle as fo
+from test_gpu_parity import assert_matrix_close, csr_global, oracle_mesh
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx(fedd_lib):
+    c = fedd_lib.Context(device=0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def cylinder(fedd_lib):
+    m1 = fedd_lib.read_mesh(os.path.join(GOLD, "DFG3DCylinder_1k.mesh"), 3)
+    m2 = fedd_lib.p2_of_p1(m1, volume_id=0)
+    return m1, m2
+
+
+def test_p2_scalar_forms(fedd_lib, ctx, cylinder):
+    m1, m2 = cylinder
+    om2 = oracle_mesh(m2)
+    ctx.mesh_set_dict(m2)
+    nnz = ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+    ctx.assemble(fedd_lib.FORM_LAPLACE)
+    K = fo.assembly_laplace(om2)
+    assert nnz == K.nnz
+    A, _ = csr_global(ctx, om2.n_global)
+    assert_matrix_close(A, K)
+    ctx.assemble(fedd_lib.FORM_MASS)
+    A, _ = csr_global(ctx, om2.n_global)
+    assert_matrix_close(A, fo.assembly_mass(om2))
+    ctx.assemble_rhs([1.0])
+    np.testing.assert_allclose(ctx.rhs_get(), fo.assembly_rhs(om2, [1.0]), rtol=0, atol=1e-10 * 1e-3)
+
+
+@pytest.mark.parametrize("which", ["cylinder_p2p1", "square_p2p1", "cube_p1p1"])
+def test_div_blocks_and_merge(fedd_lib, ctx, cylinder, which):
+    if which == "cylinder_p2p1":
+        m1, mv = cylinder
+    elif which == "square_p2p1":
+        m1 = fedd_lib.read_mesh(os.path.join(GOLD, "square.mesh"), 2)
+        mv = fedd_lib.p2_of_p1(m1, volume_id=10)
+    else:
+        m1 = fedd_lib.structured_mesh(3, 1, 3)
+        mv = m1
+    dim = m1["dim"]
+    omv, omp = oracle_mesh(mv), oracle_mesh(m1)
+    n_p = m1["xyz"].shape[0]
+    nu = 0.7
+    ctx.mesh_set_dict(mv)
+    ctx.pattern_build(dim, fedd_lib.BLOCK_DIAG)
+    ctx.assemble(fedd_lib.FORM_LAPLACE_VEC)
+    ctx.matrix_scale(-1, nu)
+    ctx.matrix_store(0)
+    ctx.assemble_div(n_p, 1, 2)
+    Ao, BTo, Bo = fo.stokes_blocks(omv, omp, nu)
+    B = ctx.matrix_get(1)
+    BT = ctx.matrix_get(2)
+    assert_matrix_close(B, -Bo)          # unscaled on the device so far
+    assert_matrix_close(BT, -BTo)
+    assert abs(B - BT.T).max() < 1e-12 * abs(B).max()
+    ctx.matrix_scale(1, -1.0)
+    ctx.matrix_scale(2, -1.0)
+    assert_matrix_close(ctx.matrix_get(0), Ao)
+    ctx.block_merge(0, 2, 1, -1)
+    Mo = fo.block_merge(Ao, BTo, Bo)
+    rowptr, col, val, gid = ctx.csr_get()
+    n = rowptr.shape[0] - 1
+    assert n == Mo.shape[0]
+    Mg = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+    assert_matrix_close(Mg, Mo)
+    # merged global ids: velocity dim*g+d, pressure shifted by dim*(max velocity node id + 1)
+    nv = mv["xyz"].shape[0]
+    np.testing.assert_array_equal(gid[:dim * nv], np.arange(dim * nv))
+    np.testing.assert_array_equal(gid[dim * nv:], dim * nv + np.arange(n_p))
+    x = np.random.default_rng(1).standard_normal(n)
+    np.testing.assert_allclose(ctx.spmv(x), Mo @ x, rtol=0, atol=1e-10 * np.abs(Mo @ x).max())
+
+
+def test_small_stokes_solve(fedd_lib, ctx):
+    """Channel flow on a 4 x 4-cell square, P2/P1 Taylor-Hood, merged saddle-point system;
+    unpreconditioned full GMRES against a direct solve."""
+    m1 = fedd_lib.structured_mesh(2, 1, 4)
+    mv = fedd_lib.p2_of_p1(m1, volume_id=0)
+    dim = 2
+    omv, omp = oracle_mesh(mv), oracle_mesh(m1)
+    n_p, nv = m1["xyz"].shape[0], mv["xyz"].shape[0]
+    ctx.mesh_set_dict(mv)
+    ctx.pattern_build(dim, fedd_lib.BLOCK_DIAG)
+    ctx.assemble(fedd_lib.FORM_LAPLACE_VEC)
+    ctx.matrix_store(0)
+    ctx.assemble_div(n_p, 1, 2)
+    ctx.matrix_scale(1, -1.0)
+    ctx.matrix_scale(2, -1.0)
+    ctx.block_merge(0, 2, 1, -1)
+    X = mv["xyz"]
+    # channel: parabolic inflow on x = 0, no-slip walls y = 0, 1, natural outflow on x = 1
+    # (well posed without pinning the pressure; cond ~ 2e4)
+    inflow = X[:, 0] < 1e-12
+    wall = (X[:, 1] < 1e-12) | (X[:, 1] > 1 - 1e-12)
+    rows, vals = [], []
+    for node in np.nonzero(inflow | wall)[0]:
+        for d in range(dim):
+            rows.append(dim * node + d)
+            y = X[node, 1]
+            vals.append(4.0 * y * (1.0 - y) if (inflow[node] and not wall[node] and d == 0) else 0.0)
+    rows = np.array(rows); vals = np.array(vals)
+    n = dim * nv + n_p
+    ctx.rhs_set(np.zeros(n))
+    ctx.dirichlet_rows(rows, vals)
+    Ao, BTo, Bo = fo.stokes_blocks(omv, omp, 1.0)
+    Mo = fo.block_merge(Ao, BTo, Bo)
+    is_dir = np.zeros(n, dtype=bool); is_dir[rows] = True
+    g = np.zeros(n); g[rows] = vals
+    M_bc, rhs_bc = fo.set_dirichlet(Mo, np.zeros(n), is_dir, g)
+    rowptr, col, val, gid = ctx.csr_get()
+    assert_matrix_close(sp.csr_matrix((val, col, rowptr), shape=(n, n)), M_bc)
+    np.testing.assert_allclose(ctx.rhs_get(), rhs_bc, atol=1e-15)
+    x, its, rel = ctx.gmres(None, rtol=1e-13, max_it=n, restart=n, use_prec=False)
+    xd = fo.direct_solve(M_bc, rhs_bc)
+    assert rel <= 1e-12
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
