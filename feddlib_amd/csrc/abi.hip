@@ -446,7 +446,6 @@ extern "C" int fedd_schwarz_setup(fedd_ctx* c, int overlap, int combine, int two
     FEDD_CHECK(overlap >= 0 && overlap <= 4, "fedd_schwarz_setup: overlap %d", overlap);
     FEDD_CHECK(combine >= 0 && combine <= 2, "fedd_schwarz_setup: combine mode %d", combine);
     FEDD_CHECK(two_level == 0, "fedd_schwarz_setup: the GDSW coarse level (coarse_kind %d) is not built yet", coarse_kind);
-    FEDD_CHECK(!c->merged, "fedd_schwarz_setup: Schwarz subdomains for merged block systems are not built yet");
     FEDD_HIP(hipSetDevice(c->device));
     c->sw_overlap = overlap;
     c->sw_combine = combine;

@@ -14,6 +14,7 @@
 // Apply = one workgroup per subdomain streaming its slab of A_i^-1 once from HBM (HBM-bound).
 #include "fedd_internal.hpp"
 #include <algorithm>
+#include <climits>
 #include <cmath>
 
 namespace fedd {
@@ -57,10 +58,13 @@ __global__ void k_minmax(const double* __restrict__ xyz, int32_t n, int dim, dou
         }
 }
 
-__global__ void k_bin_id(const double* __restrict__ xyz, int32_t n, BinGeom gm, int32_t* __restrict__ raw,
-                         int32_t* cnt) {
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// box of every owned DOF = box of the node that carries it (dof / dofs, or the dof -> node map of a
+// merged block system)
+__global__ void k_bin_id(const double* __restrict__ xyz, int32_t n, int dofs, const int32_t* __restrict__ dof_node,
+                         BinGeom gm, int32_t* __restrict__ raw, int32_t* cnt) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int32_t i = dof_node ? dof_node[r] : r / dofs;
     int32_t b = 0, mul = 1;
     for (int d = 0; d < gm.dim; ++d) {
         int ix = (int)floor((xyz[(int64_t)i * gm.dim + d] - gm.lo[d]) / gm.w[d]);
@@ -68,7 +72,7 @@ __global__ void k_bin_id(const double* __restrict__ xyz, int32_t n, BinGeom gm, 
         b += mul * ix;
         mul *= gm.g[d];
     }
-    raw[i] = b;
+    raw[r] = b;
     atomicAdd(&cnt[b], 1);
 }
 
@@ -120,10 +124,11 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
     __shared__ int32_t lst[HS];
     __shared__ int32_t s_cnt, s_prev;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int32_t nb = bin_ptr[b], nn = bin_ptr[b + 1] - nb;
-    const int n_own = nn * dofs;
+    (void)dofs;
+    const int32_t nb = bin_ptr[b];
+    const int n_own = bin_ptr[b + 1] - nb;   // the box lists dofs
     int32_t* out = sub_dofs + (int64_t)b * NMAX;
-    for (int k = tid; k < n_own && k < NMAX; k += 256) out[k] = bin_nodes[nb + k / dofs] * dofs + k % dofs;
+    for (int k = tid; k < n_own && k < NMAX; k += 256) out[k] = bin_nodes[nb + k];
     for (int k = tid; k < HS; k += 256) tab[k] = -1;
     if (tid == 0) {
         s_cnt = 0;
@@ -134,11 +139,11 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
         // sources: owned dofs (layer 0) or everything collected so far (later layers)
         const int nsrc = layer == 0 ? n_own : s_prev;
         for (int k = tid; k < nsrc; k += 256) {
-            const int32_t src = layer == 0 ? bin_nodes[nb + k / dofs] * dofs + k % dofs : lst[k];
+            const int32_t src = layer == 0 ? bin_nodes[nb + k] : lst[k];
             if (src >= n_rows) continue;
             for (int32_t p = rowptr[src]; p < rowptr[src + 1]; ++p) {
                 const int32_t col = colind[p];
-                if (col < n_rows && node_bin[col / dofs] == b) continue;
+                if (col < n_rows && node_bin[col] == b) continue;
                 uint32_t h = ((uint32_t)col * 2654435761u) % HS;
                 for (int probe = 0; probe < HS; ++probe) {
                     const int32_t old = atomicCAS(&tab[h], -1, col);
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
                                                        const double* __restrict__ val, int32_t n_rows,
                                                        int restricted, const int64_t* __restrict__ inv_ptr,
                                                        double* __restrict__ inv, int32_t* __restrict__ bad,
-                                                       int n_lo, int n_hi) {
+                                                       int n_lo, int n_hi, int32_t p_off) {
     constexpr int NP = 16 * T;
     __shared__ int32_t sdof[NP];
     __shared__ double stage[16][NP + 1];
@@ -256,13 +261,21 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
         __syncthreads();
     }
     // ---- elimination ----
+    // Pivot order: for a merged saddle-point system (dofs >= p_off are pressures, zero diagonal)
+    // all velocity pivots first, then the pressures (their Schur complement is definite), which is
+    // safe without row exchanges; storage order is untouched (any symmetric pivot order gives the
+    // same inverse).  Plain systems: one pass.
     bool singular = false;
+    int step = 0;
+    const int npass = p_off == INT32_MAX ? 1 : 2;
+    for (int pass = 0; pass < npass; ++pass) {
 #pragma unroll
     for (int kb = 0; kb < T; ++kb) {
         for (int kc = 0; kc < 16; ++kc) {
             const int k = 16 * kb + kc;
             if (k >= n) break;
-            const int buf = k & 1;
+            if (npass == 2 && (sdof[k] >= p_off) != (pass == 1)) continue;
+            const int buf = (step++) & 1;
             if (tx == kc) {
 #pragma unroll
                 for (int a = 0; a < T; ++a) colbuf[buf][ty + 16 * a] = A[a][kb];
@@ -296,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
                 for (int bb = 0; bb < T; ++bb) A[a][bb] = fma(-cc[a], rr[bb], A[a][bb]);
         }
     }
+    }
     if (singular && tid == 0) bad[0] = 1;
     // ---- needed rows of the inverse -> column-major slab [c][rp] ----
     const int nrow = restricted ? no : n;
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(256) void k_invert(const int32_t* __restrict__ sub_
                                                 const int64_t* __restrict__ inv_ptr, double* __restrict__ inv,
                                                 double* __restrict__ work, int64_t work_stride, int lds_nmax,
                                                 int32_t* __restrict__ bad, int first_bin, int only_large,
-                                                int n_skip) {
+                                                int n_skip, int32_t p_off) {
     extern __shared__ double sm[];
     __shared__ int32_t sdof[NMAX];
     const int b = first_bin + blockIdx.x, tid = threadIdx.x;
@@ -363,7 +377,10 @@ __global__ __launch_bounds__(256) void k_invert(const int32_t* __restrict__ sub_
     }
     __syncthreads();
     const int tx = tid & 63, ty = tid >> 6;
+    const int npass = p_off == INT32_MAX ? 1 : 2;  // velocities first, then pressures (see k_invert_reg)
+    for (int pass = 0; pass < npass; ++pass)
     for (int k = 0; k < n; ++k) {
+        if (npass == 2 && (sdof[k] >= p_off) != (pass == 1)) continue;
         const double piv = A[k * ld + k];
         if (tid == 0 && !(fabs(piv) > 1e-300)) bad[0] = 1;
         const double pinv = 1.0 / piv;
@@ -494,21 +511,22 @@ int schwarz_setup(fedd_ctx* c) {
         nraw *= g;
     }
     FEDD_CHECK(nraw < ((int64_t)1 << 30), "schwarz setup: %lld boxes", (long long)nraw);
-    // ---- nodes -> boxes, drop empty boxes, counting sort ----
-    FEDD_TRY(c->d_itmp0.ensure((size_t)n_own));        // raw bin of each node
+    // ---- dofs -> boxes (box of the carrying node), drop empty boxes, counting sort ----
+    FEDD_TRY(c->d_itmp0.ensure((size_t)n_rows));       // raw box of each dof
     FEDD_TRY(c->d_itmp1.ensure((size_t)nraw + 1));     // raw counts
     FEDD_TRY(c->d_itmp2.ensure((size_t)nraw + 1));     // flags -> compact ids
     FEDD_HIP(hipMemsetAsync(c->d_itmp1.p, 0, ((size_t)nraw + 1) * sizeof(int32_t), c->stream));
-    const dim3 gn((n_own + 255) / 256), gb((unsigned)((nraw + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(k_bin_id, gn, blk, 0, c->stream, (const double*)c->d_xyz.p, n_own, gm, c->d_itmp0.p, c->d_itmp1.p);
+    const dim3 gn((n_rows + 255) / 256), gb((unsigned)((nraw + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(k_bin_id, gn, blk, 0, c->stream, (const double*)c->d_xyz.p, n_rows, dofs,
+                       (const int32_t*)(c->merged ? c->d_dof_node.p : nullptr), gm, c->d_itmp0.p, c->d_itmp1.p);
     hipLaunchKernelGGL(k_flag_nonempty, gb, blk, 0, c->stream, (const int32_t*)c->d_itmp1.p, (int32_t)nraw, c->d_itmp2.p);
     int64_t nsub = 0;
     FEDD_TRY(exclusive_scan_i32(c, c->d_itmp2.p, c->d_itmp2.p, nraw, &nsub));
     FEDD_CHECK(nsub > 0, "schwarz setup: no subdomain");
     c->sw_nsub = nsub;
     FEDD_TRY(c->d_bin_ptr.ensure((size_t)nsub + 1));
-    FEDD_TRY(c->d_bin_nodes.ensure((size_t)n_own));
-    FEDD_TRY(c->d_node_bin.ensure((size_t)n_own));
+    FEDD_TRY(c->d_bin_nodes.ensure((size_t)n_rows));   // dofs grouped by box
+    FEDD_TRY(c->d_node_bin.ensure((size_t)n_rows));    // compact box id of each dof
     FEDD_TRY(c->d_sub_n.ensure((size_t)nsub));
     FEDD_TRY(c->d_sub_nown.ensure((size_t)nsub));
     FEDD_TRY(c->d_sub_dofs.ensure((size_t)nsub * NMAX));
@@ -517,7 +535,7 @@ int schwarz_setup(fedd_ctx* c) {
     FEDD_TRY(exclusive_scan_i32(c, c->d_bin_ptr.p, c->d_bin_ptr.p, nsub, nullptr));
     // cursor = copy of bin_ptr (reuse the raw-count buffer)
     FEDD_HIP(hipMemcpyAsync(c->d_itmp1.p, c->d_bin_ptr.p, (size_t)nsub * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
-    hipLaunchKernelGGL(k_fill_bins, gn, blk, 0, c->stream, (const int32_t*)c->d_itmp0.p, (const int32_t*)c->d_itmp2.p, n_own,
+    hipLaunchKernelGGL(k_fill_bins, gn, blk, 0, c->stream, (const int32_t*)c->d_itmp0.p, (const int32_t*)c->d_itmp2.p, n_rows,
                        c->d_itmp1.p, c->d_node_bin.p, c->d_bin_nodes.p);
     hipLaunchKernelGGL(k_sort_bins, dim3((unsigned)((nsub + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_bin_ptr.p,
                        (int32_t)nsub, c->d_bin_nodes.p);
@@ -545,6 +563,8 @@ int schwarz_setup(fedd_ctx* c) {
     FEDD_TRY(c->d_flags.ensure(16));
     int32_t* d_bad = c->d_flags.p + 1;
     FEDD_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), c->stream));
+    // merged block systems: dofs >= p_off are pressures and are pivoted after the velocities
+    const int32_t p_off = c->merged ? (int32_t)c->merged_nA : INT32_MAX;
     // size classes of the register-tiled kernel (n <= 16 T); anything larger falls back below
     {
         const dim3 grid((unsigned)nsub);
@@ -554,7 +574,7 @@ int schwarz_setup(fedd_ctx* c) {
                            (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,                   \
                            (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p,                       \
                            (const double*)c->d_val.p, n_rows, restricted, (const int64_t*)c->d_inv_ptr.p,      \
-                           c->d_inv.p, d_bad, (LO), (HI))
+                           c->d_inv.p, d_bad, (LO), (HI), p_off)
         INV_REG(2, 0, 32);
         INV_REG(4, 32, 64);
         INV_REG(6, 64, 96);
@@ -572,7 +592,7 @@ int schwarz_setup(fedd_ctx* c) {
                            (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const int32_t*)c->d_rowptr.p,
                            (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, n_rows, restricted,
                            (const int64_t*)c->d_inv_ptr.p, c->d_inv.p, (double*)nullptr, (int64_t)0, lds_nmax, d_bad, 0, 0,
-                           n_skip);
+                           n_skip, p_off);
         if (max_n > lds_nmax) {
             // too large for LDS: same algorithm on a global (L2-resident) workspace, in chunks of
             // 1024 workgroups so that the workspace stays bounded
@@ -585,7 +605,7 @@ int schwarz_setup(fedd_ctx* c) {
                                    (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
                                    (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p,
                                    (const double*)c->d_val.p, n_rows, restricted, (const int64_t*)c->d_inv_ptr.p,
-                                   c->d_inv.p, c->d_w.p, stride, lds_nmax, d_bad, (int)first, 1, n_skip);
+                                   c->d_inv.p, c->d_w.p, stride, lds_nmax, d_bad, (int)first, 1, n_skip, p_off);
             }
         }
     }
