@@ -14,8 +14,11 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfedd_hip.so")
 FORM_LAPLACE, FORM_LAPLACE_VEC, FORM_MASS, FORM_MASS_VEC, FORM_LINELAS = range(5)
 BLOCK_SCALAR, BLOCK_DIAG, BLOCK_FULL = range(3)
 COMBINE_RESTRICTED, COMBINE_AVERAGING, COMBINE_FULL = range(3)
-(T_SYMBOLIC, T_ASSEMBLE, T_RHS, T_DIRICHLET, T_SPMV, T_SCHWARZ_SETUP, T_SCHWARZ_APPLY, T_ORTHO) = range(8)
-TIMER_NAMES = ["symbolic", "assemble", "rhs", "dirichlet", "spmv", "schwarz_setup", "schwarz_apply", "ortho"]
+(T_SYMBOLIC, T_ASSEMBLE, T_RHS, T_DIRICHLET, T_SPMV, T_SCHWARZ_SETUP, T_SCHWARZ_APPLY, T_ORTHO, T_COARSE_SETUP,
+ T_COARSE_APPLY) = range(10)
+TIMER_NAMES = ["symbolic", "assemble", "rhs", "dirichlet", "spmv", "schwarz_setup", "schwarz_apply", "ortho",
+               "coarse_setup", "coarse_apply"]
+COARSE_Q1 = 1
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
@@ -61,6 +64,9 @@ SIGNATURES = {
     "fedd_spmv_device": [C.c_void_p, C.c_int],
     "fedd_schwarz_setup": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],
     "fedd_schwarz_set_target": [C.c_void_p, C.c_int, C.c_double],
+    "fedd_schwarz_set_coarse": [C.c_void_p, C.c_double],
+    "fedd_schwarz_coarse_sizes": [C.c_void_p, _i32p, _i64p],
+    "fedd_schwarz_coarse_get": [C.c_void_p, _f64p],
     "fedd_schwarz_apply": [C.c_void_p, _f64p, _f64p],
     "fedd_schwarz_apply_device": [C.c_void_p, C.c_int],
     "fedd_schwarz_info": [C.c_void_p, _i64p, _i64p, _i64p],
@@ -335,6 +341,18 @@ class Context:
 
     def schwarz_setup(self, overlap=1, combine=COMBINE_RESTRICTED, two_level=0, coarse_kind=0):
         _chk(self._L.fedd_schwarz_setup(self._h, overlap, combine, two_level, coarse_kind))
+
+    def schwarz_set_coarse(self, cells_target):
+        _chk(self._L.fedd_schwarz_set_coarse(self._h, float(cells_target)))
+
+    def schwarz_coarse(self):
+        """(cells per direction, K0^-1) of the coarse level"""
+        g = np.zeros(3, dtype=np.int32)
+        n0 = C.c_int64()
+        _chk(self._L.fedd_schwarz_coarse_sizes(self._h, _p(g, _i32p), C.byref(n0)))
+        K = np.empty((n0.value, n0.value), dtype=np.float64)
+        _chk(self._L.fedd_schwarz_coarse_get(self._h, _p(K, _f64p)))
+        return g, K
 
     def schwarz_info(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()

@@ -122,6 +122,12 @@ extern "C" void fedd_ctx_destroy(fedd_ctx* c) {
         for (auto* b : db) b->release();
         c->d_inv_ptr.release();
         c->d_dof_node.release();
+        fedd::DevBuf<int32_t>* cib[] = {&c->d_co_key[0], &c->d_co_key[1], &c->d_co_val[0], &c->d_co_val[1],
+                                        &c->d_co_cell_ptr};
+        for (auto* b : cib) b->release();
+        fedd::DevBuf<double>* cdb[] = {&c->d_co_mask, &c->d_co_cellK, &c->d_co_K, &c->d_co_panel,
+                                       &c->d_co_part, &c->d_co_r0, &c->d_co_z0};
+        for (auto* b : cdb) b->release();
         for (auto& m : c->aux) {
             m.rowptr.release();
             m.colind.release();
@@ -156,7 +162,7 @@ extern "C" int fedd_mesh_set(fedd_ctx* c, int dim, int nen, int64_t n_elem, cons
     c->nen = nen;
     c->n_elem = n_elem;
     c->n_own = n_uni;
-    c->have_adj = c->have_pattern = c->have_schwarz = false;
+    c->have_adj = c->have_pattern = c->have_schwarz = c->have_coarse = false;
     c->halo = fedd::HaloPlan();
 
     // column-local numbering: owned nodes in unique-map order, then ghosts sorted by global id
@@ -445,11 +451,40 @@ extern "C" int fedd_schwarz_setup(fedd_ctx* c, int overlap, int combine, int two
     FEDD_CHECK(c->have_pattern, "fedd_schwarz_setup: assemble the matrix first");
     FEDD_CHECK(overlap >= 0 && overlap <= 4, "fedd_schwarz_setup: overlap %d", overlap);
     FEDD_CHECK(combine >= 0 && combine <= 2, "fedd_schwarz_setup: combine mode %d", combine);
-    FEDD_CHECK(two_level == 0, "fedd_schwarz_setup: the GDSW coarse level (coarse_kind %d) is not built yet", coarse_kind);
+    FEDD_CHECK(two_level == 0 || coarse_kind == FEDD_COARSE_Q1,
+               "fedd_schwarz_setup: coarse_kind %d is not built (FEDD_COARSE_Q1 = %d is)", coarse_kind, FEDD_COARSE_Q1);
+    FEDD_CHECK(two_level == 0 || !c->merged,
+               "fedd_schwarz_setup: the coarse level takes node-interleaved systems, not a merged block system");
     FEDD_HIP(hipSetDevice(c->device));
     c->sw_overlap = overlap;
     c->sw_combine = combine;
+    c->sw_two_level = two_level ? 1 : 0;
     return schwarz_setup(c);
+}
+
+extern "C" int fedd_schwarz_set_coarse(fedd_ctx* c, double cells_target) {
+    FEDD_CHECK(c, "null context");
+    FEDD_CHECK(cells_target >= 0 && cells_target < 1e9, "fedd_schwarz_set_coarse: cells_target %g", cells_target);
+    c->co_cells_target = cells_target;
+    return 0;
+}
+
+extern "C" int fedd_schwarz_coarse_sizes(fedd_ctx* c, int32_t cells[3], int64_t* n0) {
+    FEDD_CHECK(c && c->have_coarse, "fedd_schwarz_coarse_sizes: no coarse level");
+    if (cells)
+        for (int d = 0; d < 3; ++d) cells[d] = c->co_geom.g[d];
+    if (n0) *n0 = c->co_n0;
+    return 0;
+}
+
+extern "C" int fedd_schwarz_coarse_get(fedd_ctx* c, double* k0_inverse) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_coarse && k0_inverse, "fedd_schwarz_coarse_get: no coarse level / null pointer");
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_HIP(hipMemcpy2DAsync(k0_inverse, (size_t)c->co_n0 * sizeof(double), c->d_co_K.p, (size_t)c->co_ld * sizeof(double),
+                              (size_t)c->co_n0 * sizeof(double), (size_t)c->co_n0, hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 extern "C" int fedd_schwarz_info(fedd_ctx* c, int64_t* n_sub, int64_t* max_size, int64_t* inverse_bytes) {

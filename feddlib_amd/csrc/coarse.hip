@@ -1,0 +1,748 @@
+// Coarse level of the two-level Schwarz operator:  z += Phi K0^-1 Phi^T r.
+//
+// Stands in for the coarse operator the reference gets from FROSch under "TwoLevel" = true
+//   feddlib/problems/tests/laplace/parametersPrec.xml:13, 62-122 (GDSWCoarseOperator, IPOUHarmonic)
+//   feddlib/problems/Solver/Preconditioner_def.hpp:243-463 (where the list is handed to Thyra).
+// GDSW builds its space from the interface of a few large subdomains (one per rank); this library
+// runs thousands of small subdomains per GPU, so the coarse space is geometric instead (normative
+// definition, DESIGN.md "two-level"; the tests check it against an independent CPU restatement):
+//   Phi   = multilinear hat functions of a regular lattice of (g_d + 1) points per direction over
+//           the global bounding box, evaluated at the node that carries the dof, one copy per dof
+//           component; rows of Dirichlet dofs are zero,
+//   K0    = Phi^T A Phi (dense, lattice dofs without support get a unit diagonal, the others a
+//           relative diagonal shift of 1e-12), inverted explicitly and replicated on every rank.
+// Setup: nodes are grouped by lattice cell with a stable radix split (deterministic order), one
+// wave per cell forms the cell's 2^dim x 4^dim Galerkin block, a gather kernel sums the blocks of
+// the <= 2^dim cells around each lattice point in a fixed order, and K0 is inverted in place by a
+// blocked Gauss-Jordan sweep whose rank-64 updates run on the f64 matrix cores
+// (v_mfma_f64_16x16x4_f64) -- the one genuinely dense contraction of the solver.
+// Apply: cell-wise restriction (fixed summation order), dense K0^-1 r0, prolongation.
+#include "fedd_internal.hpp"
+#include <algorithm>
+#include <cmath>
+
+namespace fedd {
+namespace {
+
+constexpr int NB = 64;  // block size of the dense inversion
+
+struct Loc {
+    int i0[3];
+    double f[3];
+};
+
+template <int DIM>
+__device__ __forceinline__ Loc locate(const CoarseGeom& cg, const double* __restrict__ xyz, int32_t node) {
+    Loc o;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        o.i0[d] = 0;
+        o.f[d] = 0.0;
+    }
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        const double t = (xyz[(int64_t)node * DIM + d] - cg.lo[d]) / cg.L[d] * (double)cg.g[d];
+        int i = (int)floor(t);
+        i = min(cg.g[d] - 1, max(0, i));
+        o.i0[d] = i;
+        o.f[d] = t - (double)i;
+    }
+    return o;
+}
+
+template <int DIM>
+__device__ __forceinline__ double corner_weight(const Loc& o, int a) {
+    double w = 1.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) w *= ((a >> d) & 1) ? o.f[d] : 1.0 - o.f[d];
+    return w;
+}
+
+template <int DIM>
+__device__ __forceinline__ int32_t lattice_node(const CoarseGeom& cg, const int i0[3], int a) {
+    int32_t id = 0, mul = 1;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        id += mul * (i0[d] + ((a >> d) & 1));
+        mul *= cg.np[d];
+    }
+    return id;
+}
+
+template <int DIM>
+__device__ __forceinline__ int32_t cell_of(const CoarseGeom& cg, const int i0[3]) {
+    int32_t id = 0, mul = 1;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        id += mul * i0[d];
+        mul *= cg.g[d];
+    }
+    return id;
+}
+
+// ---- nodes -> lattice cells ----
+template <int DIM>
+__global__ void k_cell_key(CoarseGeom cg, const double* __restrict__ xyz, int32_t n, int32_t* __restrict__ key,
+                           int32_t* __restrict__ val, int32_t* cnt) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Loc o = locate<DIM>(cg, xyz, i);
+    const int32_t c = cell_of<DIM>(cg, o.i0);
+    key[i] = c;
+    val[i] = i;
+    atomicAdd(&cnt[c], 1);
+}
+
+// one stable radix-split pass on bit `bit`: zeros first, both halves keep their order
+__global__ void k_split_flags(const int32_t* __restrict__ key, int32_t n, int bit, int32_t* __restrict__ flag) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = ((key[i] >> bit) & 1) ? 0 : 1;
+}
+
+__global__ void k_split_scatter(const int32_t* __restrict__ key, const int32_t* __restrict__ val,
+                                const int32_t* __restrict__ pos, int32_t n, int bit, int32_t* __restrict__ key_out,
+                                int32_t* __restrict__ val_out) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t zeros = pos[n - 1] + (((key[n - 1] >> bit) & 1) ? 0 : 1);
+    const int32_t k = key[i];
+    const int32_t dst = ((k >> bit) & 1) ? zeros + (i - pos[i]) : pos[i];
+    key_out[dst] = k;
+    val_out[dst] = val[i];
+}
+
+__global__ void k_mask(const int32_t* __restrict__ isdir, int64_t n, double* __restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mask[i] = isdir[i] ? 0.0 : 1.0;
+}
+
+// ---- per-cell Galerkin block ----
+// One wave per lattice cell.  For the nodes i of the cell (64 at a time, one per lane) and the
+// component pair (k, l): P[slot][lane] = sum_j A_(i,k),(j,l) * w_j(slot) over the 4^DIM lattice
+// points around the cell, then out[a][slot] += sum_lane w_i(a) * P[slot][lane] with lane = slot.
+// Every sum runs in a fixed order: the result does not depend on scheduling.
+template <int DIM>
+__global__ __launch_bounds__(64) void k_cell_galerkin(CoarseGeom cg, const int32_t* __restrict__ cell_ptr,
+                                                      const int32_t* __restrict__ cell_nodes,
+                                                      const double* __restrict__ xyz,
+                                                      const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ colind,
+                                                      const double* __restrict__ val,
+                                                      const double* __restrict__ mask, int dofs,
+                                                      double* __restrict__ cellK, int32_t* __restrict__ bad) {
+    constexpr int NC = 1 << DIM, NS = DIM == 3 ? 64 : 16;
+    __shared__ double P[NS][65];
+    __shared__ double W[NC][64];
+    const int cell = blockIdx.x, lane = threadIdx.x;
+    int cc[3] = {0, 0, 0};
+    {
+        int r = cell;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            cc[d] = r % cg.g[d];
+            r /= cg.g[d];
+        }
+    }
+    const int32_t nb = cell_ptr[cell], ne = cell_ptr[cell + 1];
+    for (int k = 0; k < dofs; ++k)
+        for (int l = 0; l < dofs; ++l) {
+            double acc[NC];
+#pragma unroll
+            for (int a = 0; a < NC; ++a) acc[a] = 0.0;
+            for (int32_t base = nb; base < ne; base += 64) {
+#pragma unroll 8
+                for (int s = 0; s < NS; ++s) P[s][lane] = 0.0;
+                const int32_t node = base + lane < ne ? cell_nodes[base + lane] : -1;
+                if (node >= 0) {
+                    const Loc oi = locate<DIM>(cg, xyz, node);
+                    const int32_t row = node * dofs + k;
+                    const double mrow = mask[row];
+#pragma unroll
+                    for (int a = 0; a < NC; ++a) W[a][lane] = corner_weight<DIM>(oi, a) * mrow;
+                    if (mrow != 0.0) {
+                        for (int32_t p = rowptr[row]; p < rowptr[row + 1]; ++p) {
+                            const int32_t col = colind[p];
+                            const int32_t jn = col / dofs;
+                            if (col - jn * dofs != l) continue;
+                            const double v = val[p] * mask[col];
+                            if (v == 0.0) continue;
+                            const Loc oj = locate<DIM>(cg, xyz, jn);
+                            int rel[3] = {0, 0, 0};
+                            bool ok = true;
+#pragma unroll
+                            for (int d = 0; d < DIM; ++d) {
+                                rel[d] = oj.i0[d] - cc[d] + 1;
+                                ok = ok && rel[d] >= 0 && rel[d] <= 2;
+                            }
+                            if (!ok) {
+                                bad[0] = 1;  // a matrix entry couples cells that are not neighbours
+                                continue;
+                            }
+#pragma unroll
+                            for (int b = 0; b < NC; ++b) {
+                                int slot = 0;
+#pragma unroll
+                                for (int d = DIM - 1; d >= 0; --d) slot = slot * 4 + rel[d] + ((b >> d) & 1);
+                                P[slot][lane] += v * corner_weight<DIM>(oj, b);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int a = 0; a < NC; ++a) W[a][lane] = 0.0;
+                }
+                __syncthreads();
+                if (lane < NS) {
+                    for (int t = 0; t < 64; ++t) {
+                        const double pv = P[lane][t];
+#pragma unroll
+                        for (int a = 0; a < NC; ++a) acc[a] = fma(W[a][t], pv, acc[a]);
+                    }
+                }
+                __syncthreads();
+            }
+            if (lane < NS) {
+#pragma unroll
+                for (int a = 0; a < NC; ++a)
+                    cellK[((((int64_t)cell * dofs + k) * dofs + l) * NC + a) * NS + lane] = acc[a];
+            }
+        }
+}
+
+// K0[(I,k)][(J,l)] = sum over the cells around lattice point I of their block entry for J
+template <int DIM>
+__global__ void k_coarse_gather(CoarseGeom cg, int dofs, int64_t n_lat, const double* __restrict__ cellK,
+                                double* __restrict__ K, int64_t ld) {
+    constexpr int NC = 1 << DIM, NS = DIM == 3 ? 64 : 16, NW = DIM == 3 ? 125 : 25;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_lat * NW) return;
+    const int64_t I = t / NW;
+    int w = (int)(t - I * NW);
+    int iI[3] = {0, 0, 0}, iJ[3] = {0, 0, 0};
+    {
+        int64_t r = I;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            iI[d] = (int)(r % cg.np[d]);
+            r /= cg.np[d];
+            iJ[d] = iI[d] + (w % 5) - 2;
+            w /= 5;
+            if (iJ[d] < 0 || iJ[d] >= cg.np[d]) return;
+        }
+    }
+    int64_t J = 0;
+    {
+        int64_t mul = 1;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            J += mul * iJ[d];
+            mul *= cg.np[d];
+        }
+    }
+    for (int k = 0; k < dofs; ++k)
+        for (int l = 0; l < dofs; ++l) {
+            double sum = 0.0;
+            for (int a = 0; a < NC; ++a) {
+                int cell = 0, mul = 1, slot = 0, smul = 1;
+                bool ok = true;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) {
+                    const int cd = iI[d] - ((a >> d) & 1);
+                    const int sd = iJ[d] - cd + 1;
+                    ok = ok && cd >= 0 && cd < cg.g[d] && sd >= 0 && sd <= 3;
+                    cell += mul * cd;
+                    mul *= cg.g[d];
+                    slot += smul * sd;
+                    smul *= 4;
+                }
+                if (ok) sum += cellK[((((int64_t)cell * dofs + k) * dofs + l) * NC + a) * NS + slot];
+            }
+            K[(I * dofs + k) * ld + J * dofs + l] = sum;
+        }
+}
+
+// rows without any entry (lattice dofs without support) and the padding rows get a unit diagonal,
+// the others the relative diagonal shift; one wave per row
+__global__ __launch_bounds__(256) void k_fix_diag(double* __restrict__ K, int64_t ld, int64_t n0) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= ld) return;
+    if (row >= n0) {
+        if (lane == 0) K[row * ld + row] = 1.0;
+        return;
+    }
+    bool any = false;
+    for (int64_t j = lane; j < n0; j += 64) any = any || K[row * ld + j] != 0.0;
+    const bool row_any = __ballot(any) != 0ull;
+    if (lane == 0) K[row * ld + row] = row_any ? K[row * ld + row] * (1.0 + 1e-12) : 1.0;
+}
+
+// ---- blocked Gauss-Jordan inversion (no pivoting: K0 is symmetric positive definite) ----
+// step kb with pivot block D = K[kb,kb]:  K[kb,kb] <- D^-1, K[kb,j] <- D^-1 K[kb,j],
+// K[i,kb] <- -K[i,kb] D^-1, K[i,j] <- K[i,j] - K[i,kb] D^-1 K[kb,j]  (i, j != kb).
+
+// D^-1 of the 64 x 64 pivot block, register tiled (the scheme of schwarz.hip k_invert_reg, T = 4)
+__global__ __launch_bounds__(256) void k_diag_inv(const double* __restrict__ K, int64_t ld, int kb,
+                                                  double* __restrict__ Dinv, int32_t* __restrict__ bad) {
+    constexpr int T = 4;
+    __shared__ double colbuf[2][NB], rowbuf[2][NB];
+    const int tid = threadIdx.x, ty = tid & 15, tx = tid >> 4;
+    const double* __restrict__ D = K + ((int64_t)kb * NB) * ld + (int64_t)kb * NB;
+    double A[T][T];
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int b = 0; b < T; ++b) A[a][b] = D[(int64_t)(ty + 16 * a) * ld + tx + 16 * b];
+    bool singular = false;
+#pragma unroll
+    for (int kq = 0; kq < T; ++kq) {
+#pragma unroll 1
+        for (int kc = 0; kc < 16; ++kc) {
+            const int k = 16 * kq + kc;
+            const int buf = k & 1;
+            if (tx == kc) {
+#pragma unroll
+                for (int a = 0; a < T; ++a) colbuf[buf][ty + 16 * a] = A[a][kq];
+            }
+            if (ty == kc) {
+#pragma unroll
+                for (int b = 0; b < T; ++b) rowbuf[buf][tx + 16 * b] = A[kq][b];
+            }
+            __syncthreads();
+            const double piv = rowbuf[buf][k];
+            singular = singular || !(piv > 1e-300);
+            const double pinv = 1.0 / piv;
+            double cc[T], rr[T];
+#pragma unroll
+            for (int a = 0; a < T; ++a) cc[a] = colbuf[buf][ty + 16 * a];
+#pragma unroll
+            for (int b = 0; b < T; ++b) rr[b] = rowbuf[buf][tx + 16 * b] * pinv;
+            if (ty == kc) {
+                cc[kq] = -1.0;
+#pragma unroll
+                for (int b = 0; b < T; ++b) A[kq][b] = 0.0;
+            }
+            if (tx == kc) {
+                rr[kq] = pinv;
+#pragma unroll
+                for (int a = 0; a < T; ++a) A[a][kq] = 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < T; ++a)
+#pragma unroll
+                for (int b = 0; b < T; ++b) A[a][b] = fma(-cc[a], rr[b], A[a][b]);
+        }
+    }
+    if (singular && tid == 0) bad[0] = 1;
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int b = 0; b < T; ++b) Dinv[(ty + 16 * a) * NB + tx + 16 * b] = A[a][b];
+}
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// 64 x 64 x 64 product on the f64 matrix cores: the four waves of the workgroup each own a 32 x 32
+// quadrant (2 x 2 tiles of v_mfma_f64_16x16x4_f64).  A-fragment lane l = A[l & 15][k = l >> 4],
+// B-fragment B[k = l >> 4][l & 15], result register q of lane l = C[(l >> 4) + 4 q][l & 15].
+constexpr int LDA_S = 68, LDB_S = 80;  // LDS leading dimensions: the fragment reads are 2-way at worst
+
+__device__ __forceinline__ void mm64(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
+                                     int64_t ldb, double* As, double* Bs, double4_t acc[2][2]) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e >> 6, cidx = e & 63;
+        As[r * LDA_S + cidx] = A[(int64_t)r * lda + cidx];
+        Bs[r * LDB_S + cidx] = B[(int64_t)r * ldb + cidx];
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r0 = 32 * (wave >> 1), c0 = 32 * (wave & 1);
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int s = 0; s < NB / 4; ++s) {
+        const double a0 = As[(r0 + li) * LDA_S + 4 * s + lk];
+        const double a1 = As[(r0 + 16 + li) * LDA_S + 4 * s + lk];
+        const double b0 = Bs[(4 * s + lk) * LDB_S + c0 + li];
+        const double b1 = Bs[(4 * s + lk) * LDB_S + c0 + 16 + li];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+
+// element (row, col) of the workgroup's 64 x 64 tile held in acc[ti][tj] register q
+#define MM64_FOR_EACH(BODY)                                                     \
+    {                                                                           \
+        const int wave_ = threadIdx.x >> 6, lane_ = threadIdx.x & 63;           \
+        _Pragma("unroll") for (int ti = 0; ti < 2; ++ti)                        \
+        _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                         \
+            const int row = 32 * (wave_ >> 1) + 16 * ti + (lane_ >> 4) + 4 * q; \
+            const int col = 32 * (wave_ & 1) + 16 * tj + (lane_ & 15);          \
+            const double v = acc[ti][tj][q];                                    \
+            BODY                                                                \
+        }                                                                       \
+    }
+
+// column block bj: save the column panel tile C[bj] = K[bj, kb] and form R[bj] = Dinv K[kb, bj]
+__global__ __launch_bounds__(256) void k_panels(const double* __restrict__ K, int64_t ld, int kb,
+                                                const double* __restrict__ Dinv, double* __restrict__ R,
+                                                double* __restrict__ Cp) {
+    __shared__ double As[NB * LDA_S];
+    __shared__ double Bs[NB * LDB_S];
+    const int bj = blockIdx.x;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e >> 6, cidx = e & 63;
+        Cp[((int64_t)bj * NB + r) * NB + cidx] = K[((int64_t)bj * NB + r) * ld + (int64_t)kb * NB + cidx];
+    }
+    if (bj == kb) return;
+    double4_t acc[2][2];
+    mm64(Dinv, NB, K + ((int64_t)kb * NB) * ld + (int64_t)bj * NB, ld, As, Bs, acc);
+    MM64_FOR_EACH(R[(int64_t)row * ld + (int64_t)bj * NB + col] = v;)
+}
+
+__global__ __launch_bounds__(256) void k_update(double* __restrict__ K, int64_t ld, int kb,
+                                                const double* __restrict__ Dinv, const double* __restrict__ R,
+                                                const double* __restrict__ Cp) {
+    __shared__ double As[NB * LDA_S];
+    __shared__ double Bs[NB * LDB_S];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    double* __restrict__ tile = K + ((int64_t)bi * NB) * ld + (int64_t)bj * NB;
+    if (bi == kb) {
+        const double* __restrict__ src = bj == kb ? Dinv : R + (int64_t)bj * NB;
+        const int64_t lds = bj == kb ? NB : ld;
+        for (int e = threadIdx.x; e < NB * NB; e += 256) {
+            const int r = e >> 6, cidx = e & 63;
+            tile[(int64_t)r * ld + cidx] = src[(int64_t)r * lds + cidx];
+        }
+        return;
+    }
+    double4_t acc[2][2];
+    if (bj == kb) {
+        mm64(Cp + (int64_t)bi * NB * NB, NB, Dinv, NB, As, Bs, acc);
+        MM64_FOR_EACH(tile[(int64_t)row * ld + col] = -v;)
+    } else {
+        mm64(Cp + (int64_t)bi * NB * NB, NB, R + (int64_t)bj * NB, ld, As, Bs, acc);
+        MM64_FOR_EACH(tile[(int64_t)row * ld + col] -= v;)
+    }
+}
+
+// ---- apply ----
+template <int DIM, int DOFS>
+__global__ __launch_bounds__(256) void k_restrict_cells(CoarseGeom cg, const int32_t* __restrict__ cell_ptr,
+                                                        const int32_t* __restrict__ cell_nodes,
+                                                        const double* __restrict__ xyz,
+                                                        const double* __restrict__ mask,
+                                                        const double* __restrict__ r, double* __restrict__ part) {
+    constexpr int NC = 1 << DIM, NV = NC * DOFS;
+    __shared__ double red[4][NV];
+    const int cell = blockIdx.x, tid = threadIdx.x;
+    double acc[NC][DOFS];
+#pragma unroll
+    for (int a = 0; a < NC; ++a)
+#pragma unroll
+        for (int k = 0; k < DOFS; ++k) acc[a][k] = 0.0;
+    for (int32_t idx = cell_ptr[cell] + tid; idx < cell_ptr[cell + 1]; idx += 256) {
+        const int32_t node = cell_nodes[idx];
+        const Loc o = locate<DIM>(cg, xyz, node);
+        double rv[DOFS];
+#pragma unroll
+        for (int k = 0; k < DOFS; ++k) rv[k] = r[(int64_t)node * DOFS + k] * mask[(int64_t)node * DOFS + k];
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            const double w = corner_weight<DIM>(o, a);
+#pragma unroll
+            for (int k = 0; k < DOFS; ++k) acc[a][k] = fma(w, rv[k], acc[a][k]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NC; ++a)
+#pragma unroll
+        for (int k = 0; k < DOFS; ++k) {
+            double v = acc[a][k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((tid & 63) == 0) red[tid >> 6][a * DOFS + k] = v;
+        }
+    __syncthreads();
+    if (tid < NV) part[(int64_t)cell * NV + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+template <int DIM>
+__global__ void k_restrict_nodes(CoarseGeom cg, int dofs, int64_t n_lat, const double* __restrict__ part,
+                                 double* __restrict__ r0) {
+    constexpr int NC = 1 << DIM;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_lat * dofs) return;
+    const int64_t I = t / dofs;
+    const int k = (int)(t - I * dofs);
+    int iI[3] = {0, 0, 0};
+    {
+        int64_t r = I;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            iI[d] = (int)(r % cg.np[d]);
+            r /= cg.np[d];
+        }
+    }
+    double sum = 0.0;
+    for (int a = 0; a < NC; ++a) {
+        int cell = 0, mul = 1;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            const int cd = iI[d] - ((a >> d) & 1);
+            ok = ok && cd >= 0 && cd < cg.g[d];
+            cell += mul * cd;
+            mul *= cg.g[d];
+        }
+        if (ok) sum += part[((int64_t)cell * NC + a) * dofs + k];
+    }
+    r0[t] = sum;
+}
+
+// y = K x for the dense n0 x n0 matrix, one wave per row
+__global__ __launch_bounds__(256) void k_dense_mv(const double* __restrict__ K, int64_t ld, int64_t n0,
+                                                  const double* __restrict__ x, double* __restrict__ y) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n0) return;
+    const double* __restrict__ kr = K + row * ld;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t j = lane;
+    for (; j + 192 < n0; j += 256) {
+        s0 = fma(kr[j], x[j], s0);
+        s1 = fma(kr[j + 64], x[j + 64], s1);
+        s2 = fma(kr[j + 128], x[j + 128], s2);
+        s3 = fma(kr[j + 192], x[j + 192], s3);
+    }
+    for (; j < n0; j += 64) s0 = fma(kr[j], x[j], s0);
+    double v = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) y[row] = v;
+}
+
+template <int DIM>
+__global__ void k_prolong_add(CoarseGeom cg, int dofs, int64_t n_rows, const double* __restrict__ xyz,
+                              const double* __restrict__ mask, const double* __restrict__ z0,
+                              double* __restrict__ z) {
+    constexpr int NC = 1 << DIM;
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const double m = mask[row];
+    if (m == 0.0) return;
+    const int32_t node = (int32_t)(row / dofs);
+    const int k = (int)(row - (int64_t)node * dofs);
+    const Loc o = locate<DIM>(cg, xyz, node);
+    double sum = 0.0;
+#pragma unroll
+    for (int a = 0; a < NC; ++a)
+        sum = fma(corner_weight<DIM>(o, a), z0[(int64_t)lattice_node<DIM>(cg, o.i0, a) * dofs + k], sum);
+    z[row] += sum * m;
+}
+
+int dense_invert(fedd_ctx* c, double* K, int64_t ld, int32_t* d_bad) {
+    const int nblk = (int)(ld / NB);
+    FEDD_TRY(c->d_co_panel.ensure((size_t)NB * NB + 2 * (size_t)NB * ld));
+    double* Dinv = c->d_co_panel.p;
+    double* R = Dinv + NB * NB;
+    double* Cp = R + (size_t)NB * ld;
+    for (int kb = 0; kb < nblk; ++kb) {
+        hipLaunchKernelGGL(k_diag_inv, dim3(1), dim3(256), 0, c->stream, (const double*)K, ld, kb, Dinv, d_bad);
+        hipLaunchKernelGGL(k_panels, dim3(nblk), dim3(256), 0, c->stream, (const double*)K, ld, kb, (const double*)Dinv, R, Cp);
+        hipLaunchKernelGGL(k_update, dim3(nblk, nblk), dim3(256), 0, c->stream, K, ld, kb, (const double*)Dinv,
+                           (const double*)R, (const double*)Cp);
+    }
+    FEDD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+#define COARSE_DIM(KERNEL, ...)                      \
+    do {                                             \
+        if (dim == 3) { KERNEL(3, __VA_ARGS__); }    \
+        else { KERNEL(2, __VA_ARGS__); }             \
+    } while (0)
+
+int coarse_setup(fedd_ctx* c) {
+    ScopedTimer timer(c, FEDD_T_COARSE_SETUP);
+    const int dim = c->dim, dofs = c->dofs;
+    const int32_t n_own = (int32_t)c->n_own;
+    FEDD_CHECK(dim == 2 || dim == 3, "coarse setup: dim %d", dim);
+    FEDD_CHECK(dofs >= 1 && dofs <= MAX_DOFS, "coarse setup: %d dofs per node", dofs);
+    FEDD_CHECK(c->n_rows == (int64_t)dofs * c->n_own, "coarse setup: the system is not node-interleaved");
+    // ---- global bounding box and node count ----
+    double lo[3], hi[3];
+    FEDD_TRY(bounding_box(c, n_own, lo, hi));
+    double n_global = (double)n_own;
+    if (c->nranks > 1) {
+        // min / max over ranks through the sum transport: every rank fills its own slots
+        const int nr = c->nranks, len = nr * 7;
+        std::vector<double> h((size_t)len, 0.0);
+        for (int d = 0; d < 3; ++d) {
+            h[(size_t)c->rank * 7 + d] = lo[d];
+            h[(size_t)c->rank * 7 + 3 + d] = hi[d];
+        }
+        h[(size_t)c->rank * 7 + 6] = (double)n_own;
+        FEDD_TRY(c->d_co_r0.ensure(std::max<size_t>((size_t)len, c->d_co_r0.cap)));
+        FEDD_HIP(hipMemcpyAsync(c->d_co_r0.p, h.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, len));
+        FEDD_HIP(hipMemcpyAsync(h.data(), c->d_co_r0.p, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        n_global = 0.0;
+        for (int r = 0; r < nr; ++r) {
+            for (int d = 0; d < 3; ++d) {
+                lo[d] = std::min(lo[d], h[(size_t)r * 7 + d]);
+                hi[d] = std::max(hi[d], h[(size_t)r * 7 + 3 + d]);
+            }
+            n_global += h[(size_t)r * 7 + 6];
+        }
+    }
+    // ---- lattice: g_d = max(1, floor(L_d / H + 0.5)), H = (V / cells_target)^(1/dim) ----
+    double target = c->co_cells_target;
+    if (!(target > 0)) target = std::min(3375.0, std::max(1.0, std::floor(n_global / 500.0)));
+    CoarseGeom cg;
+    cg.dim = dim;
+    double V = 1.0;
+    for (int d = 0; d < dim; ++d) V *= (hi[d] - lo[d] > 0 ? hi[d] - lo[d] : 1.0);
+    const double H = std::pow(V / target, 1.0 / dim);
+    int64_t ncell = 1, nlat = 1;
+    for (int d = 0; d < 3; ++d) {
+        cg.g[d] = 1;
+        cg.np[d] = 1;
+        cg.lo[d] = 0.0;
+        cg.L[d] = 1.0;
+        if (d >= dim) continue;
+        const double Ld = hi[d] - lo[d];
+        cg.lo[d] = lo[d];
+        cg.L[d] = Ld > 0 ? Ld : 1.0;
+        int g = (int)std::floor(cg.L[d] / H + 0.5);
+        if (g < 1 || !(Ld > 0)) g = 1;
+        cg.g[d] = g;
+        cg.np[d] = g + 1;
+        ncell *= g;
+        nlat *= g + 1;
+    }
+    const int64_t n0 = nlat * dofs;
+    FEDD_CHECK(n0 <= COARSE_MAX_DOFS,
+               "coarse setup: %lld coarse dofs, the dense coarse solver takes at most %d; lower "
+               "fedd_schwarz_set_coarse (now %g cells)", (long long)n0, COARSE_MAX_DOFS, target);
+    const int64_t ld = (n0 + NB - 1) / NB * NB;
+    c->co_geom = cg;
+    c->co_ncell = ncell;
+    c->co_nlat = nlat;
+    c->co_n0 = n0;
+    c->co_ld = ld;
+    const dim3 blk(256), gn((n_own + 255) / 256);
+    // ---- owned nodes grouped by cell, in node order (stable radix split on the cell id) ----
+    for (int q = 0; q < 2; ++q) {
+        FEDD_TRY(c->d_co_key[q].ensure((size_t)n_own));
+        FEDD_TRY(c->d_co_val[q].ensure((size_t)n_own));
+    }
+    FEDD_TRY(c->d_co_cell_ptr.ensure((size_t)ncell + 1));
+    FEDD_TRY(c->d_itmp0.ensure((size_t)n_own));
+    FEDD_HIP(hipMemsetAsync(c->d_co_cell_ptr.p, 0, ((size_t)ncell + 1) * sizeof(int32_t), c->stream));
+#define K_CELL_KEY(D, ...) hipLaunchKernelGGL(k_cell_key<D>, gn, blk, 0, c->stream, __VA_ARGS__)
+    COARSE_DIM(K_CELL_KEY, cg, (const double*)c->d_xyz.p, n_own, c->d_co_key[0].p, c->d_co_val[0].p, c->d_co_cell_ptr.p);
+#undef K_CELL_KEY
+    FEDD_TRY(exclusive_scan_i32(c, c->d_co_cell_ptr.p, c->d_co_cell_ptr.p, ncell + 1, nullptr));
+    int cur = 0;
+    for (int bit = 0; ((int64_t)1 << bit) < ncell; ++bit) {
+        hipLaunchKernelGGL(k_split_flags, gn, blk, 0, c->stream, (const int32_t*)c->d_co_key[cur].p, n_own, bit, c->d_itmp0.p);
+        FEDD_TRY(exclusive_scan_i32(c, c->d_itmp0.p, c->d_itmp0.p, n_own, nullptr));
+        hipLaunchKernelGGL(k_split_scatter, gn, blk, 0, c->stream, (const int32_t*)c->d_co_key[cur].p,
+                           (const int32_t*)c->d_co_val[cur].p, (const int32_t*)c->d_itmp0.p, n_own, bit,
+                           c->d_co_key[1 - cur].p, c->d_co_val[1 - cur].p);
+        cur = 1 - cur;
+    }
+    c->co_sorted = cur;
+    const int32_t* cell_nodes = c->d_co_val[cur].p;
+    // ---- Dirichlet mask over the column space (ghost dofs through the halo) ----
+    FEDD_TRY(c->d_co_mask.ensure((size_t)c->n_cols));
+    hipLaunchKernelGGL(k_mask, dim3((unsigned)((c->n_rows + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_isdir.p,
+                       c->n_rows, c->d_co_mask.p);
+    if (c->n_cols != c->n_rows) FEDD_TRY(halo_import(c, c->d_co_mask.p, dofs));
+    // ---- K0 = Phi^T A Phi ----
+    const int NC = 1 << dim, NS = dim == 3 ? 64 : 16, NW = dim == 3 ? 125 : 25;
+    FEDD_TRY(c->d_co_cellK.ensure((size_t)ncell * dofs * dofs * NC * NS));
+    FEDD_TRY(c->d_co_K.ensure((size_t)ld * ld));
+    FEDD_TRY(c->d_flags.ensure(16));
+    int32_t* d_bad = c->d_flags.p + 3;
+    FEDD_HIP(hipMemsetAsync(d_bad, 0, 2 * sizeof(int32_t), c->stream));
+    FEDD_HIP(hipMemsetAsync(c->d_co_K.p, 0, (size_t)ld * ld * sizeof(double), c->stream));
+#define K_GALERKIN(D, ...) hipLaunchKernelGGL(k_cell_galerkin<D>, dim3((unsigned)ncell), dim3(64), 0, c->stream, __VA_ARGS__)
+    COARSE_DIM(K_GALERKIN, cg, (const int32_t*)c->d_co_cell_ptr.p, cell_nodes, (const double*)c->d_xyz.p,
+               (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p, (const double*)c->d_val.p,
+               (const double*)c->d_co_mask.p, dofs, c->d_co_cellK.p, d_bad);
+#undef K_GALERKIN
+#define K_GATHER(D, ...) hipLaunchKernelGGL(k_coarse_gather<D>, dim3((unsigned)((nlat * NW + 255) / 256)), blk, 0, c->stream, __VA_ARGS__)
+    COARSE_DIM(K_GATHER, cg, dofs, nlat, (const double*)c->d_co_cellK.p, c->d_co_K.p, ld);
+#undef K_GATHER
+    if (c->nranks > 1) {
+        FEDD_CHECK(ld * ld < ((int64_t)1 << 31), "coarse setup: K0 too large for one all-reduce");
+        FEDD_TRY(allreduce_sum(c, c->d_co_K.p, (int)(ld * ld)));
+    }
+    hipLaunchKernelGGL(k_fix_diag, dim3((unsigned)((ld + 3) / 4)), blk, 0, c->stream, c->d_co_K.p, ld, n0);
+    // ---- K0 <- K0^-1 ----
+    FEDD_TRY(dense_invert(c, c->d_co_K.p, ld, d_bad + 1));
+    int32_t bad[2] = {0, 0};
+    FEDD_HIP(hipMemcpyAsync(bad, d_bad, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    FEDD_CHECK(!bad[0], "coarse setup: a matrix entry couples lattice cells that are not neighbours "
+                        "(the lattice is finer than the mesh); lower fedd_schwarz_set_coarse (now %g cells)", target);
+    FEDD_CHECK(!bad[1], "coarse setup: K0 is not positive definite (lattice too fine for the mesh?); lower "
+                        "fedd_schwarz_set_coarse (now %g cells)", target);
+    FEDD_TRY(c->d_co_part.ensure((size_t)ncell * NC * dofs));
+    FEDD_TRY(c->d_co_r0.ensure(std::max<size_t>((size_t)ld, c->d_co_r0.cap)));
+    FEDD_TRY(c->d_co_z0.ensure((size_t)ld));
+    FEDD_HIP(hipGetLastError());
+    c->have_coarse = true;
+    return 0;
+}
+
+int coarse_apply_add(fedd_ctx* c, const double* d_r_owned, double* d_z_owned) {
+    ScopedTimer timer(c, FEDD_T_COARSE_APPLY);
+    const int dim = c->dim, dofs = c->dofs;
+    const CoarseGeom cg = c->co_geom;
+    const int64_t ncell = c->co_ncell, nlat = c->co_nlat, n0 = c->co_n0, ld = c->co_ld;
+    const int32_t* cell_nodes = c->d_co_val[c->co_sorted].p;
+    const dim3 blk(256);
+#define K_RESTRICT(D, F)                                                                                          \
+    hipLaunchKernelGGL((k_restrict_cells<D, F>), dim3((unsigned)ncell), blk, 0, c->stream, cg,                   \
+                       (const int32_t*)c->d_co_cell_ptr.p, cell_nodes, (const double*)c->d_xyz.p,                 \
+                       (const double*)c->d_co_mask.p, d_r_owned, c->d_co_part.p)
+    if (dim == 3) {
+        if (dofs == 1) K_RESTRICT(3, 1);
+        else if (dofs == 2) K_RESTRICT(3, 2);
+        else K_RESTRICT(3, 3);
+    } else {
+        if (dofs == 1) K_RESTRICT(2, 1);
+        else if (dofs == 2) K_RESTRICT(2, 2);
+        else K_RESTRICT(2, 3);
+    }
+#undef K_RESTRICT
+#define K_RNODES(D, ...) hipLaunchKernelGGL(k_restrict_nodes<D>, dim3((unsigned)((n0 + 255) / 256)), blk, 0, c->stream, __VA_ARGS__)
+    COARSE_DIM(K_RNODES, cg, dofs, nlat, (const double*)c->d_co_part.p, c->d_co_r0.p);
+#undef K_RNODES
+    timer.stop();
+    if (c->nranks > 1) FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, (int)n0));
+    ScopedTimer timer2(c, FEDD_T_COARSE_APPLY);
+    hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)((n0 + 3) / 4)), blk, 0, c->stream, (const double*)c->d_co_K.p, ld, n0,
+                       (const double*)c->d_co_r0.p, c->d_co_z0.p);
+#define K_PROLONG(D, ...) hipLaunchKernelGGL(k_prolong_add<D>, dim3((unsigned)((c->n_rows + 255) / 256)), blk, 0, c->stream, __VA_ARGS__)
+    COARSE_DIM(K_PROLONG, cg, dofs, c->n_rows, (const double*)c->d_xyz.p, (const double*)c->d_co_mask.p,
+               (const double*)c->d_co_z0.p, d_z_owned);
+#undef K_PROLONG
+    FEDD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fedd

@@ -89,6 +89,15 @@ struct DevCsr {
 };
 constexpr int MAX_AUX = 4;
 
+// regular lattice of the coarse level: g cells and np = g + 1 points per direction (1 point in
+// directions beyond dim), over the global bounding box [lo, lo + L]
+struct CoarseGeom {
+    int dim = 0;
+    int g[3] = {1, 1, 1}, np[3] = {1, 1, 1};
+    double lo[3] = {0, 0, 0}, L[3] = {1, 1, 1};
+};
+constexpr int COARSE_MAX_DOFS = 8192;   // dense K0^-1: 8192^2 * 8 B = 512 MiB
+
 struct TimerSlot {
     double total_ms = 0.0;
     int64_t launches = 0;
@@ -156,6 +165,21 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_inv;                 // per subdomain [n_i][rp_i] column-major slab
     fedd::DevBuf<double> d_mult;                // [n_cols] multiplicity (averaging)
     bool have_schwarz = false;
+
+    // ---- coarse level (two-level Schwarz) ----
+    int sw_two_level = 0;
+    double co_cells_target = 0.0;               // 0 = default
+    fedd::CoarseGeom co_geom;
+    int64_t co_ncell = 0, co_nlat = 0, co_n0 = 0, co_ld = 0;
+    fedd::DevBuf<int32_t> d_co_key[2], d_co_val[2];   // radix split ping-pong (cell id, node)
+    fedd::DevBuf<int32_t> d_co_cell_ptr;        // [ncell+1]; nodes of cell: d_co_val[co_sorted]
+    int co_sorted = 0;
+    fedd::DevBuf<double> d_co_mask;             // [n_cols] 1 = free dof, 0 = Dirichlet
+    fedd::DevBuf<double> d_co_cellK;            // per-cell Galerkin blocks
+    fedd::DevBuf<double> d_co_K;                // [ld*ld] K0, then K0^-1
+    fedd::DevBuf<double> d_co_panel;            // Dinv [64*64] | R [64*ld] | C [ld*64]
+    fedd::DevBuf<double> d_co_part, d_co_r0, d_co_z0;
+    bool have_coarse = false;
 
     // ---- GMRES workspace ----
     fedd::DevBuf<double> d_V, d_Z;              // [(m+1)*n_rows], [n_cols] scratch
@@ -234,6 +258,11 @@ int halo_import(fedd_ctx* c, double* d_xcol, int dofs);                    // fi
 // schwarz.hip
 int schwarz_setup(fedd_ctx* c);
 int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned);
+int bounding_box(fedd_ctx* c, int64_t n_nodes, double lo[3], double hi[3]);   // of d_xyz[0, n_nodes)
+
+// coarse.hip
+int coarse_setup(fedd_ctx* c);
+int coarse_apply_add(fedd_ctx* c, const double* d_r_owned, double* d_z_owned);   // z += Phi K0^-1 Phi^T r
 
 // gmres.hip
 int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart,

@@ -469,30 +469,44 @@ __global__ void k_div(double* __restrict__ z, const double* __restrict__ m, int6
 
 }  // namespace
 
+int bounding_box(fedd_ctx* c, int64_t n_nodes, double lo[3], double hi[3]) {
+    const int nblk = 128;
+    FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>((size_t)nblk * 6, c->d_dtmp0.cap)));
+    hipLaunchKernelGGL(k_minmax, dim3(nblk), dim3(256), 0, c->stream, (const double*)c->d_xyz.p, (int32_t)n_nodes, c->dim,
+                       c->d_dtmp0.p);
+    std::vector<double> part((size_t)nblk * 6);
+    FEDD_HIP(hipMemcpyAsync(part.data(), c->d_dtmp0.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = 0.0;
+        hi[d] = 0.0;
+        if (d >= c->dim) continue;
+        double mn = 1e300, mx = -1e300;
+        for (int k = 0; k < nblk; ++k) {
+            mn = std::min(mn, part[(size_t)k * 6 + d]);
+            mx = std::max(mx, part[(size_t)k * 6 + 3 + d]);
+        }
+        lo[d] = mn;
+        hi[d] = mx;
+    }
+    return 0;
+}
+
 int schwarz_setup(fedd_ctx* c) {
+    c->have_coarse = false;
     ScopedTimer timer(c, FEDD_T_SCHWARZ_SETUP);
     const int32_t n_own = (int32_t)c->n_own;
     const int dim = c->dim, dofs = c->dofs;
     const int32_t n_rows = (int32_t)c->n_rows;
     FEDD_CHECK(n_own > 0, "schwarz setup: no owned nodes");
     // ---- bounding box of the owned nodes ----
-    const int nblk = 128;
-    FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>((size_t)nblk * 6, c->d_dtmp0.cap)));
-    hipLaunchKernelGGL(k_minmax, dim3(nblk), dim3(256), 0, c->stream, (const double*)c->d_xyz.p, n_own, dim, c->d_dtmp0.p);
-    std::vector<double> part((size_t)nblk * 6);
-    FEDD_HIP(hipMemcpyAsync(part.data(), c->d_dtmp0.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    FEDD_HIP(hipStreamSynchronize(c->stream));
     BinGeom gm;
     gm.dim = dim;
-    double L[3] = {0, 0, 0};
+    double L[3] = {0, 0, 0}, bb_lo[3], bb_hi[3];
+    FEDD_TRY(bounding_box(c, n_own, bb_lo, bb_hi));
     for (int d = 0; d < dim; ++d) {
-        double mn = 1e300, mx = -1e300;
-        for (int k = 0; k < nblk; ++k) {
-            mn = std::min(mn, part[(size_t)k * 6 + d]);
-            mx = std::max(mx, part[(size_t)k * 6 + 3 + d]);
-        }
-        gm.lo[d] = mn;
-        L[d] = mx - mn;
+        gm.lo[d] = bb_lo[d];
+        L[d] = bb_hi[d] - bb_lo[d];
     }
     // regular grid of boxes with about sw_target nodes each (same formula as the oracle)
     double V = 1.0;
@@ -622,6 +636,8 @@ int schwarz_setup(fedd_ctx* c) {
     FEDD_TRY(c->d_ycol.ensure((size_t)c->n_cols));
     FEDD_HIP(hipGetLastError());
     c->have_schwarz = true;
+    timer.stop();
+    if (c->sw_two_level) FEDD_TRY(coarse_setup(c));
     return 0;
 }
 
@@ -656,6 +672,7 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned) {
                                (const double*)c->d_mult.p, c->n_rows);
         FEDD_HIP(hipMemcpyAsync(d_z_owned, z, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
+    if (c->have_coarse) FEDD_TRY(coarse_apply_add(c, d_r_owned, d_z_owned));
     FEDD_HIP(hipGetLastError());
     return 0;
 }

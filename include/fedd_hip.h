@@ -56,7 +56,9 @@ enum fedd_timer {
     FEDD_T_SCHWARZ_SETUP = 5,
     FEDD_T_SCHWARZ_APPLY = 6,
     FEDD_T_ORTHO    = 7,  /* GMRES multi-dot / multi-axpy kernels              */
-    FEDD_T_COUNT    = 8
+    FEDD_T_COARSE_SETUP = 8,  /* second level: Galerkin product + dense inverse */
+    FEDD_T_COARSE_APPLY = 9,  /* second level: restrict, K0^-1, prolongate      */
+    FEDD_T_COUNT    = 10
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -184,9 +186,21 @@ int fedd_spmv_device(fedd_ctx* ctx, int reps);
  * feddlib/problems/Solver/Preconditioner_def.hpp:243-463; options from
  * feddlib/problems/tests/laplace/parametersPrec.xml:10-61).  Subdomains are `target_nodes`-node
  * boxes of the rank's owned nodes (batched, many per GPU), extended by `overlap` graph
- * layers; exact dense local solves.  two_level/coarse_kind: reserved (GDSW is a "next" row). */
+ * layers; exact dense local solves.
+ * two_level != 0 adds a coarse level, M^-1 = M_one^-1 + Phi K0^-1 Phi^T, the role FROSch's
+ * GDSWCoarseOperator plays under "TwoLevel" = true (parametersPrec.xml:62-122).  coarse_kind:
+ * FEDD_COARSE_Q1 = multilinear hat functions of a regular lattice over the global bounding box
+ * (DESIGN.md "two-level" gives the normative definition and why it stands in for GDSW here);
+ * K0 = Phi^T A Phi is formed and inverted on the device, replicated on every rank. */
+#define FEDD_COARSE_Q1 1
 int fedd_schwarz_setup(fedd_ctx* ctx, int overlap, int combine, int two_level, int coarse_kind);
 int fedd_schwarz_set_target(fedd_ctx* ctx, int target_nodes, double scale);
+/* number of lattice cells the coarse level aims at (0 = default: global nodes / 500, clamped to
+ * [1, 3375]); call before fedd_schwarz_setup */
+int fedd_schwarz_set_coarse(fedd_ctx* ctx, double cells_target);
+/* coarse level read-back (parity): lattice cells per direction, coarse dofs n0, K0^-1 row-major */
+int fedd_schwarz_coarse_sizes(fedd_ctx* ctx, int32_t cells[3], int64_t* n0);
+int fedd_schwarz_coarse_get(fedd_ctx* ctx, double* k0_inverse);
 int fedd_schwarz_apply(fedd_ctx* ctx, const double* r_owned, double* z_owned);
 int fedd_schwarz_apply_device(fedd_ctx* ctx, int reps);
 int fedd_schwarz_info(fedd_ctx* ctx, int64_t* n_subdomains, int64_t* max_size, int64_t* inverse_bytes);

@@ -909,6 +909,71 @@ class RAS:
         return z
 
 
+def coarse_lattice(lo: np.ndarray, L: np.ndarray, cells_target: float):
+    """Normative coarse lattice of the product's second level: g_d = max(1, floor(L_d / H + 0.5))
+    cells per direction, H = (V / cells_target)^(1/dim), V = product of the non-degenerate extents
+    of the GLOBAL bounding box [lo, lo + L]; degenerate directions get one cell."""
+    dim = lo.shape[0]
+    Lpos = np.where(L > 0, L, 1.0)
+    H = (float(np.prod(Lpos)) / float(cells_target)) ** (1.0 / dim)
+    g = np.maximum(1, np.floor(Lpos / H + 0.5).astype(np.int64))
+    return np.where(L > 0, g, 1)
+
+
+class CoarseQ1:
+    """Second (coarse) level added to the one-level operator: M^-1 = M_RAS^-1 + Phi K0^-1 Phi^T.
+    Normative definition (DESIGN.md 'two-level'): Phi = multilinear (Q1) hat functions of a regular
+    lattice of (g_d + 1) points per direction over the global bounding box, evaluated at the node
+    that carries the dof, one copy per dof component (coarse dof = dofs * lattice_node + k), rows of
+    Dirichlet dofs zeroed; K0 = Phi^T A Phi, lattice dofs without support get a unit diagonal, the
+    rest a relative diagonal shift of 1e-12.  This plays the role of FROSch's GDSWCoarseOperator
+    (parametersPrec.xml:62-122, 'TwoLevel' = true); GDSW's interface-based space is defined for few
+    large subdomains and is not what is built here (DESIGN.md explains the substitution)."""
+
+    def __init__(self, A: sp.csr_matrix, xyz: np.ndarray, is_dir: np.ndarray, dofs: int = 1,
+                 cells_target: float = 1000.0, lo=None, L=None):
+        n_nodes, dim = xyz.shape
+        lo = xyz.min(axis=0) if lo is None else np.asarray(lo, dtype=float)
+        L = (xyz.max(axis=0) - lo) if L is None else np.asarray(L, dtype=float)
+        g = coarse_lattice(lo, L, cells_target)
+        Lpos = np.where(L > 0, L, 1.0)
+        t = (xyz - lo) / Lpos * g
+        i0 = np.clip(np.floor(t).astype(np.int64), 0, g - 1)
+        f = t - i0
+        stride = np.ones(dim, dtype=np.int64)
+        for d in range(1, dim):
+            stride[d] = stride[d - 1] * (g[d - 1] + 1)
+        n_lat = int(np.prod(g + 1))
+        rows, cols, vals = [], [], []
+        free = (~np.asarray(is_dir, dtype=bool)).astype(float)
+        for corner in range(1 << dim):
+            w = np.ones(n_nodes)
+            node = np.zeros(n_nodes, dtype=np.int64)
+            for d in range(dim):
+                bit = (corner >> d) & 1
+                w = w * (f[:, d] if bit else 1.0 - f[:, d])
+                node += stride[d] * (i0[:, d] + bit)
+            for k in range(dofs):
+                r = dofs * np.arange(n_nodes) + k
+                rows.append(r)
+                cols.append(dofs * node + k)
+                vals.append(w * free[r])
+        n = dofs * n_nodes
+        self.g = g
+        self.n0 = dofs * n_lat
+        self.Phi = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                                 shape=(n, self.n0))
+        K0 = (self.Phi.T @ A.tocsr() @ self.Phi).toarray()
+        d = np.diag(K0).copy()
+        empty = ~(np.abs(K0).sum(axis=1) > 0)
+        K0[np.diag_indices(self.n0)] = np.where(empty, 1.0, d * (1.0 + 1e-12))
+        self.K0 = K0
+        self.K0inv = np.linalg.inv(K0)
+
+    def apply(self, r: np.ndarray) -> np.ndarray:
+        return self.Phi @ (self.K0inv @ (self.Phi.T @ r))
+
+
 def gmres_right(A, b, M=None, rtol=1e-8, max_it=100, restart=100, x0=None):
     """Right-preconditioned restarted GMRES, block size 1 (what Stratimikos/Belos 'Block GMRES'
     with an 'unspecified'-side Thyra preconditioner runs; parametersSolver.xml:5-15), classical

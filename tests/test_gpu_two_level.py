@@ -1,0 +1,122 @@
+"""Two-level Schwarz on the GPU against the oracle's CoarseQ1 (normative definition of the coarse
+level that stands in for FROSch's GDSWCoarseOperator, parametersPrec.xml:13, 62-122): lattice,
+dense K0^-1 (Galerkin product + blocked Gauss-Jordan on the f64 matrix cores), operator apply,
+iteration counts, elasticity, 2D, and the misuse messages."""
+import numpy as np
+import pytest
+
+import fedd_oracle as fo
+from test_gpu_parity import oracle_mesh
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(fedd_lib):
+    c = fedd_lib.Context(device=0)
+    yield c
+    c.close()
+
+
+def laplace_setup(fedd_lib, ctx, dim, M, bc=(1, 2, 3)):
+    m = fedd_lib.structured_mesh(dim, 1, M)
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+    ctx.assemble(fedd_lib.FORM_LAPLACE)
+    ctx.assemble_rhs([1.0])
+    ctx.dirichlet(list(bc), [0.0] * len(bc))
+    om = oracle_mesh(m)
+    A_bc, rhs_bc, _, _, flags = fo.laplace_problem(om, bc_flags=bc)
+    return m, om, A_bc, rhs_bc, np.isin(flags, bc)
+
+
+@pytest.mark.parametrize("dim,M,cells", [(3, 12, 27), (3, 16, 200), (2, 24, 36), (3, 10, 1)])
+def test_coarse_matrix_and_apply(fedd_lib, ctx, dim, M, cells):
+    m, om, A_bc, rhs_bc, is_dir = laplace_setup(fedd_lib, ctx, dim, M)
+    ctx.schwarz_set_target(27 if dim == 3 else 9, 1.0)
+    ctx.schwarz_set_coarse(cells)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
+    g, Kinv = ctx.schwarz_coarse()
+    co = fo.CoarseQ1(A_bc, m["xyz"], is_dir, 1, cells_target=cells)
+    np.testing.assert_array_equal(g[:dim], co.g)
+    assert Kinv.shape == (co.n0, co.n0)
+    np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-10 * np.abs(co.K0inv).max())
+    node_bin, nb, _ = fo.schwarz_bins(m["xyz"], 27 if dim == 3 else 9)
+    ras = fo.RAS(A_bc, node_bin, nb)
+    rng = np.random.default_rng(5)
+    for _ in range(2):
+        r = rng.standard_normal(A_bc.shape[0])
+        z = ctx.schwarz_apply(r)
+        zo = ras.apply(r) + co.apply(r)
+        np.testing.assert_allclose(z, zo, rtol=0, atol=1e-10 * np.abs(zo).max())
+    # same operator twice: the apply is deterministic
+    r = rng.standard_normal(A_bc.shape[0])
+    np.testing.assert_array_equal(ctx.schwarz_apply(r), ctx.schwarz_apply(r))
+
+
+def test_two_level_solve_iterations(fedd_lib, ctx):
+    m, om, A_bc, rhs_bc, is_dir = laplace_setup(fedd_lib, ctx, 3, 24)
+    ctx.schwarz_set_target(27, 1.0)
+    ctx.schwarz_set_coarse(216)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+    x1, its1, _ = ctx.gmres(None, rtol=1e-8, max_it=300, restart=100, use_prec=True)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
+    x2, its2, rel2 = ctx.gmres(None, rtol=1e-8, max_it=300, restart=100, use_prec=True)
+    node_bin, nb, _ = fo.schwarz_bins(m["xyz"], 27)
+    ras = fo.RAS(A_bc, node_bin, nb)
+    co = fo.CoarseQ1(A_bc, m["xyz"], is_dir, 1, cells_target=216)
+    _, its_o, _ = fo.gmres_right(A_bc, rhs_bc, lambda r: ras.apply(r) + co.apply(r), rtol=1e-8, max_it=300, restart=100)
+    assert abs(its2 - its_o) <= 1
+    assert its2 < its1
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    assert np.abs(x2 - xd).max() <= 1e-6 * np.abs(xd).max()
+    # back to one level: the coarse part is gone
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+    _, its3, _ = ctx.gmres(None, rtol=1e-8, max_it=300, restart=100, use_prec=True)
+    assert its3 == its1
+    with pytest.raises(fedd_lib.FeddError, match="no coarse level"):
+        ctx.schwarz_coarse()
+
+
+def test_two_level_elasticity(fedd_lib, ctx):
+    """3 dofs per node, FULL pattern: the coarse space carries one hat function per component."""
+    M = 8
+    m = fedd_lib.structured_mesh(3, 1, M)
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(3, fedd_lib.BLOCK_FULL)
+    mu, nu = 1.0, 0.3
+    lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
+    ctx.assemble(fedd_lib.FORM_LINELAS, [lam, mu])
+    ctx.assemble_rhs([0.0, 1.0, 0.0])
+    ctx.dirichlet([2], [0.0, 0.0, 0.0])
+    om = oracle_mesh(m)
+    A_bc, rhs_bc, _, _, flags = fo.linelas_problem(om, mu, nu)
+    is_dir = np.repeat(np.isin(flags, (2,)), 3)
+    ctx.schwarz_set_target(8, 1.0)
+    ctx.schwarz_set_coarse(27)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
+    g, Kinv = ctx.schwarz_coarse()
+    co = fo.CoarseQ1(A_bc, m["xyz"], is_dir, 3, cells_target=27)
+    assert Kinv.shape == (co.n0, co.n0)
+    np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-10 * np.abs(co.K0inv).max())
+    node_bin, nb, _ = fo.schwarz_bins(m["xyz"], 8)
+    ras = fo.RAS(A_bc, node_bin, nb, dofs=3)
+    r = np.random.default_rng(2).standard_normal(A_bc.shape[0])
+    zo = ras.apply(r) + co.apply(r)
+    np.testing.assert_allclose(ctx.schwarz_apply(r), zo, rtol=0, atol=1e-10 * np.abs(zo).max())
+    x, its, rel = ctx.gmres(None, rtol=1e-10, max_it=300, restart=150, use_prec=True)
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    assert np.abs(x - xd).max() <= 1e-7 * np.abs(xd).max()
+
+
+def test_two_level_misuse(fedd_lib, ctx):
+    laplace_setup(fedd_lib, ctx, 3, 6)
+    with pytest.raises(fedd_lib.FeddError, match="coarse_kind 7 is not built"):
+        ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=7)
+    ctx.schwarz_set_coarse(20000)
+    with pytest.raises(fedd_lib.FeddError, match="at most 8192|finer than the mesh|not positive definite"):
+        ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
+    ctx.schwarz_set_coarse(0)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
+    g, Kinv = ctx.schwarz_coarse()
+    assert tuple(g) == (1, 1, 1) and Kinv.shape == (8, 8)    # default: 343 nodes / 500 -> one cell

@@ -104,7 +104,7 @@ def test_api_misuse_is_reported(fedd_lib, ctx):
     ctx.assemble(fedd_lib.FORM_LAPLACE)
     with pytest.raises(fedd_lib.FeddError, match="preconditioner requested"):
         ctx.gmres(None, use_prec=True)
-    with pytest.raises(fedd_lib.FeddError, match="not built yet"):
+    with pytest.raises(fedd_lib.FeddError, match="coarse_kind 0 is not built"):
         ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1)
     ctx.schwarz_set_target(100000, 1.0)          # one 64-node box + overlap would exceed nothing; 4^3 = 64 dofs
     ctx.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])

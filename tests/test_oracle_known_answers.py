@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 import fedd_oracle as fo
 
@@ -230,3 +231,36 @@ def test_solver_invariants():
     # restarted, unpreconditioned
     x, its, hist = fo.gmres_right(A_bc, rhs_bc, None, rtol=1e-12, max_it=2000, restart=9)
     np.testing.assert_allclose(x, xd, atol=1e-9 * np.abs(xd).max())
+
+
+def test_coarse_level_invariants():
+    """Second level (CoarseQ1): lattice formula, partition of unity on the free dofs, linear
+    functions reproduced, K0 symmetric positive definite, fewer iterations than one level."""
+    np.testing.assert_array_equal(fo.coarse_lattice(np.zeros(3), np.ones(3), 1000.0), [10, 10, 10])
+    np.testing.assert_array_equal(fo.coarse_lattice(np.zeros(3), np.array([4.0, 1.0, 1.0]), 32.0), [8, 2, 2])
+    np.testing.assert_array_equal(fo.coarse_lattice(np.zeros(2), np.array([1.0, 0.0]), 7.0), [3, 1])
+    m = fo.build_mesh_structured(3, 1, 16)
+    A_bc, rhs_bc, _, _, flags = fo.laplace_problem(m)
+    is_dir = flags > 0
+    co = fo.CoarseQ1(A_bc, m.xyz_uni, is_dir, 1, cells_target=64)
+    assert tuple(co.g) == (4, 4, 4) and co.n0 == 125
+    np.testing.assert_allclose(co.Phi @ np.ones(co.n0), (~is_dir).astype(float), atol=1e-14)
+    # lattice point coordinates interpolate back to the node coordinates (Q1 reproduces linears)
+    ax = np.linspace(0.0, 1.0, 5)
+    lat = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), axis=-1).transpose(2, 1, 0, 3).reshape(-1, 3)
+    np.testing.assert_allclose((co.Phi @ lat)[~is_dir], m.xyz_uni[~is_dir], atol=1e-14)
+    assert abs(co.K0 - co.K0.T).max() < 1e-13 * abs(co.K0).max()
+    assert np.linalg.eigvalsh(0.5 * (co.K0 + co.K0.T)).min() > 0
+    nb_, nb, g = fo.schwarz_bins(m.xyz_uni, 27)
+    ras = fo.RAS(A_bc, nb_, nb)
+    _, its1, _ = fo.gmres_right(A_bc, rhs_bc, ras.apply, rtol=1e-8, max_it=200, restart=100)
+    x, its2, _ = fo.gmres_right(A_bc, rhs_bc, lambda r: ras.apply(r) + co.apply(r), rtol=1e-8, max_it=200, restart=100)
+    assert its2 < its1
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    assert np.abs(x - xd).max() < 1e-6 * np.abs(xd).max()
+    # vector problem: one hat function per component
+    A3 = sp.kron(A_bc, sp.identity(3)).tocsr()
+    co3 = fo.CoarseQ1(A3, m.xyz_uni, np.repeat(is_dir, 3), 3, cells_target=64)
+    assert co3.n0 == 375
+    np.testing.assert_allclose(co3.K0[0::3, 0::3], co.K0, atol=1e-12 * abs(co.K0).max())
+    assert abs(co3.K0[0::3, 1::3]).max() == 0

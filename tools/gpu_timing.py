@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--restart", type=int, default=100)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--noprec", action="store_true")
+    ap.add_argument("--coarse", type=float, default=-1.0, help="two-level: lattice cells target (0 = default)")
     a = ap.parse_args()
     t0 = time.time()
     m = capi.structured_mesh(3, 1, a.M)
@@ -43,7 +44,12 @@ def main():
         w["dirichlet"] = time.perf_counter() - t; t = time.perf_counter()
         if not a.noprec:
             c.schwarz_set_target(a.target, a.scale)
-            c.schwarz_setup(1, capi.COMBINE_RESTRICTED); c.sync()
+            if a.coarse >= 0:
+                c.schwarz_set_coarse(a.coarse)
+                c.schwarz_setup(1, capi.COMBINE_RESTRICTED, two_level=1, coarse_kind=capi.COARSE_Q1)
+            else:
+                c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+            c.sync()
         w["schwarz_setup"] = time.perf_counter() - t; t = time.perf_counter()
         _, its, rel = c.gmres(None, rtol=a.rtol, max_it=2000, restart=a.restart, use_prec=not a.noprec, want_x=False)
         c.sync()
@@ -78,6 +84,8 @@ def main():
         c.spmv_device(50); c.sync()
         tk = c.timing_get()["spmv"]
         print(json.dumps({"spmv_kind": kind, "ms": tk[0] / tk[1], "GBs": (12 * nnz + 20 * nr) / (tk[0] / tk[1]) / 1e6}), flush=True)
+    if not a.noprec:
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED)     # pattern_build above dropped the operator
     c.timing_reset()
     c.spmv_device(50); c.sync()
     if not a.noprec:
