@@ -696,6 +696,16 @@ int coarse_setup(fedd_ctx* c) {
     int32_t bad[2] = {0, 0};
     FEDD_HIP(hipMemcpyAsync(bad, d_bad, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     FEDD_HIP(hipStreamSynchronize(c->stream));
+    if (c->nranks > 1) {
+        // every rank must take the same decision: share the flags
+        double hb[2] = {(double)bad[0], (double)bad[1]};
+        FEDD_HIP(hipMemcpyAsync(c->d_co_r0.p, hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
+        FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, 2));
+        FEDD_HIP(hipMemcpyAsync(hb, c->d_co_r0.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        bad[0] = hb[0] != 0.0;
+        bad[1] = hb[1] != 0.0;
+    }
     FEDD_CHECK(!bad[0], "coarse setup: a matrix entry couples lattice cells that are not neighbours "
                         "(the lattice is finer than the mesh); lower fedd_schwarz_set_coarse (now %g cells)", target);
     FEDD_CHECK(!bad[1], "coarse setup: K0 is not positive definite (lattice too fine for the mesh?); lower "

@@ -49,7 +49,17 @@ def _worker(rank, world, port, dec, M, q):
         c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
         x, its, rel = c.gmres(None, rtol=1e-13, max_it=600, restart=100, use_prec=True)
         rowptr, col, val, gid = c.csr_get()
-        q.put((rank, m["gid_uni"], x, y, its, rel, rowptr, col, val, gid, c.rhs_get()))
+        rhs = c.rhs_get()
+        # second level on top: K0^-1 (replicated), the coarse part of the apply, and a solve
+        r = np.random.default_rng(12).standard_normal(m["n_global"])[m["gid_uni"]]
+        z1 = c.schwarz_apply(r)
+        c.schwarz_set_coarse(16)
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED, two_level=1, coarse_kind=capi.COARSE_Q1)
+        g, Kinv = c.schwarz_coarse()
+        z2 = c.schwarz_apply(r)
+        x2, its2, rel2 = c.gmres(None, rtol=1e-13, max_it=600, restart=100, use_prec=True)
+        two = dict(g=g, Kinv=Kinv, zc=z2 - z1, x=x2, its=its2, rel=rel2)
+        q.put((rank, m["gid_uni"], x, y, its, rel, rowptr, col, val, gid, rhs, two))
         c.close()
     finally:
         dist.destroy_process_group()
@@ -73,14 +83,25 @@ def test_multirank_solve_on_one_gpu(fedd_lib, dec, M):
     ref = fedd_lib.structured_mesh(3, (1, 1, 1), [d * M for d in dec], 0)
     om = fo.Mesh(dim=3, fe="P1", conn=ref["conn"], xyz=ref["xyz"], gid_rep=ref["gid_rep"], flag_rep=ref["flag_rep"],
                  gid_uni=ref["gid_uni"], flag_uni=ref["flag_uni"], xyz_uni=None, n_global=ref["n_global"])
-    A_bc, rhs_bc, _, _, _ = fo.laplace_problem(om)
+    A_bc, rhs_bc, _, _, flags = fo.laplace_problem(om)
     xd = fo.direct_solve(A_bc, rhs_bc)
+    co = fo.CoarseQ1(A_bc, ref["xyz"], np.isin(flags, (1, 2, 3)), 1, cells_target=16)
+    rc = np.random.default_rng(12).standard_normal(ref["n_global"])
+    zc_ref = co.apply(rc)
+    xx2 = np.zeros_like(xd)
+    its2_all = set()
     xg = np.random.default_rng(11).standard_normal(ref["n_global"])
     yref = A_bc @ xg
     xx = np.zeros_like(xd)
     its_all = set()
-    for rank, gu, x, y, its, rel, rowptr, col, val, gid, rhs in res:
+    for rank, gu, x, y, its, rel, rowptr, col, val, gid, rhs, two in res:
         xx[gu] = x
+        xx2[gu] = two["x"]
+        its2_all.add(two["its"])
+        assert two["rel"] <= 1e-13
+        np.testing.assert_array_equal(two["g"], co.g)
+        np.testing.assert_allclose(two["Kinv"], co.K0inv, rtol=0, atol=1e-10 * np.abs(co.K0inv).max())
+        np.testing.assert_allclose(two["zc"], zc_ref[gu], rtol=0, atol=1e-10 * np.abs(zc_ref).max())
         its_all.add(its)
         assert rel <= 1e-13
         np.testing.assert_allclose(y, yref[gu], rtol=0, atol=1e-10 * np.abs(yref).max())
@@ -92,3 +113,5 @@ def test_multirank_solve_on_one_gpu(fedd_lib, dec, M):
         np.testing.assert_allclose(rhs, rhs_bc[gu], rtol=0, atol=1e-14)
     assert len(its_all) == 1                      # every rank took the same convergence decision
     np.testing.assert_allclose(xx, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
+    assert len(its2_all) == 1
+    np.testing.assert_allclose(xx2, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
