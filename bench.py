@@ -43,17 +43,23 @@ def parse():
     ap.add_argument("--max-it", type=int, default=2000)
     ap.add_argument("--target", type=int, default=27, help="nodes per Schwarz subdomain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-level", action="store_true", help="skip the extra two-level measurement")
+    ap.add_argument("--coarse", type=float, default=0.0, help="two-level variant: lattice cells (0 = library default)")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cells per direction of the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
 
 
-def one_step(c, capi, a):
+def one_step(c, capi, a, two_level=False):
     c.pattern_build(1, capi.BLOCK_SCALAR)
     c.assemble(capi.FORM_LAPLACE)
     c.assemble_rhs([1.0])
     c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
     c.schwarz_set_target(a.target, 1.0)
-    c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+    if two_level:
+        c.schwarz_set_coarse(a.coarse)
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED, two_level=1, coarse_kind=capi.COARSE_Q1)
+    else:
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
     _, its, rel = c.gmres(None, rtol=a.rtol, max_it=a.max_it, restart=a.restart, use_prec=True, want_x=False)
     return its, rel
 
@@ -162,6 +168,31 @@ def main():
     nr, ncol, nnz = c.csr_sizes()
     info = c.schwarz_info()
 
+    # ---- extra, outside the headline number: the same step with the coarse level switched on ----
+    two = None
+    if not a.no_two_level:
+        one_step(c, capi, a, two_level=True)
+        c.sync()
+        c.timing_reset()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            its2, rel2 = one_step(c, capi, a, two_level=True)
+        c.sync()
+        barrier()
+        dt2 = time.perf_counter() - t0
+        if N > 1:
+            tt = torch.tensor([dt2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt2 = float(tt.item())
+        g2, _ = c.schwarz_coarse_sizes()
+        tm2 = c.timing_get()
+        two = {"value": n_global * a.steps / dt2, "unit": "DoF/s", "ms_per_step": dt2 / a.steps * 1e3,
+               "gmres_iterations": its2, "relres": rel2, "coarse_cells": [int(v) for v in g2],
+               "coarse_dofs": int(c.schwarz_coarse_sizes()[1]),
+               "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in tm2.items()},
+               "note": "same step with fedd_schwarz_setup(two_level=1, FEDD_COARSE_Q1); not the headline config"}
+
     if rank == 0:
         # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md), this rank's share
         models = {
@@ -209,6 +240,8 @@ def main():
             "spmv_frac_hbm_peak": kern["spmv"]["GBs"] / HBM_PEAK_GBS if "spmv" in kern else None,
             "mesh_generation_s": t_mesh, "mesh_upload_s": t_upload,
         }
+        if two is not None:
+            out["two_level_variant"] = two
         if N == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out), flush=True)

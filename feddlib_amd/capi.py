@@ -345,6 +345,12 @@ class Context:
     def schwarz_set_coarse(self, cells_target):
         _chk(self._L.fedd_schwarz_set_coarse(self._h, float(cells_target)))
 
+    def schwarz_coarse_sizes(self):
+        g = np.zeros(3, dtype=np.int32)
+        n0 = C.c_int64()
+        _chk(self._L.fedd_schwarz_coarse_sizes(self._h, _p(g, _i32p), C.byref(n0)))
+        return g, n0.value
+
     def schwarz_coarse(self):
         """(cells per direction, K0^-1) of the coarse level"""
         g = np.zeros(3, dtype=np.int32)

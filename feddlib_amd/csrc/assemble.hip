@@ -452,27 +452,55 @@ struct RhsArgs {
     double f[MAX_DOFS];
 };
 
+// load vector in two phases: |det B_e| of every element (coalesced over elements), then each owned
+// node sums base[local index] * |det| over its adjacent elements in adjacency order
 template <int DIM>
-__global__ void k_rhs(RhsArgs a) {
-    const int32_t node = blockIdx.x * blockDim.x + threadIdx.x;
-    if (node >= a.n_own) return;
-    double sum = 0.0;
-    for (int32_t p = a.n2e_ptr[node]; p < a.n2e_ptr[node + 1]; ++p) {
-        const int32_t idx = a.n2e[p];
-        const int32_t e = idx / a.nen;
-        const int li = idx - e * a.nen;
-        double X[DIM + 1][DIM];
+__global__ void k_elem_absdet(const int32_t* __restrict__ conn, int nen, const double* __restrict__ xyz,
+                              int64_t n_elem, double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_elem) return;
+    double X[DIM + 1][DIM];
 #pragma unroll
-        for (int v = 0; v <= DIM; ++v) {
-            const int32_t nd = a.conn[(int64_t)e * a.nen + v];
+    for (int v = 0; v <= DIM; ++v) {
+        const int32_t nd = conn[e * nen + v];
 #pragma unroll
-            for (int d = 0; d < DIM; ++d) X[v][d] = a.xyz[(int64_t)nd * DIM + d];
-        }
-        double b = 0.0;
-        for (int i = 0; i < 10; ++i) b = i == li ? a.base[i] : b;
-        sum += b * fabs(affine_det<DIM>(X));
+        for (int d = 0; d < DIM; ++d) X[v][d] = xyz[(int64_t)nd * DIM + d];
     }
-    for (int d = 0; d < a.dofs; ++d) a.rhs[(int64_t)node * a.dofs + d] = sum * a.f[d];
+    out[e] = fabs(affine_det<DIM>(X));
+}
+
+// RHS_NPB nodes per workgroup: the (node, element) pairs of the workgroup are one contiguous run
+// of the adjacency, read coalesced with one lane per pair into an LDS park; then one lane per
+// node adds its segment in adjacency order (the order does not depend on the launch shape).
+constexpr int RHS_NPB = 64;
+
+__global__ __launch_bounds__(256) void k_rhs(RhsArgs a, const double* __restrict__ absdet, int cap) {
+    extern __shared__ double park[];
+    const int32_t node0 = blockIdx.x * RHS_NPB;
+    const int32_t node1 = min(a.n_own, node0 + RHS_NPB);
+    const int32_t p0 = a.n2e_ptr[node0];
+    const int tid = threadIdx.x;
+    const int32_t node = node0 + tid;
+    const bool mine = tid < RHS_NPB && node < node1;
+    const int32_t nb = mine ? a.n2e_ptr[node] : 0, ne = mine ? a.n2e_ptr[node + 1] : 0;
+    double sum = 0.0;
+    // the run is processed in windows of `cap` pairs (one window unless a node has very many elements)
+    for (int32_t w0 = p0; w0 < a.n2e_ptr[node1]; w0 += cap) {
+        const int32_t w1 = min(a.n2e_ptr[node1], w0 + cap);
+        for (int32_t p = w0 + tid; p < w1; p += 256) {
+            const int32_t idx = a.n2e[p];
+            const int32_t e = idx / a.nen;
+            const int li = idx - e * a.nen;
+            double b = 0.0;
+            for (int i = 0; i < 10; ++i) b = i == li ? a.base[i] : b;
+            park[p - w0] = b * absdet[e];
+        }
+        __syncthreads();
+        for (int32_t p = max(nb, w0); p < min(ne, w1); ++p) sum += park[p - w0];
+        __syncthreads();
+    }
+    if (mine)
+        for (int d = 0; d < a.dofs; ++d) a.rhs[(int64_t)node * a.dofs + d] = sum * a.f[d];
 }
 
 struct BcArgs {
@@ -761,9 +789,18 @@ int assemble_rhs(fedd_ctx* c, int dofs, const double* f_const, int extra_degree)
     }
     for (int d = 0; d < MAX_DOFS; ++d) a.f[d] = d < dofs ? f_const[d] : 0.0;
     const dim3 grid((unsigned)((c->n_own + 255) / 256)), block(256);
+    FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>((size_t)c->n_elem, c->d_dtmp0.cap)));
+    const dim3 egrid((unsigned)((c->n_elem + 255) / 256));
     ScopedTimer t(c, FEDD_T_RHS);
-    if (dim == 2) hipLaunchKernelGGL(k_rhs<2>, grid, block, 0, c->stream, a);
-    else hipLaunchKernelGGL(k_rhs<3>, grid, block, 0, c->stream, a);
+    if (dim == 2)
+        hipLaunchKernelGGL(k_elem_absdet<2>, egrid, block, 0, c->stream, (const int32_t*)c->d_conn.p, nen,
+                           (const double*)c->d_xyz.p, c->n_elem, c->d_dtmp0.p);
+    else
+        hipLaunchKernelGGL(k_elem_absdet<3>, egrid, block, 0, c->stream, (const int32_t*)c->d_conn.p, nen,
+                           (const double*)c->d_xyz.p, c->n_elem, c->d_dtmp0.p);
+    const int cap = std::max(256, std::min(RHS_NPB * std::max(1, c->max_deg), 6144));
+    hipLaunchKernelGGL(k_rhs, dim3((unsigned)((c->n_own + RHS_NPB - 1) / RHS_NPB)), block, (size_t)cap * sizeof(double),
+                       c->stream, a, (const double*)c->d_dtmp0.p, cap);
     t.stop();
     FEDD_HIP(hipGetLastError());
     return 0;

@@ -83,14 +83,22 @@ __device__ __forceinline__ int32_t cell_of(const CoarseGeom& cg, const int i0[3]
 // ---- nodes -> lattice cells ----
 template <int DIM>
 __global__ void k_cell_key(CoarseGeom cg, const double* __restrict__ xyz, int32_t n, int32_t* __restrict__ key,
-                           int32_t* __restrict__ val, int32_t* cnt) {
+                           int32_t* __restrict__ val) {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Loc o = locate<DIM>(cg, xyz, i);
-    const int32_t c = cell_of<DIM>(cg, o.i0);
-    key[i] = c;
+    key[i] = cell_of<DIM>(cg, o.i0);
     val[i] = i;
-    atomicAdd(&cnt[c], 1);
+}
+
+// cell_ptr from the sorted keys: position i opens every cell in (key[i-1], key[i]]
+__global__ void k_cell_bounds(const int32_t* __restrict__ key, int32_t n, int32_t ncell, int32_t* __restrict__ ptr) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t k = key[i], prev = i > 0 ? key[i - 1] : -1;
+    for (int32_t c = prev + 1; c <= k; ++c) ptr[c] = i;
+    if (i == n - 1)
+        for (int32_t c = k + 1; c <= ncell; ++c) ptr[c] = n;
 }
 
 // one stable radix-split pass on bit `bit`: zeros first, both halves keep their order
@@ -649,11 +657,9 @@ int coarse_setup(fedd_ctx* c) {
     }
     FEDD_TRY(c->d_co_cell_ptr.ensure((size_t)ncell + 1));
     FEDD_TRY(c->d_itmp0.ensure((size_t)n_own));
-    FEDD_HIP(hipMemsetAsync(c->d_co_cell_ptr.p, 0, ((size_t)ncell + 1) * sizeof(int32_t), c->stream));
 #define K_CELL_KEY(D, ...) hipLaunchKernelGGL(k_cell_key<D>, gn, blk, 0, c->stream, __VA_ARGS__)
-    COARSE_DIM(K_CELL_KEY, cg, (const double*)c->d_xyz.p, n_own, c->d_co_key[0].p, c->d_co_val[0].p, c->d_co_cell_ptr.p);
+    COARSE_DIM(K_CELL_KEY, cg, (const double*)c->d_xyz.p, n_own, c->d_co_key[0].p, c->d_co_val[0].p);
 #undef K_CELL_KEY
-    FEDD_TRY(exclusive_scan_i32(c, c->d_co_cell_ptr.p, c->d_co_cell_ptr.p, ncell + 1, nullptr));
     int cur = 0;
     for (int bit = 0; ((int64_t)1 << bit) < ncell; ++bit) {
         hipLaunchKernelGGL(k_split_flags, gn, blk, 0, c->stream, (const int32_t*)c->d_co_key[cur].p, n_own, bit, c->d_itmp0.p);
@@ -664,6 +670,8 @@ int coarse_setup(fedd_ctx* c) {
         cur = 1 - cur;
     }
     c->co_sorted = cur;
+    hipLaunchKernelGGL(k_cell_bounds, gn, blk, 0, c->stream, (const int32_t*)c->d_co_key[cur].p, n_own, (int32_t)ncell,
+                       c->d_co_cell_ptr.p);
     const int32_t* cell_nodes = c->d_co_val[cur].p;
     // ---- Dirichlet mask over the column space (ghost dofs through the halo) ----
     FEDD_TRY(c->d_co_mask.ensure((size_t)c->n_cols));
