@@ -616,7 +616,7 @@ int coarse_setup(fedd_ctx* c) {
     }
     // ---- lattice: g_d = max(1, floor(L_d / H + 0.5)), H = (V / cells_target)^(1/dim) ----
     double target = c->co_cells_target;
-    if (!(target > 0)) target = std::min(3375.0, std::max(1.0, std::floor(n_global / 500.0)));
+    if (!(target > 0)) target = std::min(3375.0, std::max(1.0, std::floor(n_global / 1000.0)));
     CoarseGeom cg;
     cg.dim = dim;
     double V = 1.0;

@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
     }
 }
 
-__device__ __forceinline__ int roundup8(int v) { return (v + 7) & ~7; }
+// leading dimension of a slab = number of stored rows: the apply kernel's lanes (row, column group)
+// then walk the slab as one contiguous stream without padding bytes
+__device__ __forceinline__ int slab_ld(int v) { return v; }
 
 __global__ void k_slab_sizes(const int32_t* __restrict__ sub_n, const int32_t* __restrict__ sub_nown, int32_t nb,
                              int restricted, int64_t* __restrict__ sz) {
@@ -183,7 +185,7 @@ __global__ void k_slab_sizes(const int32_t* __restrict__ sub_n, const int32_t* _
     if (b >= nb) return;
     const int n = sub_n[b];
     const int no = restricted ? sub_nown[b] : n;
-    const int64_t s = (int64_t)n * roundup8(no);
+    const int64_t s = (int64_t)n * slab_ld(no);
     sz[b] = (s + 15) & ~(int64_t)15;
 }
 
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
     if (singular && tid == 0) bad[0] = 1;
     // ---- needed rows of the inverse -> column-major slab [c][rp] ----
     const int nrow = restricted ? no : n;
-    const int rp = roundup8(nrow);
+    const int rp = slab_ld(nrow);
     double* __restrict__ slab = inv + inv_ptr[b];
 #pragma unroll
     for (int a = 0; a < T; ++a) {
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(256) void k_invert(const int32_t* __restrict__ sub_
         __syncthreads();
     }
     const int nrow = restricted ? no : n;
-    const int rp = roundup8(nrow);
+    const int rp = slab_ld(nrow);
     double* slab = inv + inv_ptr[b];
     for (int e = tid; e < n * rp; e += 256) {
         const int c = e / rp, r = e - c * rp;
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(256) void k_apply(const int32_t* __restrict__ sub_n
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = sub_n[b];
     const int nrow = RESTRICTED ? sub_nown[b] : n;
-    const int rp = roundup8(nrow);
+    const int rp = slab_ld(nrow);
     const int S = 256 / rp;
     for (int c = tid; c < n; c += 256) {
         const int32_t d = sub_dofs[(int64_t)b * NMAX + c];

@@ -195,7 +195,7 @@ int fedd_spmv_device(fedd_ctx* ctx, int reps);
 #define FEDD_COARSE_Q1 1
 int fedd_schwarz_setup(fedd_ctx* ctx, int overlap, int combine, int two_level, int coarse_kind);
 int fedd_schwarz_set_target(fedd_ctx* ctx, int target_nodes, double scale);
-/* number of lattice cells the coarse level aims at (0 = default: global nodes / 500, clamped to
+/* number of lattice cells the coarse level aims at (0 = default: global nodes / 1000, clamped to
  * [1, 3375]); call before fedd_schwarz_setup */
 int fedd_schwarz_set_coarse(fedd_ctx* ctx, double cells_target);
 /* coarse level read-back (parity): lattice cells per direction, coarse dofs n0, K0^-1 row-major */

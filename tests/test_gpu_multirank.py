@@ -115,3 +115,69 @@ def test_multirank_solve_on_one_gpu(fedd_lib, dec, M):
     np.testing.assert_allclose(xx, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
     assert len(its2_all) == 1
     np.testing.assert_allclose(xx2, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
+
+
+def _worker_elasticity(rank, world, port, dec, M, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from feddlib_amd import capi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = capi.structured_mesh(3, dec, [M] * 3, rank, ghosts=True)
+        c = capi.Context(device=0, rank=rank, nranks=world, nccl_id=None)
+        c.mesh_set_dict(m)
+        c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, [M] * 3, m["gid_rep"]))
+        c.comm_set_torch_dist(dist)
+        mu, nu = 1.0, 0.3
+        lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
+        c.pattern_build(3, capi.BLOCK_FULL)
+        c.assemble(capi.FORM_LINELAS, [lam, mu])
+        c.assemble_rhs([0.0, 1.0, 0.0])
+        c.dirichlet([2], [0.0, 0.0, 0.0])
+        c.schwarz_set_target(8, 1.0)
+        c.schwarz_set_coarse(8)
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED, two_level=1, coarse_kind=capi.COARSE_Q1)
+        g, Kinv = c.schwarz_coarse()
+        x, its, rel = c.gmres(None, rtol=1e-13, max_it=800, restart=200, use_prec=True)
+        q.put((rank, m["gid_uni"], x, its, rel, g, Kinv))
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multirank_elasticity_two_level(fedd_lib):
+    """cfg 5 in miniature: 3 dofs per node, FULL blocks, ghost halo with 3 values per node, two ranks,
+    coarse level replicated; solution and K0^-1 against the single-domain oracle."""
+    import torch.multiprocessing as mp
+    dec, M = (1, 1, 2), 4
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_elasticity, args=(r, world, port, dec, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = fedd_lib.structured_mesh(3, (1, 1, 1), [d * M for d in dec], 0)
+    om = fo.Mesh(dim=3, fe="P1", conn=ref["conn"], xyz=ref["xyz"], gid_rep=ref["gid_rep"], flag_rep=ref["flag_rep"],
+                 gid_uni=ref["gid_uni"], flag_uni=ref["flag_uni"], xyz_uni=None, n_global=ref["n_global"])
+    A_bc, rhs_bc, _, _, flags = fo.linelas_problem(om, 1.0, 0.3)
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    co = fo.CoarseQ1(A_bc, ref["xyz"], np.repeat(np.isin(flags, (2,)), 3), 3, cells_target=8)
+    xx = np.zeros_like(xd)
+    its_all = set()
+    for rank, gu, x, its, rel, g, Kinv in res:
+        gd = (3 * gu[:, None] + np.arange(3)[None, :]).ravel()
+        xx[gd] = x
+        its_all.add(its)
+        assert rel <= 1e-13
+        np.testing.assert_array_equal(g, co.g)
+        np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-10 * np.abs(co.K0inv).max())
+    assert len(its_all) == 1
+    np.testing.assert_allclose(xx, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
