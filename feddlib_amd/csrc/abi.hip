@@ -556,7 +556,9 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
 
 extern "C" int fedd_timing_enable(fedd_ctx* c, int on) {
     NEED_DEVICE(c);
+    FEDD_CHECK(on >= 0 && on <= 1024, "fedd_timing_enable: %d", on);
     c->timing = on != 0;
+    c->timing_stride = on > 1 ? on : 1;
     return 0;
 }
 
@@ -567,6 +569,7 @@ extern "C" int fedd_timing_reset(fedd_ctx* c) {
     for (int t = 0; t < FEDD_T_COUNT; ++t) {
         c->timers[t].total_ms = 0;
         c->timers[t].launches = 0;
+        c->timers[t].seen = 0;
     }
     return 0;
 }
@@ -576,8 +579,10 @@ extern "C" int fedd_timing_get(fedd_ctx* c, int timer, double* total_ms, int64_t
     FEDD_CHECK(timer >= 0 && timer < FEDD_T_COUNT, "fedd_timing_get: timer %d", timer);
     FEDD_HIP(hipStreamSynchronize(c->stream));
     FEDD_TRY(timing_flush(c));
-    if (total_ms) *total_ms = c->timers[timer].total_ms;
-    if (launches) *launches = c->timers[timer].launches;
+    // sampled classes: the total is the sampled average times the number of launches seen
+    const auto& s = c->timers[timer];
+    if (total_ms) *total_ms = s.launches > 0 ? s.total_ms * (double)s.seen / (double)s.launches : 0.0;
+    if (launches) *launches = s.seen;
     return 0;
 }
 

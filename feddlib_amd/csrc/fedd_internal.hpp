@@ -100,7 +100,8 @@ constexpr int COARSE_MAX_DOFS = 8192;   // dense K0^-1: 8192^2 * 8 B = 512 MiB
 
 struct TimerSlot {
     double total_ms = 0.0;
-    int64_t launches = 0;
+    int64_t launches = 0;   // launches that were timed
+    int64_t seen = 0;       // launches that passed through (timed or not)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
@@ -199,6 +200,7 @@ struct fedd_ctx {
 
     // ---- timing ----
     bool timing = false;
+    int timing_stride = 1;
     fedd::TimerSlot timers[FEDD_T_COUNT];
 };
 
@@ -209,8 +211,14 @@ struct ScopedTimer {
     fedd_ctx* c;
     int id;
     hipEvent_t a = nullptr, b = nullptr;
-    ScopedTimer(fedd_ctx* ctx, int timer) : c(ctx), id(timer) {
-        if (c->timing) {
+    ScopedTimer(fedd_ctx* ctx, int timer) : c(ctx), id(timer) {   // timer < 0: no-op
+        if (c->timing && timer >= 0) {
+            // the per-iteration classes are sampled every timing_stride-th launch: an event pair
+            // around each of several hundred small launches per solve costs a few percent
+            const bool per_iteration = timer == FEDD_T_SPMV || timer == FEDD_T_SCHWARZ_APPLY ||
+                                       timer == FEDD_T_ORTHO || timer == FEDD_T_COARSE_APPLY;
+            const int64_t k = c->timers[id].seen++;
+            if (per_iteration && c->timing_stride > 1 && k % c->timing_stride != 0) return;
             if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
                 (void)hipEventRecord(a, c->stream);
         }

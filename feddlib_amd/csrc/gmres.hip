@@ -313,12 +313,36 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
         if (relres_out) *relres_out = 0.0;
         return 0;
     }
+    // The convergence test of iteration j is read on the host while iteration j + 1 is already
+    // queued (two pinned slots, one event each): the device never waits for the host round trip.
+    // An iteration queued past convergence only writes basis column j + 2, Hessenberg column
+    // j + 1 and g[j+1..j+2], none of which the update of x with k = j + 1 columns reads.
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int q = 0; q < 2; ++q) FEDD_HIP(hipEventCreateWithFlags(&ev[q], hipEventDisableTiming));
+    struct EvGuard {
+        hipEvent_t* e;
+        ~EvGuard() {
+            for (int q = 0; q < 2; ++q)
+                if (e[q]) (void)hipEventDestroy(e[q]);
+        }
+    } ev_guard{ev};
     bool converged = false;
     while (!converged && its < max_it) {
         hipLaunchKernelGGL(k_cycle_init, dim3(1), dim3(1), 0, st, S, o, m, (const double*)(S + o.nrm + 3));
         hipLaunchKernelGGL(k_scale_to, gn, blk, 0, st, (const double*)r, (const double*)(S + o.misc + 1), V, n);
         int k = 0;
-        for (int j = 0; j < m && its < max_it; ++j) {
+        int issued = its, checked = 0, queued = 0;  // iterations of this cycle: results read / queued
+        auto check = [&](int jj) -> int {           // 1 = stop (converged or breakdown), < 0 = error
+            if (hipEventSynchronize(ev[jj & 1]) != hipSuccess) return -1;
+            const double* hp = c->h_pinned + 4 * (jj & 1);
+            ++its;
+            ++checked;
+            k = jj + 1;
+            relres = hp[0] / beta0;
+            const bool breakdown = !(hp[2] > 0.0);
+            return (relres <= rtol || breakdown) ? 1 : 0;
+        };
+        for (int j = 0; j < m && issued < max_it; ++j) {
             const double* vj = V + (int64_t)j * ldv;
             if (use_prec) FEDD_TRY(schwarz_apply(c, vj, z));
             FEDD_TRY(spmv_owned(c, use_prec ? z : vj, w));
@@ -356,16 +380,23 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
                                (const int32_t*)gate);
             hipLaunchKernelGGL(k_scale_to, gn, blk, 0, st, (const double*)w, (const double*)(S + o.misc + 1),
                                V + (int64_t)(j + 1) * ldv, n);
-            FEDD_HIP(hipMemcpyAsync(c->h_pinned, S + o.misc, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-            FEDD_HIP(hipStreamSynchronize(st));
-            ++its;
-            k = j + 1;
-            relres = c->h_pinned[0] / beta0;
-            const bool breakdown = !(c->h_pinned[2] > 0.0);
-            if (relres <= rtol || breakdown) {
-                converged = true;
-                break;
+            FEDD_HIP(hipMemcpyAsync(c->h_pinned + 4 * (j & 1), S + o.misc, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            FEDD_HIP(hipEventRecord(ev[j & 1], st));
+            ++issued;
+            ++queued;
+            if (j > 0) {
+                const int rc = check(j - 1);
+                FEDD_CHECK(rc >= 0, "gmres: waiting for iteration %d failed", j - 1);
+                if (rc) {
+                    converged = true;
+                    break;
+                }
             }
+        }
+        if (!converged && checked < queued) {
+            const int rc = check(queued - 1);
+            FEDD_CHECK(rc >= 0, "gmres: waiting for iteration %d failed", queued - 1);
+            converged = rc != 0;
         }
         // x += M^-1 (V y)
         hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(k + 1) * sizeof(double), st, S, o, k, m);
