@@ -81,6 +81,10 @@ extern "C" int fedd_ctx_create(fedd_ctx** out, int device, const void* nccl_uniq
             delete c;
             return 1;
         }
+        {
+            int cu = 0;
+            if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) c->n_cu = cu;
+        }
         if (hipHostMalloc((void**)&c->h_pinned, 4096 * sizeof(double)) != hipSuccess) {
             set_error("fedd_ctx_create: pinned allocation failed");
             delete c;
@@ -550,6 +554,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     const std::string k(key);
     if (k == "spmv_kind") c->spmv_kind = (int)value;
     else if (k == "asm_kind") c->asm_kind = (int)value;
+    else if (k == "apply_kind") c->apply_kind = (int)value;
     else FEDD_CHECK(false, "fedd_set_option: unknown key '%s'", key);
     return 0;
 }

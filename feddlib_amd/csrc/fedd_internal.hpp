@@ -109,6 +109,7 @@ struct TimerSlot {
 
 struct fedd_ctx {
     int device = -1;  // < 0: host-only context (no HIP calls; host logic tests)
+    int n_cu = 256;   // compute units of the device (persistent launches)
     int rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     ncclComm* comm = nullptr;
@@ -157,7 +158,8 @@ struct fedd_ctx {
     int sw_target = 27;
     double sw_scale = 1.0;
     int sw_overlap = 1, sw_combine = 0;
-    int64_t sw_nsub = 0, sw_max_size = 0, sw_inv_elems = 0;
+    int64_t sw_nsub = 0, sw_max_size = 0, sw_max_own = 0, sw_inv_elems = 0;
+    int apply_kind = 0;                         // restricted apply: 0 = flat streaming kernel, 1 = strided (A/B)
     fedd::DevBuf<int32_t> d_node_bin;           // [n_own] compact bin id of each owned node
     fedd::DevBuf<int32_t> d_bin_ptr, d_bin_nodes;   // [nsub+1], [n_own]
     fedd::DevBuf<int32_t> d_sub_n, d_sub_nown;  // [nsub] total / owned dofs of each subdomain
