@@ -680,12 +680,15 @@ int LinearSolver<SC, LO, GO, NO>::solve(Problem_Type* problem, BlockMultiVectorP
     const int cmb = combine == "Averaging" ? FEDD_COMBINE_AVERAGING : (combine == "Full" ? FEDD_COMBINE_FULL : FEDD_COMBINE_RESTRICTED);
     const bool usePrec = precType != "None";
     if (usePrec && type != "MonolithicConstPrec") {
-        // TwoLevel (GDSW) requests run one-level here; say so instead of silently ignoring it
-        if (frosch.get("TwoLevel", false) && problem->getVerbose())
-            std::cout << "-- note: the GDSW coarse level is not built yet, running one-level Schwarz --" << std::endl;
+        // "TwoLevel" = true (parametersPrec.xml:17) switches the coarse level on.  The coarse space is
+        // this library's lattice space, not FROSch's GDSW: say so.
+        const bool twoLevel = frosch.get("TwoLevel", false);
+        if (twoLevel && problem->getVerbose())
+            std::cout << "-- note: TwoLevel runs the Q1-lattice coarse space of libfedd_hip, not GDSW --" << std::endl;
         const int target = frosch.get("Subdomain Nodes", 27);
         feddCheck(fedd_schwarz_set_target(ctx, target, 1.0), "fedd_schwarz_set_target");
-        feddCheck(fedd_schwarz_setup(ctx, overlap, cmb, 0, 0), "fedd_schwarz_setup");
+        feddCheck(fedd_schwarz_set_coarse(ctx, frosch.get("Coarse Cells", 0.0)), "fedd_schwarz_set_coarse");
+        feddCheck(fedd_schwarz_setup(ctx, overlap, cmb, twoLevel ? 1 : 0, twoLevel ? FEDD_COARSE_Q1 : 0), "fedd_schwarz_setup");
     }
     auto b = rhs.is_null() ? problem->getRhs() : rhs;
     auto x = problem->getSolution();

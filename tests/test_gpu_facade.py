@@ -45,7 +45,7 @@ def test_reference_laplace_xml_files_2d(driver, tmp_path):
     xd = fo.direct_solve(A_bc, rhs_bc)
     assert rel <= 1e-8 and 0 < its <= 100
     np.testing.assert_allclose(x, xd, rtol=0, atol=1e-6 * np.abs(xd).max())      # tolerance-limited (1e-8 residual)
-    assert "GDSW coarse level is not built yet" in log                           # TwoLevel=true in that file: said, not hidden
+    assert "Q1-lattice coarse space" in log        # TwoLevel=true in that file: honoured, and the substitution is said
 
 
 def test_3d_tight_tolerance_matches_oracle(driver, tmp_path):
