@@ -233,6 +233,28 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
     __syncthreads();
     double A[T][T];
     // ---- dense extraction, 16 rows at a time through the LDS stage ----
+    // Lane (r, l) = (tid >> 4, tid & 15) handles entry l (+16, +32, ...) of rows r + 16 a.  The global
+    // loads of all T tiles are issued first (row bounds, then the first column id and value of each
+    // row), so that the T dependent load chains overlap instead of running one tile after another.
+    int32_t pb[T], pe[T], col0[T];
+    double v0[T];
+    {
+        const int r = tid >> 4, l = tid & 15;
+#pragma unroll
+        for (int a = 0; a < T; ++a) {
+            const int i = r + 16 * a;
+            const int32_t g = i < n ? sdof[i] : -1;
+            const bool stored = g >= 0 && g < n_rows;
+            pb[a] = stored ? rowptr[g] + l : 0;
+            pe[a] = stored ? rowptr[g + 1] : 0;
+        }
+#pragma unroll
+        for (int a = 0; a < T; ++a) {
+            const bool have = pb[a] < pe[a];
+            col0[a] = have ? colind[pb[a]] : -1;
+            v0[a] = have ? val[pb[a]] : 0.0;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < T; ++a) {
         for (int e = tid; e < 16 * (NP + 1); e += 256) (&stage[0][0])[e] = 0.0;
@@ -243,14 +265,19 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
             if (i < n) {
                 const int32_t g = sdof[i];
                 if (g < n_rows) {
-                    for (int32_t p = rowptr[g] + l; p < rowptr[g + 1]; p += 16) {
-                        const int32_t col = colind[p];
+                    int32_t col = col0[a];
+                    double v = v0[a];
+                    for (int32_t p = pb[a]; p < pe[a]; p += 16) {
+                        if (p != pb[a]) {
+                            col = colind[p];
+                            v = val[p];
+                        }
                         int cidx = bsearch_i32(sdof, no, col);
                         if (cidx < 0) {
                             cidx = bsearch_i32(sdof + no, n - no, col);
                             if (cidx >= 0) cidx += no;
                         }
-                        if (cidx >= 0) stage[r][cidx] = val[p];
+                        if (cidx >= 0) stage[r][cidx] = v;
                     }
                 } else if (l == 0) {
                     stage[r][i] = 1.0;  // ghost row (not stored on this rank): identity
@@ -271,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
     // same inverse).  Plain systems: one pass.
     bool singular = false;
     int step = 0;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int npass = p_off == INT32_MAX ? 1 : 2;
     for (int pass = 0; pass < npass; ++pass) {
 #pragma unroll
@@ -280,9 +308,13 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
             if (k >= n) break;
             if (npass == 2 && (sdof[k] >= p_off) != (pass == 1)) continue;
             const int buf = (step++) & 1;
-            if (tx == kc) {
+            // tx == kc holds in one wave only (tx = tid >> 4): the other three skip by a scalar branch
+            const bool col_wave = wave == (kc >> 2);
+            if (col_wave) {
+                if (tx == kc) {
 #pragma unroll
-                for (int a = 0; a < T; ++a) colbuf[buf][ty + 16 * a] = A[a][kb];
+                    for (int a = 0; a < T; ++a) colbuf[buf][ty + 16 * a] = A[a][kb];
+                }
             }
             if (ty == kc) {
 #pragma unroll
@@ -291,7 +323,11 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
             __syncthreads();
             const double piv = rowbuf[buf][k];
             singular = singular || !(fabs(piv) > 1e-300);
-            const double pinv = 1.0 / piv;
+            // reciprocal: hardware estimate (about 23 bits) + two Newton steps instead of the IEEE
+            // division sequence
+            double pinv = __builtin_amdgcn_rcp(piv);
+            pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);
+            pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);
             double cc[T], rr[T];
 #pragma unroll
             for (int a = 0; a < T; ++a) cc[a] = colbuf[buf][ty + 16 * a];
@@ -302,10 +338,12 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
 #pragma unroll
                 for (int bb = 0; bb < T; ++bb) A[kb][bb] = 0.0;
             }
-            if (tx == kc) {
-                rr[kb] = pinv;
+            if (col_wave) {
+                if (tx == kc) {
+                    rr[kb] = pinv;
 #pragma unroll
-                for (int a = 0; a < T; ++a) A[a][kb] = 0.0;
+                    for (int a = 0; a < T; ++a) A[a][kb] = 0.0;
+                }
             }
 #pragma unroll
             for (int a = 0; a < T; ++a)

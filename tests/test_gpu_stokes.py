@@ -133,3 +133,40 @@ def test_small_stokes_solve(fedd_lib, ctx):
     xd = fo.direct_solve(M_bc, rhs_bc)
     assert rel <= 1e-12
     np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+
+
+def test_cfg4_block_assembly_on_the_6k_cylinder(fedd_lib, ctx):
+    """cfg 4 of BASELINE.json on the mesh it names: DFG3DCylinder_6k.mesh, P2 velocity / P1 pressure,
+    27 618 tets -> 45 007 P2 + 6 721 P1 nodes = 141 742 dofs.  All blocks and the merged saddle-point
+    matrix against the oracle; also the device time of the block assembly."""
+    m1 = fedd_lib.read_mesh(os.path.join(GOLD, "DFG3DCylinder_6k.mesh"), 3)
+    mv = fedd_lib.p2_of_p1(m1, volume_id=0)
+    n_p, nv = m1["xyz"].shape[0], mv["xyz"].shape[0]
+    assert m1["conn"].shape == (27618, 4) and (nv, n_p) == (45007, 6721) and 3 * nv + n_p == 141742
+    omv, omp = oracle_mesh(mv), oracle_mesh(m1)
+    nu = 1.0e-3
+    ctx.mesh_set_dict(mv)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    ctx.pattern_build(3, fedd_lib.BLOCK_DIAG)
+    ctx.assemble(fedd_lib.FORM_LAPLACE_VEC)
+    ctx.matrix_scale(-1, nu)
+    ctx.matrix_store(0)
+    ctx.assemble_div(n_p, 1, 2)
+    ctx.matrix_scale(1, -1.0)
+    ctx.matrix_scale(2, -1.0)
+    ctx.block_merge(0, 2, 1, -1)
+    tm = ctx.timing_get()
+    ctx.timing_enable(False)
+    Ao, BTo, Bo = fo.stokes_blocks(omv, omp, nu)
+    assert_matrix_close(ctx.matrix_get(0), Ao)
+    assert_matrix_close(ctx.matrix_get(1), Bo)
+    assert_matrix_close(ctx.matrix_get(2), BTo)
+    Mo = fo.block_merge(Ao, BTo, Bo)
+    rowptr, col, val, gid = ctx.csr_get()
+    n = rowptr.shape[0] - 1
+    assert n == 141742 and rowptr[-1] == Mo.nnz
+    assert_matrix_close(sp.csr_matrix((val, col, rowptr), shape=(n, n)), Mo)
+    x = np.random.default_rng(4).standard_normal(n)
+    np.testing.assert_allclose(ctx.spmv(x), Mo @ x, rtol=0, atol=1e-10 * np.abs(Mo @ x).max())
+    print("cfg4 device ms: symbolic %.3f assemble %.3f" % (tm["symbolic"][0], tm["assemble"][0]))
