@@ -444,7 +444,7 @@ extern "C" int fedd_spmv_device(fedd_ctx* c, int reps) {
 
 extern "C" int fedd_schwarz_set_target(fedd_ctx* c, int target_nodes, double scale) {
     FEDD_CHECK(c, "null context");
-    FEDD_CHECK(target_nodes >= 1 && scale > 0, "fedd_schwarz_set_target: target %d scale %g", target_nodes, scale);
+    FEDD_CHECK(target_nodes >= 0 && scale > 0, "fedd_schwarz_set_target: target %d scale %g", target_nodes, scale);
     c->sw_target = target_nodes;
     c->sw_scale = scale;
     return 0;

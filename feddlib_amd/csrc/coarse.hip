@@ -138,10 +138,14 @@ __global__ __launch_bounds__(64) void k_cell_galerkin(CoarseGeom cg, const int32
                                                       const double* __restrict__ val,
                                                       const double* __restrict__ mask, int dofs,
                                                       double* __restrict__ cellK, int32_t* __restrict__ bad) {
+    // grid = (cells, dofs * dofs component pairs, chunks): chunk z takes the 64-node batches
+    // z, z + gridDim.z, ... of the cell; the gather kernel adds the chunks in order
     constexpr int NC = 1 << DIM, NS = DIM == 3 ? 64 : 16;
     __shared__ double P[NS][65];
     __shared__ double W[NC][64];
     const int cell = blockIdx.x, lane = threadIdx.x;
+    const int k = blockIdx.y / dofs, l = blockIdx.y - k * dofs;
+    const int nch = gridDim.z, ch = blockIdx.z;
     int cc[3] = {0, 0, 0};
     {
         int r = cell;
@@ -152,12 +156,11 @@ __global__ __launch_bounds__(64) void k_cell_galerkin(CoarseGeom cg, const int32
         }
     }
     const int32_t nb = cell_ptr[cell], ne = cell_ptr[cell + 1];
-    for (int k = 0; k < dofs; ++k)
-        for (int l = 0; l < dofs; ++l) {
+        {
             double acc[NC];
 #pragma unroll
             for (int a = 0; a < NC; ++a) acc[a] = 0.0;
-            for (int32_t base = nb; base < ne; base += 64) {
+            for (int32_t base = nb + 64 * ch; base < ne; base += 64 * nch) {
 #pragma unroll 8
                 for (int s = 0; s < NS; ++s) P[s][lane] = 0.0;
                 const int32_t node = base + lane < ne ? cell_nodes[base + lane] : -1;
@@ -212,14 +215,14 @@ __global__ __launch_bounds__(64) void k_cell_galerkin(CoarseGeom cg, const int32
             if (lane < NS) {
 #pragma unroll
                 for (int a = 0; a < NC; ++a)
-                    cellK[((((int64_t)cell * dofs + k) * dofs + l) * NC + a) * NS + lane] = acc[a];
+                    cellK[(((((int64_t)cell * nch + ch) * dofs + k) * dofs + l) * NC + a) * NS + lane] = acc[a];
             }
         }
 }
 
 // K0[(I,k)][(J,l)] = sum over the cells around lattice point I of their block entry for J
 template <int DIM>
-__global__ void k_coarse_gather(CoarseGeom cg, int dofs, int64_t n_lat, const double* __restrict__ cellK,
+__global__ void k_coarse_gather(CoarseGeom cg, int dofs, int nch, int64_t n_lat, const double* __restrict__ cellK,
                                 double* __restrict__ K, int64_t ld) {
     constexpr int NC = 1 << DIM, NS = DIM == 3 ? 64 : 16, NW = DIM == 3 ? 125 : 25;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,7 +266,9 @@ __global__ void k_coarse_gather(CoarseGeom cg, int dofs, int64_t n_lat, const do
                     slot += smul * sd;
                     smul *= 4;
                 }
-                if (ok) sum += cellK[((((int64_t)cell * dofs + k) * dofs + l) * NC + a) * NS + slot];
+                if (ok)
+                    for (int ch = 0; ch < nch; ++ch)
+                        sum += cellK[(((((int64_t)cell * nch + ch) * dofs + k) * dofs + l) * NC + a) * NS + slot];
             }
             K[(I * dofs + k) * ld + J * dofs + l] = sum;
         }
@@ -680,19 +685,23 @@ int coarse_setup(fedd_ctx* c) {
     if (c->n_cols != c->n_rows) FEDD_TRY(halo_import(c, c->d_co_mask.p, dofs));
     // ---- K0 = Phi^T A Phi ----
     const int NC = 1 << dim, NS = dim == 3 ? 64 : 16, NW = dim == 3 ? 125 : 25;
-    FEDD_TRY(c->d_co_cellK.ensure((size_t)ncell * dofs * dofs * NC * NS));
+    // chunks per cell: about 256 nodes each (4 batches), so that few, well-filled cells still
+    // spread over the device
+    const int nch = (int)std::min<int64_t>(16, std::max<int64_t>(1, ((int64_t)n_own / ncell + 255) / 256));
+    FEDD_TRY(c->d_co_cellK.ensure((size_t)ncell * nch * dofs * dofs * NC * NS));
     FEDD_TRY(c->d_co_K.ensure((size_t)ld * ld));
     FEDD_TRY(c->d_flags.ensure(16));
     int32_t* d_bad = c->d_flags.p + 3;
     FEDD_HIP(hipMemsetAsync(d_bad, 0, 2 * sizeof(int32_t), c->stream));
     FEDD_HIP(hipMemsetAsync(c->d_co_K.p, 0, (size_t)ld * ld * sizeof(double), c->stream));
-#define K_GALERKIN(D, ...) hipLaunchKernelGGL(k_cell_galerkin<D>, dim3((unsigned)ncell), dim3(64), 0, c->stream, __VA_ARGS__)
+#define K_GALERKIN(D, ...) \
+    hipLaunchKernelGGL(k_cell_galerkin<D>, dim3((unsigned)ncell, (unsigned)(dofs * dofs), (unsigned)nch), dim3(64), 0, c->stream, __VA_ARGS__)
     COARSE_DIM(K_GALERKIN, cg, (const int32_t*)c->d_co_cell_ptr.p, cell_nodes, (const double*)c->d_xyz.p,
                (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p, (const double*)c->d_val.p,
                (const double*)c->d_co_mask.p, dofs, c->d_co_cellK.p, d_bad);
 #undef K_GALERKIN
 #define K_GATHER(D, ...) hipLaunchKernelGGL(k_coarse_gather<D>, dim3((unsigned)((nlat * NW + 255) / 256)), blk, 0, c->stream, __VA_ARGS__)
-    COARSE_DIM(K_GATHER, cg, dofs, nlat, (const double*)c->d_co_cellK.p, c->d_co_K.p, ld);
+    COARSE_DIM(K_GATHER, cg, dofs, nch, nlat, (const double*)c->d_co_cellK.p, c->d_co_K.p, ld);
 #undef K_GATHER
     if (c->nranks > 1) {
         FEDD_CHECK(ld * ld < ((int64_t)1 << 31), "coarse setup: K0 too large for one all-reduce");

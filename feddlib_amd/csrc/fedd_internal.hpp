@@ -155,7 +155,7 @@ struct fedd_ctx {
     fedd::DevBuf<int32_t> d_dof_node;           // [n_rows] node whose coordinates place the dof (merged systems)
 
     // ---- Schwarz ----
-    int sw_target = 27;
+    int sw_target = 0;                          // nodes per box; 0 = default (27 / dofs per node)
     double sw_scale = 1.0;
     int sw_overlap = 1, sw_combine = 0;
     int64_t sw_nsub = 0, sw_max_size = 0, sw_max_own = 0, sw_inv_elems = 0;

@@ -643,7 +643,10 @@ int schwarz_setup(fedd_ctx* c) {
     // regular grid of boxes with about sw_target nodes each (same formula as the oracle)
     double V = 1.0;
     for (int d = 0; d < dim; ++d) V *= (L[d] > 0 ? L[d] : 1.0);
-    const double s = c->sw_scale * std::pow(V * (double)c->sw_target / (double)n_own, 1.0 / dim);
+    // default target: 27 nodes for scalar problems, 27 / dofs for node-interleaved vector problems
+    // (the dense local solver takes 256 dofs including the overlap)
+    const int target = c->sw_target > 0 ? c->sw_target : (c->merged ? 27 : std::max(1, 27 / std::max(1, dofs)));
+    const double s = c->sw_scale * std::pow(V * (double)target / (double)n_own, 1.0 / dim);
     int64_t nraw = 1;
     for (int d = 0; d < 3; ++d) {
         gm.g[d] = 1;
@@ -698,7 +701,7 @@ int schwarz_setup(fedd_ctx* c) {
     c->sw_max_own = max_own;
     FEDD_CHECK(max_n <= NMAX,
                "schwarz setup: an overlapping subdomain has %d dofs, the dense local solver takes at most %d; "
-               "lower the target with fedd_schwarz_set_target (now %d nodes)", max_n, NMAX, c->sw_target);
+               "lower the target with fedd_schwarz_set_target (now %d nodes)", max_n, NMAX, target);
     // ---- slab offsets ----
     const int restricted = c->sw_combine == FEDD_COMBINE_RESTRICTED ? 1 : 0;
     FEDD_TRY(c->d_inv_ptr.ensure((size_t)nsub + 1));
@@ -729,14 +732,17 @@ int schwarz_setup(fedd_ctx* c) {
         INV_REG(6, 64, 96);
         INV_REG(7, 96, 112);
         INV_REG(8, 112, 128);
+        INV_REG(9, 128, 144);
+        INV_REG(10, 144, 160);
 #undef INV_REG
     }
-    const int n_skip = 128;
+    const int n_skip = 160;
     if (max_n > n_skip) {
         // largest n whose matrix (odd leading dimension) plus the two pivot buffers fits 150 KB of LDS
         int lds_nmax = std::min(max_n, 134);
         const size_t lds = ((size_t)lds_nmax * (lds_nmax | 1) + 2 * NMAX) * sizeof(double);
         FEDD_HIP(hipFuncSetAttribute((const void*)k_invert<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds_nmax > n_skip)  // (the register-tiled classes now reach past what fits LDS)
         hipLaunchKernelGGL(k_invert<true>, dim3((unsigned)nsub), blk, lds, c->stream, (const int32_t*)c->d_sub_n.p,
                            (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const int32_t*)c->d_rowptr.p,
                            (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, n_rows, restricted,

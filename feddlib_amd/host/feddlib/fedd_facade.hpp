@@ -685,7 +685,7 @@ int LinearSolver<SC, LO, GO, NO>::solve(Problem_Type* problem, BlockMultiVectorP
         const bool twoLevel = frosch.get("TwoLevel", false);
         if (twoLevel && problem->getVerbose())
             std::cout << "-- note: TwoLevel runs the Q1-lattice coarse space of libfedd_hip, not GDSW --" << std::endl;
-        const int target = frosch.get("Subdomain Nodes", 27);
+        const int target = frosch.get("Subdomain Nodes", 0);   // 0 = the library's default (27 / dofs per node)
         feddCheck(fedd_schwarz_set_target(ctx, target, 1.0), "fedd_schwarz_set_target");
         feddCheck(fedd_schwarz_set_coarse(ctx, frosch.get("Coarse Cells", 0.0)), "fedd_schwarz_set_coarse");
         feddCheck(fedd_schwarz_setup(ctx, overlap, cmb, twoLevel ? 1 : 0, twoLevel ? FEDD_COARSE_Q1 : 0), "fedd_schwarz_setup");

@@ -194,6 +194,7 @@ int fedd_spmv_device(fedd_ctx* ctx, int reps);
  * K0 = Phi^T A Phi is formed and inverted on the device, replicated on every rank. */
 #define FEDD_COARSE_Q1 1
 int fedd_schwarz_setup(fedd_ctx* ctx, int overlap, int combine, int two_level, int coarse_kind);
+/* target_nodes = 0 (the default): 27 nodes for scalar problems, 27 / dofs-per-node for vector ones */
 int fedd_schwarz_set_target(fedd_ctx* ctx, int target_nodes, double scale);
 /* number of lattice cells the coarse level aims at (0 = default: global nodes / 1000, clamped to
  * [1, 3375]); call before fedd_schwarz_setup */

@@ -107,6 +107,12 @@ def test_two_level_elasticity(fedd_lib, ctx):
     x, its, rel = ctx.gmres(None, rtol=1e-10, max_it=300, restart=150, use_prec=True)
     xd = fo.direct_solve(A_bc, rhs_bc)
     assert np.abs(x - xd).max() <= 1e-7 * np.abs(xd).max()
+    # default subdomain size for a 3-dof problem: 27 / 3 nodes per box, which the dense local solver takes
+    ctx.schwarz_set_target(0, 1.0)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+    node_bin, nb, _ = fo.schwarz_bins(m["xyz"], 9)
+    info = ctx.schwarz_info()
+    assert info["n_subdomains"] == nb and info["max_size"] <= 256
 
 
 def test_two_level_misuse(fedd_lib, ctx):
