@@ -140,10 +140,17 @@ struct Off {
     int H, cs, sn, g, h1, h2, nrm, y, misc;
 };
 
-// after pass 1: decide DGKS re-orthogonalisation.  nrm[0] = w.w before, nrm[1] = after pass 1.
-__global__ void k_dgks_gate(const double* __restrict__ before, const double* __restrict__ after,
-                            int32_t* __restrict__ gate) {
-    gate[0] = after[0] < 0.5 * before[0] ? 1 : 0;
+// DGKS test from the pass-1 coefficients alone: with an orthonormal basis ||w - V h||^2 =
+// ||w||^2 - ||h||^2, so the second pass is needed iff ||h||^2 > 1/2 ||w||^2 (h1[0..j] = V^T w,
+// h1[j+1] = w.w, all already reduced over ranks).  When the test does not fire the difference has
+// no cancellation and is the squared norm after the pass (nrm1); when it fires the norm comes from
+// the second pass.  No extra reduction, no extra all-reduce.
+__global__ void k_dgks_gate(const double* __restrict__ h1, int j, int32_t* __restrict__ gate, double* __restrict__ nrm1) {
+    double s = 0.0;
+    for (int c = 0; c <= j; ++c) s += h1[c] * h1[c];
+    const double ww = h1[j + 1];
+    gate[0] = s > 0.5 * ww ? 1 : 0;
+    nrm1[0] = fmax(ww - s, 0.0);
 }
 
 // Finish column j of the Hessenberg matrix: h = h1 (+ h2), h_{j+1,j} = ||w||; apply the previous
@@ -354,14 +361,10 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
                 hipLaunchKernelGGL(k_reduce_cols, dim3(j + 2), blk, 0, st, (const double*)c->d_part.p, S + o.h1, nblk,
                                    (const int32_t*)nullptr);
                 FEDD_TRY(allreduce_sum(c, S + o.h1, j + 2));
-                // h1[j+1] now holds w.w (read in place by k_dgks_gate)
+                // h1[j+1] now holds w.w: gate and the norm after pass 1 follow from h1 alone
+                hipLaunchKernelGGL(k_dgks_gate, dim3(1), dim3(1), 0, st, (const double*)(S + o.h1), j, gate, S + o.nrm + 1);
                 hipLaunchKernelGGL(k_multiaxpy, dim3(nblk2), blk, 0, st, (const double*)V, ldv, n, j + 1,
                                    (const double*)(S + o.h1), w, c->d_part.p, (const int32_t*)nullptr);
-                hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, S + o.nrm + 1, nblk2,
-                                   (const int32_t*)nullptr);
-                FEDD_TRY(allreduce_sum(c, S + o.nrm + 1, 1));
-                hipLaunchKernelGGL(k_dgks_gate, dim3(1), dim3(1), 0, st, (const double*)(S + o.h1 + j + 1),
-                                   (const double*)(S + o.nrm + 1), gate);
                 // pass 2 (gated on the device; on several ranks the gate is identical everywhere
                 // because it is computed from all-reduced numbers, so the collectives stay matched)
                 hipLaunchKernelGGL(k_multidot, dim3(nblk, (j + 2 + MD_CG - 1) / MD_CG), blk, 0, st, (const double*)V, ldv, n,
