@@ -159,12 +159,27 @@ __global__ void k_dgks_gate(const double* __restrict__ h1, int j, int32_t* __res
 // lane 0 then runs the inherently sequential rotation chain out of LDS instead of a chain of
 // dependent global loads.
 __global__ __launch_bounds__(256) void k_givens(double* __restrict__ S, Off o, int j, int m,
-                                                const int32_t* __restrict__ gate) {
+                                                const int32_t* __restrict__ gate,
+                                                const double* __restrict__ nrm2_partial, int npart) {
     extern __shared__ double gs[];  // hcol[m+2] | cs[m] | sn[m]
+    __shared__ double red[256];
     double* hc = gs;
     double* lcs = hc + (m + 2);
     double* lsn = lcs + m;
     const bool two = gate[0] != 0;
+    // one rank: the partial sums of ||w||^2 of the second pass are added here (fixed order) instead
+    // of in a launch of their own; several ranks reduce and all-reduce before this kernel
+    if (nrm2_partial && two) {
+        double s = 0.0;
+        for (int k = threadIdx.x; k < npart; k += 256) s += nrm2_partial[k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) {
+            if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) S[o.nrm + 2] = red[0];
+    }
     for (int i = threadIdx.x; i <= j; i += blockDim.x) hc[i] = S[o.h1 + i] + (two ? S[o.h2 + i] : 0.0);
     for (int i = threadIdx.x; i < j; i += blockDim.x) {
         lcs[i] = S[o.cs + i];
@@ -374,13 +389,15 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
                 FEDD_TRY(allreduce_sum(c, S + o.h2, j + 1));
                 hipLaunchKernelGGL(k_multiaxpy, dim3(nblk2), blk, 0, st, (const double*)V, ldv, n, j + 1,
                                    (const double*)(S + o.h2), w, c->d_part.p, (const int32_t*)gate);
-                hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, S + o.nrm + 2, nblk2,
-                                   (const int32_t*)gate);
-                FEDD_TRY(allreduce_sum(c, S + o.nrm + 2, 1));
+                if (c->nranks > 1) {
+                    hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, S + o.nrm + 2, nblk2,
+                                       (const int32_t*)gate);
+                    FEDD_TRY(allreduce_sum(c, S + o.nrm + 2, 1));
+                }
                 t.stop();
             }
             hipLaunchKernelGGL(k_givens, dim3(1), dim3(256), (size_t)(3 * m + 2) * sizeof(double), st, S, o, j, m,
-                               (const int32_t*)gate);
+                               (const int32_t*)gate, (const double*)(c->nranks > 1 ? nullptr : c->d_part.p), nblk2);
             hipLaunchKernelGGL(k_scale_to, gn, blk, 0, st, (const double*)w, (const double*)(S + o.misc + 1),
                                V + (int64_t)(j + 1) * ldv, n);
             FEDD_HIP(hipMemcpyAsync(c->h_pinned + 4 * (j & 1), S + o.misc, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
