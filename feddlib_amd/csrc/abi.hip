@@ -126,6 +126,7 @@ extern "C" void fedd_ctx_destroy(fedd_ctx* c) {
         for (auto* b : db) b->release();
         c->d_inv_ptr.release();
         c->d_dof_node.release();
+        c->d_pat_stash.release();
         fedd::DevBuf<int32_t>* cib[] = {&c->d_co_key[0], &c->d_co_key[1], &c->d_co_val[0], &c->d_co_val[1],
                                         &c->d_co_cell_ptr};
         for (auto* b : cib) b->release();

@@ -146,6 +146,7 @@ struct fedd_ctx {
     bool have_pattern = false;
     int spmv_kind = 0;                          // 0 = CSR-stream kernel, 1 = row-per-lane-group kernel
     int asm_kind = 0;                           // 0 = pair-parallel assembly, 1 = lane-per-row gather
+    fedd::DevBuf<int32_t> d_pat_stash;          // pattern build: merged node lists of the count pass, [k][node]
     fedd::DevBuf<int32_t> d_spmv_rows;          // CSR-stream: first row of every nnz window
     bool spmv_rows_ready = false;
     fedd::DevCsr aux[fedd::MAX_AUX];            // stored blocks (A, B, B^T, C) of a mixed problem

@@ -78,10 +78,22 @@ __global__ __launch_bounds__(64) void k_node_pattern(const int32_t* __restrict__
     }
     if (!FILL) {
         row_cnt[r] = len;
+        // stash the merged list ([k][node] layout: coalesced) so that the fill pass is a copy
+        if (colind)
+            for (int k = 0; k < len; ++k) colind[(int64_t)k * n_own + r] = lst[k * 64 + lane];
     } else {
         const int32_t b = rowptr[r];
         for (int k = 0; k < len; ++k) colind[b + k] = lst[k * 64 + lane];
     }
+}
+
+// fill pass when the count pass stashed its lists: stash[k][node] -> colind[rowptr[node] + k]
+__global__ void k_pattern_compact(const int32_t* __restrict__ stash, const int32_t* __restrict__ rowptr, int32_t n_own,
+                                  int32_t* __restrict__ colind) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_own) return;
+    const int32_t b = rowptr[r], len = rowptr[r + 1] - b;
+    for (int k = 0; k < len; ++k) colind[b + k] = stash[(int64_t)k * n_own + r];
 }
 
 // node pattern -> dof pattern, closed form (no scan): node-wise interleaved dofs
@@ -152,8 +164,15 @@ int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
     int32_t* nptr = c->d_itmp1.p;
     if (lds > 64 * 1024)
         FEDD_HIP(hipFuncSetAttribute((const void*)k_node_pattern<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the count pass stashes its merged lists (cap x n_own ints, <= 2 GiB) so the fill pass is a copy;
+    // beyond that size the fill pass merges again
+    int32_t* stash = nullptr;
+    if ((int64_t)cap * n_own <= ((int64_t)1 << 29)) {
+        FEDD_TRY(c->d_pat_stash.ensure((size_t)cap * (size_t)n_own));
+        stash = c->d_pat_stash.p;
+    }
     hipLaunchKernelGGL(k_node_pattern<false>, grid, block, lds, c->stream, c->d_conn.p, nen, c->d_n2e_ptr.p,
-                       c->d_n2e.p, n_own, cap, nptr, (const int32_t*)nullptr, (int32_t*)nullptr);
+                       c->d_n2e.p, n_own, cap, nptr, (const int32_t*)nullptr, stash);
     int32_t max_nn = 0;
     FEDD_TRY(reduce_max_i32(c, nptr, n_own, &max_nn));
     int64_t node_nnz = 0;
@@ -183,10 +202,15 @@ int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
         FEDD_TRY(c->d_itmp2.ensure((size_t)node_nnz));
         ncol = c->d_itmp2.p;
     }
-    if (lds > 64 * 1024)
-        FEDD_HIP(hipFuncSetAttribute((const void*)k_node_pattern<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_node_pattern<true>, grid, block, lds, c->stream, c->d_conn.p, nen, c->d_n2e_ptr.p,
-                       c->d_n2e.p, n_own, cap, (int32_t*)nullptr, (const int32_t*)nptr, ncol);
+    if (stash) {
+        hipLaunchKernelGGL(k_pattern_compact, dim3((unsigned)((n_own + 255) / 256)), dim3(256), 0, c->stream,
+                           (const int32_t*)stash, (const int32_t*)nptr, n_own, ncol);
+    } else {
+        if (lds > 64 * 1024)
+            FEDD_HIP(hipFuncSetAttribute((const void*)k_node_pattern<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_node_pattern<true>, grid, block, lds, c->stream, c->d_conn.p, nen, c->d_n2e_ptr.p,
+                           c->d_n2e.p, n_own, cap, (int32_t*)nullptr, (const int32_t*)nptr, ncol);
+    }
     if (scalar) {
         FEDD_HIP(hipMemcpyAsync(c->d_rowptr.p, nptr, ((size_t)n_own + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     } else {
