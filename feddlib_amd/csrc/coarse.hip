@@ -119,9 +119,13 @@ __global__ void k_split_scatter(const int32_t* __restrict__ key, const int32_t* 
     val_out[dst] = val[i];
 }
 
-__global__ void k_mask(const int32_t* __restrict__ isdir, int64_t n, double* __restrict__ mask) {
+// mask = 1 on free dofs, 0 on Dirichlet dofs; n_free += number of free dofs (integer, one atomic per wave)
+__global__ void k_mask(const int32_t* __restrict__ isdir, int64_t n, double* __restrict__ mask, int32_t* n_free) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) mask[i] = isdir[i] ? 0.0 : 1.0;
+    const bool free_dof = i < n && !isdir[i];
+    if (i < n) mask[i] = free_dof ? 1.0 : 0.0;
+    const unsigned long long b = __ballot(free_dof);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_free, (int32_t)__popcll(b));
 }
 
 // ---- per-cell Galerkin block ----
@@ -680,8 +684,11 @@ int coarse_setup(fedd_ctx* c) {
     const int32_t* cell_nodes = c->d_co_val[cur].p;
     // ---- Dirichlet mask over the column space (ghost dofs through the halo) ----
     FEDD_TRY(c->d_co_mask.ensure((size_t)c->n_cols));
+    FEDD_TRY(c->d_flags.ensure(16));
+    int32_t* d_bad = c->d_flags.p + 3;  // [0] non-neighbour coupling, [1] K0 not definite, [2] free dofs
+    FEDD_HIP(hipMemsetAsync(d_bad, 0, 3 * sizeof(int32_t), c->stream));
     hipLaunchKernelGGL(k_mask, dim3((unsigned)((c->n_rows + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_isdir.p,
-                       c->n_rows, c->d_co_mask.p);
+                       c->n_rows, c->d_co_mask.p, d_bad + 2);
     if (c->n_cols != c->n_rows) FEDD_TRY(halo_import(c, c->d_co_mask.p, dofs));
     // ---- K0 = Phi^T A Phi ----
     const int NC = 1 << dim, NS = dim == 3 ? 64 : 16, NW = dim == 3 ? 125 : 25;
@@ -690,9 +697,6 @@ int coarse_setup(fedd_ctx* c) {
     const int nch = (int)std::min<int64_t>(16, std::max<int64_t>(1, ((int64_t)n_own / ncell + 255) / 256));
     FEDD_TRY(c->d_co_cellK.ensure((size_t)ncell * nch * dofs * dofs * NC * NS));
     FEDD_TRY(c->d_co_K.ensure((size_t)ld * ld));
-    FEDD_TRY(c->d_flags.ensure(16));
-    int32_t* d_bad = c->d_flags.p + 3;
-    FEDD_HIP(hipMemsetAsync(d_bad, 0, 2 * sizeof(int32_t), c->stream));
     FEDD_HIP(hipMemsetAsync(c->d_co_K.p, 0, (size_t)ld * ld * sizeof(double), c->stream));
 #define K_GALERKIN(D, ...) \
     hipLaunchKernelGGL(k_cell_galerkin<D>, dim3((unsigned)ncell, (unsigned)(dofs * dofs), (unsigned)nch), dim3(64), 0, c->stream, __VA_ARGS__)
@@ -710,19 +714,26 @@ int coarse_setup(fedd_ctx* c) {
     hipLaunchKernelGGL(k_fix_diag, dim3((unsigned)((ld + 3) / 4)), blk, 0, c->stream, c->d_co_K.p, ld, n0);
     // ---- K0 <- K0^-1 ----
     FEDD_TRY(dense_invert(c, c->d_co_K.p, ld, d_bad + 1));
-    int32_t bad[2] = {0, 0};
-    FEDD_HIP(hipMemcpyAsync(bad, d_bad, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    int32_t bad[3] = {0, 0, 0};
+    FEDD_HIP(hipMemcpyAsync(bad, d_bad, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     FEDD_HIP(hipStreamSynchronize(c->stream));
+    double n_free = (double)bad[2];
     if (c->nranks > 1) {
-        // every rank must take the same decision: share the flags
-        double hb[2] = {(double)bad[0], (double)bad[1]};
+        // every rank must take the same decision: share the flags (and add up the free dofs)
+        double hb[3] = {(double)bad[0], (double)bad[1], n_free};
         FEDD_HIP(hipMemcpyAsync(c->d_co_r0.p, hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
-        FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, 2));
+        FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, 3));
         FEDD_HIP(hipMemcpyAsync(hb, c->d_co_r0.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
         FEDD_HIP(hipStreamSynchronize(c->stream));
         bad[0] = hb[0] != 0.0;
         bad[1] = hb[1] != 0.0;
+        n_free = hb[2];
     }
+    // more coarse dofs than free fine dofs: K0 = Phi^T A Phi cannot have full rank, its regularised
+    // inverse would amplify rounding errors by 1e12 and the operator would stop being linear
+    FEDD_CHECK(n_free == 0.0 || n_free >= (double)n0,
+               "coarse setup: %lld coarse dofs for %.0f free dofs, the lattice is too fine; lower "
+               "fedd_schwarz_set_coarse (now %g cells)", (long long)n0, n_free, target);
     FEDD_CHECK(!bad[0], "coarse setup: a matrix entry couples lattice cells that are not neighbours "
                         "(the lattice is finer than the mesh); lower fedd_schwarz_set_coarse (now %g cells)", target);
     FEDD_CHECK(!bad[1], "coarse setup: K0 is not positive definite (lattice too fine for the mesh?); lower "

@@ -1,0 +1,145 @@
+"""Edge cases of the GPU path: degenerate right-hand sides, extreme restart lengths, the smallest
+meshes, subdomain sizes on both sides of the kernels' size classes, 2D vector problems and P2 with
+the coarse level, repeated setup on one context."""
+import os
+
+import numpy as np
+import pytest
+
+import fedd_oracle as fo
+from test_gpu_parity import oracle_mesh
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx(fedd_lib):
+    c = fedd_lib.Context(device=0)
+    yield c
+    c.close()
+
+
+def laplace(fedd_lib, ctx, dim, M):
+    m = fedd_lib.structured_mesh(dim, 1, M)
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+    ctx.assemble(fedd_lib.FORM_LAPLACE)
+    ctx.assemble_rhs([1.0])
+    ctx.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+    A_bc, rhs_bc, _, _, flags = fo.laplace_problem(oracle_mesh(m))
+    return m, A_bc, rhs_bc, flags
+
+
+def test_zero_rhs_and_exact_initial_guess(fedd_lib, ctx):
+    m, A_bc, rhs_bc, _ = laplace(fedd_lib, ctx, 3, 4)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+    x, its, rel = ctx.gmres(np.zeros_like(rhs_bc), rtol=1e-10, max_it=50, restart=20, use_prec=True)
+    assert its == 0 and rel == 0.0 and not x.any()            # b = 0: zero iterations, x = 0
+
+
+@pytest.mark.parametrize("restart,max_it", [(1, 400), (2, 400), (1000, 60)])
+def test_extreme_restart_lengths(fedd_lib, ctx, restart, max_it):
+    m, A_bc, rhs_bc, _ = laplace(fedd_lib, ctx, 3, 5)
+    ctx.schwarz_set_target(27, 1.0)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+    x, its, rel = ctx.gmres(None, rtol=1e-10, max_it=max_it, restart=restart, use_prec=True)
+    assert rel <= 1e-10 and its <= max_it
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-7 * np.abs(xd).max())
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_one_cell_mesh_all_dirichlet(fedd_lib, ctx, dim):
+    """M = 1: every node is on the boundary, the system is the identity; everything still runs."""
+    m, A_bc, rhs_bc, _ = laplace(fedd_lib, ctx, dim, 1)
+    ctx.schwarz_set_target(27, 1.0)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
+    x, its, rel = ctx.gmres(None, rtol=1e-12, max_it=10, restart=10, use_prec=True)
+    assert its <= 1 and not x.any()
+
+
+@pytest.mark.parametrize("target", [1, 2, 5, 40, 64])
+def test_subdomain_size_classes(fedd_lib, ctx, target):
+    """Box sizes from single nodes to 64 nodes: every size class of the local inversion kernels
+    (16 T dofs, T = 2 ... 10) and both apply kernels produce the oracle's operator."""
+    m, A_bc, rhs_bc, _ = laplace(fedd_lib, ctx, 3, 9)
+    ctx.schwarz_set_target(target, 1.0)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+    node_bin, nb, _ = fo.schwarz_bins(m["xyz"], target)
+    ras = fo.RAS(A_bc, node_bin, nb)
+    info = ctx.schwarz_info()
+    assert info["n_subdomains"] == nb and info["max_size"] == ras.max_size
+    r = np.random.default_rng(target).standard_normal(A_bc.shape[0])
+    zo = ras.apply(r)
+    for kind in (0, 1):
+        ctx.set_option("apply_kind", kind)
+        np.testing.assert_allclose(ctx.schwarz_apply(r), zo, rtol=0, atol=1e-10 * np.abs(zo).max())
+    ctx.set_option("apply_kind", 0)
+
+
+def test_2d_elasticity_two_level(fedd_lib, ctx):
+    m = fedd_lib.structured_mesh(2, 1, 16)
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(2, fedd_lib.BLOCK_FULL)
+    mu, nu = 1.0, 0.3
+    lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
+    ctx.assemble(fedd_lib.FORM_LINELAS, [lam, mu])
+    ctx.assemble_rhs([0.0, 1.0])
+    ctx.dirichlet([2], [0.0, 0.0])
+    A_bc, rhs_bc, _, _, flags = fo.linelas_problem(oracle_mesh(m), mu, nu, f=(0.0, 1.0))
+    ctx.schwarz_set_target(0, 1.0)
+    ctx.schwarz_set_coarse(16)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
+    g, Kinv = ctx.schwarz_coarse()
+    co = fo.CoarseQ1(A_bc, m["xyz"], np.repeat(np.isin(flags, (2,)), 2), 2, cells_target=16)
+    np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-10 * np.abs(co.K0inv).max())
+    x, its, rel = ctx.gmres(None, rtol=1e-12, max_it=400, restart=200, use_prec=True)
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+
+
+def test_p2_laplace_two_level_on_unstructured_mesh(fedd_lib, ctx):
+    """P2 nodes (vertices + edge midpoints) of the reference's cylinder mesh: the coarse space is
+    evaluated at the dof-carrying nodes, whatever they are."""
+    m1 = fedd_lib.read_mesh(os.path.join(GOLD, "DFG3DCylinder_1k.mesh"), 3)
+    m2 = fedd_lib.p2_of_p1(m1, volume_id=0)
+    ctx.mesh_set_dict(m2)
+    ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+    ctx.assemble(fedd_lib.FORM_LAPLACE)
+    ctx.assemble_rhs([1.0])
+    ctx.dirichlet([1, 2, 4], [0.0, 0.0, 0.0])
+    om = oracle_mesh(m2)
+    A_bc, rhs_bc, _, _, flags = fo.laplace_problem(om, bc_flags=(1, 2, 4))
+    ctx.schwarz_set_target(1, 1.0)      # P2 neighbourhoods are large: one node per box
+    ctx.schwarz_set_coarse(12)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
+    g, Kinv = ctx.schwarz_coarse()
+    co = fo.CoarseQ1(A_bc, m2["xyz"], np.isin(flags, (1, 2, 4)), 1, cells_target=12)
+    np.testing.assert_array_equal(g, co.g)
+    np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-10 * np.abs(co.K0inv).max())
+    x, its, rel = ctx.gmres(None, rtol=1e-12, max_it=600, restart=200, use_prec=True)
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+
+
+def test_repeated_setup_on_one_context(fedd_lib, ctx):
+    """Mesh, pattern, preconditioner and solve repeated with different sizes on the same context:
+    buffers grow and are reused, results do not depend on what ran before."""
+    out = []
+    for M in (6, 3, 6):
+        m, A_bc, rhs_bc, _ = laplace(fedd_lib, ctx, 3, M)
+        ctx.schwarz_set_target(27, 1.0)
+        ctx.schwarz_set_coarse(8 if M == 6 else 1)
+        ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
+        x, its, rel = ctx.gmres(None, rtol=1e-12, max_it=200, restart=100, use_prec=True)
+        xd = fo.direct_solve(A_bc, rhs_bc)
+        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+        out.append((x, its))
+    np.testing.assert_array_equal(out[0][0], out[2][0])        # bitwise the same solve
+    assert out[0][1] == out[2][1]
+    # 8 cells (27 lattice points) on the 4^3-node mesh with 8 free nodes: K0 cannot have full rank
+    laplace(fedd_lib, ctx, 3, 3)
+    ctx.schwarz_set_coarse(8)
+    with pytest.raises(fedd_lib.FeddError, match="27 coarse dofs for 8 free dofs"):
+        ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
