@@ -161,6 +161,7 @@ struct fedd_ctx {
     int sw_overlap = 1, sw_combine = 0;
     int64_t sw_nsub = 0, sw_max_size = 0, sw_max_own = 0, sw_inv_elems = 0;
     int apply_kind = 0;                         // restricted apply: 0 = flat streaming kernel, 1 = strided (A/B)
+    int inv_kind = 0;                           // local inverses: 0 = scalar-pivot kernel, 1 = MFMA block sweep (A/B)
     fedd::DevBuf<int32_t> d_node_bin;           // [n_own] compact bin id of each owned node
     fedd::DevBuf<int32_t> d_bin_ptr, d_bin_nodes;   // [nsub+1], [n_own]
     fedd::DevBuf<int32_t> d_sub_n, d_sub_nown;  // [nsub] total / owned dofs of each subdomain
@@ -270,6 +271,9 @@ int halo_import(fedd_ctx* c, double* d_xcol, int dofs);                    // fi
 int schwarz_setup(fedd_ctx* c);
 int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned);
 int bounding_box(fedd_ctx* c, int64_t n_nodes, double lo[3], double hi[3]);   // of d_xyz[0, n_nodes)
+
+// invert_mfma.hip: local inverses of plain systems, n <= 128, on the f64 matrix cores
+int schwarz_invert_mfma(fedd_ctx* c, int restricted, int32_t* d_bad, int max_n);
 
 // coarse.hip
 int coarse_setup(fedd_ctx* c);

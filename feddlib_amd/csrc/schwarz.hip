@@ -727,11 +727,17 @@ int schwarz_setup(fedd_ctx* c) {
                            (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p,                       \
                            (const double*)c->d_val.p, n_rows, restricted, (const int64_t*)c->d_inv_ptr.p,      \
                            c->d_inv.p, d_bad, (LO), (HI), p_off)
-        INV_REG(2, 0, 32);
-        INV_REG(4, 32, 64);
-        INV_REG(6, 64, 96);
-        INV_REG(7, 96, 112);
-        INV_REG(8, 112, 128);
+        if (!c->merged && c->inv_kind == 1) {
+            // A/B alternative for plain systems up to 128 dofs: blocks of four pivots on the f64 matrix
+            // cores (invert_mfma.hip); measured slower than the scalar-pivot kernel on MI355X
+            FEDD_TRY(schwarz_invert_mfma(c, restricted, d_bad, max_n));
+        } else {
+            INV_REG(2, 0, 32);
+            INV_REG(4, 32, 64);
+            INV_REG(6, 64, 96);
+            INV_REG(7, 96, 112);
+            INV_REG(8, 112, 128);
+        }
         INV_REG(9, 128, 144);
         INV_REG(10, 144, 160);
 #undef INV_REG

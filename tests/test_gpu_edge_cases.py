@@ -76,6 +76,11 @@ def test_subdomain_size_classes(fedd_lib, ctx, target):
         ctx.set_option("apply_kind", kind)
         np.testing.assert_allclose(ctx.schwarz_apply(r), zo, rtol=0, atol=1e-10 * np.abs(zo).max())
     ctx.set_option("apply_kind", 0)
+    # the alternative local-inverse kernel (blocks of four pivots on the f64 matrix cores)
+    ctx.set_option("inv_kind", 1)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+    np.testing.assert_allclose(ctx.schwarz_apply(r), zo, rtol=0, atol=1e-10 * np.abs(zo).max())
+    ctx.set_option("inv_kind", 0)
 
 
 def test_2d_elasticity_two_level(fedd_lib, ctx):

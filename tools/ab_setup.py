@@ -1,6 +1,8 @@
-"""Setup-phase kernels of cfg 2 in isolation, for rocprofv3 (development aid)."""
+"""Setup-phase kernels of cfg 2 in isolation: local-inverse kernels A/B (development aid)."""
 import os
 import sys
+
+import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from feddlib_amd import capi  # noqa: E402
@@ -14,16 +16,17 @@ c.assemble(capi.FORM_LAPLACE)
 c.assemble_rhs([1.0])
 c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
 c.timing_enable(True)
-c.timing_reset()
-for _ in range(3):
+r = np.random.default_rng(0).standard_normal(m["gid_uni"].shape[0])
+z = {}
+for kind in (0, 1, 0, 1):
+    c.set_option("inv_kind", kind)
     c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
-c.sync()
-t = c.timing_get()["schwarz_setup"]
-print("schwarz_setup ms", t[0] / t[1], flush=True)
-c.timing_reset()
-for _ in range(5):
-    c.assemble_rhs([1.0])
-c.sync()
-t = c.timing_get()["rhs"]
-print("rhs ms", t[0] / t[1], flush=True)
+    c.timing_reset()
+    for _ in range(3):
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+    c.sync()
+    t = c.timing_get()["schwarz_setup"]
+    print("inv_kind", kind, "schwarz_setup ms", t[0] / t[1], flush=True)
+    z[kind] = c.schwarz_apply(r)
+print("max |z0 - z1| / max |z|", np.abs(z[0] - z[1]).max() / np.abs(z[1]).max())
 c.close()
