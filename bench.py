@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--target", type=int, default=27, help="nodes per Schwarz subdomain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-level", action="store_true", help="skip the extra two-level measurement")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="development only: run the N > 1 path with all ranks on GPU 0, gloo + the library's "
+                         "host-staged transport (RCCL refuses several ranks on one device); numbers are not a measurement")
     ap.add_argument("--coarse", type=float, default=0.0, help="two-level variant: lattice cells (0 = library default)")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cells per direction of the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
@@ -116,16 +119,28 @@ def main():
     import torch
     import torch.distributed as dist
     from feddlib_amd import capi
-    torch.cuda.set_device(local_rank)
+    rehearse = a.rehearse_one_gpu and N > 1
+    dev = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev)
     nccl_id = None
     if N > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(capi.nccl_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        nccl_id = bytes(idt.cpu().numpy().tobytes())
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(capi.nccl_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            nccl_id = bytes(idt.cpu().numpy().tobytes())
+
+    def max_over_ranks(v):
+        if N == 1:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     def barrier():
         if N > 1:
@@ -137,12 +152,15 @@ def main():
     t0 = time.perf_counter()
     m = capi.structured_mesh(3, dec, cells, rank, ghosts=N > 1)
     t_mesh = time.perf_counter() - t0
-    c = capi.Context(device=local_rank, rank=rank, nranks=N, nccl_id=nccl_id)
+    c = capi.Context(device=dev, rank=rank, nranks=N, nccl_id=nccl_id)
     t0 = time.perf_counter()
     c.mesh_set_dict(m)
     if N > 1:
         c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, cells, m["gid_rep"]))
-        c.halo_exchange_setup()
+        if rehearse:
+            c.comm_set_torch_dist(dist)
+        else:
+            c.halo_exchange_setup()
     c.sync()
     t_upload = time.perf_counter() - t0
     n_global = m["n_global"]
@@ -161,11 +179,7 @@ def main():
         its, rel = one_step(c, capi, a)
     c.sync()
     barrier()
-    dt = time.perf_counter() - t0
-    if N > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     tm = c.timing_get()
     nr, ncol, nnz = c.csr_sizes()
     info = c.schwarz_info()
@@ -182,11 +196,7 @@ def main():
             its2, rel2 = one_step(c, capi, a, two_level=True)
         c.sync()
         barrier()
-        dt2 = time.perf_counter() - t0
-        if N > 1:
-            tt = torch.tensor([dt2], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt2 = float(tt.item())
+        dt2 = max_over_ranks(time.perf_counter() - t0)
         g2, _ = c.schwarz_coarse_sizes()
         tm2 = c.timing_get()
         two = {"value": n_global * a.steps / dt2, "unit": "DoF/s", "ms_per_step": dt2 / a.steps * 1e3,

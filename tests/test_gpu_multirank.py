@@ -181,3 +181,25 @@ def test_multirank_elasticity_two_level(fedd_lib):
         np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-10 * np.abs(co.K0inv).max())
     assert len(its_all) == 1
     np.testing.assert_allclose(xx, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+
+
+def test_bench_contract_n2_rehearsal(fedd_lib):
+    """bench.py's N > 1 code path (decomposition, ghost meshes, halo plan, barriers, max over ranks, one
+    JSON line from rank 0) with two ranks on one GPU over gloo (`--rehearse-one-gpu`)."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "0", "--cells", "12", "--rehearse-one-gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["config"]["dofs"] == 13 * 13 * 25 and d["config"]["relres"] <= 1e-8
+    assert d["two_level_variant"]["gmres_iterations"] <= d["config"]["gmres_iterations"]
