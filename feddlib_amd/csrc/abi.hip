@@ -81,10 +81,6 @@ extern "C" int fedd_ctx_create(fedd_ctx** out, int device, const void* nccl_uniq
             delete c;
             return 1;
         }
-        {
-            int cu = 0;
-            if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) c->n_cu = cu;
-        }
         if (hipHostMalloc((void**)&c->h_pinned, 4096 * sizeof(double)) != hipSuccess) {
             set_error("fedd_ctx_create: pinned allocation failed");
             delete c;

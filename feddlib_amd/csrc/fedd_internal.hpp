@@ -109,7 +109,6 @@ struct TimerSlot {
 
 struct fedd_ctx {
     int device = -1;  // < 0: host-only context (no HIP calls; host logic tests)
-    int n_cu = 256;   // compute units of the device (persistent launches)
     int rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     ncclComm* comm = nullptr;

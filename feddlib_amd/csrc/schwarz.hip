@@ -9,9 +9,10 @@
 // itself is not in the reference tree; the definition implemented here is normative:
 //   subdomain i  = owned nodes of box i of a regular grid over the rank's owned nodes
 //                  + `overlap` layers of the (Dirichlet-modified) matrix graph,
-//   A_i          = principal submatrix, inverted exactly (dense Gauss-Jordan in LDS),
+//   A_i          = principal submatrix, inverted exactly (register-tiled dense Gauss-Jordan),
 //   M^-1 r       = sum_i P_i A_i^-1 R_i r, P_i restricted / averaged / full prolongation.
 // Apply = one workgroup per subdomain streaming its slab of A_i^-1 once from HBM (HBM-bound).
+// With fedd_schwarz_setup(two_level = 1) the coarse level of coarse.hip is added to the result.
 #include "fedd_internal.hpp"
 #include <algorithm>
 #include <climits>

@@ -214,7 +214,9 @@ int fedd_schwarz_info(fedd_ctx* ctx, int64_t* n_subdomains, int64_t* max_size, i
 int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rtol, int max_it,
                int restart, int use_prec, int* its_out, double* relres_out);
 
-/* tuning knobs (A/B tests): "spmv_kind" 0 = CSR-stream (default), 1 = row-per-lane-group. */
+/* tuning knobs (A/B tests), 0 is the default of each: "spmv_kind" 0 = CSR-stream, 1 = row-per-lane-group;
+ * "asm_kind" 0 = pair-parallel assembly, 1 = lane-per-row gather; "apply_kind" 0 = flat streaming Schwarz
+ * apply, 1 = strided; "inv_kind" 0 = scalar-pivot local inverses, 1 = rank-4 block sweep on the matrix cores. */
 int fedd_set_option(fedd_ctx* ctx, const char* key, double value);
 
 /* device-time accounting (HIP events on the context's stream around each kernel class) */
