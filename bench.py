@@ -205,6 +205,20 @@ def main():
                "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in tm2.items()},
                "note": "same step with fedd_schwarz_setup(two_level=1, FEDD_COARSE_Q1); not the headline config"}
 
+    # ---- extra: SpMV launched back to back on resident vectors (single GPU; no halo in the loop) ----
+    spmv_b2b = None
+    if N == 1:
+        c.timing_enable(1)
+        c.spmv_device(5)
+        c.timing_reset()
+        c.spmv_device(50)
+        c.sync()
+        ms, nl = c.timing_get()["spmv"]
+        spmv_b2b = {"ms_per_launch": ms / nl, "GBs": (12.0 * nnz + 20.0 * nr) / (ms / nl) / 1e6,
+                    "frac_hbm_peak": (12.0 * nnz + 20.0 * nr) / (ms / nl) / 1e6 / HBM_PEAK_GBS,
+                    "note": "50 launches back to back: the 203 MB matrix stays in the 256 MB Infinity Cache between "
+                            "launches, so this is not a pure HBM figure; spmv_frac_hbm_peak is the in-solver one"}
+
     if rank == 0:
         # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md), this rank's share
         models = {
@@ -252,6 +266,8 @@ def main():
             "spmv_frac_hbm_peak": kern["spmv"]["GBs"] / HBM_PEAK_GBS if "spmv" in kern else None,
             "mesh_generation_s": t_mesh, "mesh_upload_s": t_upload,
         }
+        if spmv_b2b is not None:
+            out["spmv_back_to_back"] = spmv_b2b
         if two is not None:
             out["two_level_variant"] = two
         if N == 1 and not a.no_cpu_baseline:

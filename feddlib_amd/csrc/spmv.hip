@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__
     if (R0 >= R1) return;
     const int32_t base = rowptr[R0];
     const int32_t cnt = rowptr[R1] - base;
+    // the row bounds of this lane's first row are requested before the value stream (memory returns
+    // in issue order), so the row phase does not start with a dependent global load; clamped index:
+    // the load is unconditional
+    const int32_t r_first = min(R0 + tid, R1 - 1);
+    const int32_t rb0 = rowptr[r_first], re0 = rowptr[r_first + 1];
     int32_t i = tid;
     for (; i + 7 * 256 < cnt; i += 8 * 256) {
         double v[8];
@@ -80,7 +85,8 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__
     for (; i < cnt; i += 256) prod[i] = val[base + i] * x[colind[base + i]];
     __syncthreads();
     for (int32_t r = R0 + tid; r < R1; r += 256) {
-        const int32_t b = rowptr[r] - base, e = rowptr[r + 1] - base;
+        const bool first = r == R0 + tid;
+        const int32_t b = (first ? rb0 : rowptr[r]) - base, e = (first ? re0 : rowptr[r + 1]) - base;
         double s = 0.0;
         for (int32_t p = b; p < e; ++p) s += prod[p];
         y[r] = s;
