@@ -252,6 +252,219 @@ __global__ __launch_bounds__(256) void k_combine(const double* __restrict__ V, i
     u[i] = v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Delayed re-orthogonalisation (DCGS2; Bielich, Langou, Thomas, Swirydowicz, Yamazaki, Boman,
+// "Low-synch Gram-Schmidt with delayed reorthogonalization for Krylov solvers", 2022): the second
+// Gram-Schmidt pass of basis vector k+1 and the first pass of the next Krylov vector are one sweep
+// of dot products and one sweep of updates over the basis, instead of two and two.
+//
+// State before a step: V_k = [v_1 .. v_k] final (orthonormal), u = first-pass result that becomes
+// v_{k+1}, hp = first-pass coefficients of column k of H.  With B = A M^-1:
+//   wt = B u                                        (u is NOT yet re-orthogonalised or normalised)
+//   sweep 1:  s = V_k^T u,  t = V_k^T wt,  alpha2 = u.u,  gamma = u.wt      (one reduction)
+//   beta = sqrt(alpha2 - s.s);  column k of H = [hp + s ; beta]   -> Givens, residual
+//   v_{k+1} = (u - V_k s) / beta,   B v_{k+1} = (wt - V_{k+1} Hbar_k s) / beta   (B V_k = V_{k+1} Hbar_k)
+//   hp'_i = (t_i - (Hbar_k s)_i) / beta  (i <= k),  hp'_{k+1} = ((gamma - s.t)/beta - (Hbar_k s)_{k+1}) / beta
+//   sweep 2:  v_{k+1} as above,  u' = (wt - V_k t)/beta - v_{k+1} (gamma - s.t)/beta^2
+// u' is the first-pass result for the next vector; every basis column is read twice per iteration.
+
+// partial[(2 col + which) * nblk + blk]: which = 0: V_col . u, 1: V_col . w; col == ncolsV: u.u and u.w
+__global__ __launch_bounds__(256) void k_multidot2(const double* __restrict__ V, int64_t ldv, int64_t n, int ncolsV,
+                                                   const double* __restrict__ u, const double* __restrict__ w,
+                                                   double* __restrict__ partial, int nblk) {
+    __shared__ double sh[4][2 * MD_CG];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * MD_ROWS + 2 * tid;
+    double2 uv[4], wv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uv[k] = ld2(u, r0 + 512 * k, n);
+        wv[k] = ld2(w, r0 + 512 * k, n);
+    }
+    double au[MD_CG], aw[MD_CG];
+#pragma unroll
+    for (int cc = 0; cc < MD_CG; ++cc) {
+        const int col = blockIdx.y * MD_CG + cc;
+        double su = 0.0, sw = 0.0;
+        if (col <= ncolsV) {
+            const double* __restrict__ a = col < ncolsV ? V + (int64_t)col * ldv : u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double2 v = ld2(a, r0 + 512 * k, n);
+                su += v.x * uv[k].x + v.y * uv[k].y;
+                sw += v.x * wv[k].x + v.y * wv[k].y;
+            }
+        }
+        au[cc] = su;
+        aw[cc] = sw;
+    }
+#pragma unroll
+    for (int cc = 0; cc < MD_CG; ++cc) {
+        double su = au[cc], sw = aw[cc];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            su += __shfl_down(su, off, 64);
+            sw += __shfl_down(sw, off, 64);
+        }
+        if ((tid & 63) == 0) {
+            sh[tid >> 6][2 * cc] = su;
+            sh[tid >> 6][2 * cc + 1] = sw;
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * MD_CG) {
+        const int col = blockIdx.y * MD_CG + (tid >> 1);
+        if (col <= ncolsV)
+            partial[(int64_t)(2 * col + (tid & 1)) * nblk + blockIdx.x] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+    }
+}
+
+struct Off2 {
+    int Hraw, hp, st, cf;  // unrotated Hessenberg (m+1) x m, first-pass column, reduced dots, sweep-2 coefficients
+};
+
+// The small algebra of a DCGS2 step (one workgroup): finalise column kc = k - 1 of H, rotate it,
+// update g and the residual, and prepare the coefficients of sweep 2 and the next first-pass column.
+// misc[0] = |g_k| (residual), misc[2] = beta (0: breakdown), cf = [s (m) | t (m) | 1/beta | c_last].
+__global__ __launch_bounds__(256) void k_dcgs2_small(double* __restrict__ S, Off o, Off2 o2, int k, int m) {
+    extern __shared__ double sm[];  // s[m] | t[m] | hc[m+2] | lcs[m] | lsn[m] | Hs[m+1]
+    __shared__ double red[2][256];
+    double* s = sm;
+    double* t = s + m;
+    double* hc = t + m;
+    double* lcs = hc + (m + 2);
+    double* lsn = lcs + m;
+    double* Hs = lsn + m;
+    const int tid = threadIdx.x, kc = k - 1, ldh = m + 1;
+    const double* st = S + o2.st;
+    double ps = 0.0, pd = 0.0;
+    for (int i = tid; i < k; i += 256) {
+        const double si = st[2 * i], ti = st[2 * i + 1];
+        s[i] = si;
+        t[i] = ti;
+        ps += si * si;
+        pd += si * ti;
+    }
+    for (int i = tid; i < kc; i += 256) {
+        lcs[i] = S[o.cs + i];
+        lsn[i] = S[o.sn + i];
+    }
+    red[0][tid] = ps;
+    red[1][tid] = pd;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (tid < q) {
+            red[0][tid] += red[0][tid + q];
+            red[1][tid] += red[1][tid + q];
+        }
+        __syncthreads();
+    }
+    const double ss = red[0][0], sd = red[1][0];
+    const double alpha2 = st[2 * k], gamma = st[2 * k + 1];
+    const double beta2 = alpha2 - ss;
+    const double beta = beta2 > 0.0 ? sqrt(beta2) : 0.0;
+    const double ib = beta > 0.0 ? 1.0 / beta : 0.0;
+    // unrotated column kc
+    double* Hraw = S + o2.Hraw;
+    for (int i = tid; i <= k; i += 256) {
+        const double v = i < k ? S[o2.hp + i] + s[i] : beta;
+        Hraw[(int64_t)kc * ldh + i] = v;
+        hc[i] = v;
+    }
+    __syncthreads();
+    // Hs = Hbar_k s  (rows 0..k, columns 0..kc; entries below the sub-diagonal are zero)
+    for (int i = tid; i <= k; i += 256) {
+        double a = 0.0;
+        for (int c = (i > 0 ? i - 1 : 0); c < kc; ++c) a += Hraw[(int64_t)c * ldh + i] * s[c];
+        a += hc[i] * s[kc];  // the column written above, taken from LDS
+        Hs[i] = a;
+    }
+    __syncthreads();
+    // next first-pass column and the coefficients of sweep 2
+    for (int i = tid; i <= k; i += 256) {
+        const double v = i < k ? (t[i] - Hs[i]) * ib : ((gamma - sd) * ib - Hs[k]) * ib;
+        S[o2.hp + i] = v;
+    }
+    for (int i = tid; i < k; i += 256) {
+        S[o2.cf + i] = s[i];
+        S[o2.cf + m + i] = t[i];
+    }
+    if (tid == 0) {
+        S[o2.cf + 2 * m] = ib;
+        S[o2.cf + 2 * m + 1] = (gamma - sd) * ib * ib;
+        // Givens: previous rotations on the new column, new rotation, g and the residual
+        for (int i = 0; i < kc; ++i) {
+            const double a = lcs[i] * hc[i] + lsn[i] * hc[i + 1];
+            hc[i + 1] = -lsn[i] * hc[i] + lcs[i] * hc[i + 1];
+            hc[i] = a;
+        }
+        const double d = hypot(hc[kc], hc[kc + 1]);
+        const double cj = d > 0 ? hc[kc] / d : 1.0, sj = d > 0 ? hc[kc + 1] / d : 0.0;
+        S[o.cs + kc] = cj;
+        S[o.sn + kc] = sj;
+        hc[kc] = d;
+        double* H = S + o.H + (int64_t)kc * ldh;
+        for (int i = 0; i <= kc; ++i) H[i] = hc[i];
+        H[kc + 1] = 0.0;
+        const double gj = S[o.g + kc];
+        S[o.g + kc + 1] = -sj * gj;
+        S[o.g + kc] = cj * gj;
+        S[o.misc + 0] = fabs(sj * gj);
+        S[o.misc + 1] = ib;
+        S[o.misc + 2] = beta;
+    }
+}
+
+// sweep 2: V[:, k] = (u - V_k s) / beta ;  u <- (w - V_k t) / beta - V[:, k] * c_last
+__global__ __launch_bounds__(256) void k_axpy2(double* __restrict__ V, int64_t ldv, int64_t n, int k,
+                                               const double* __restrict__ cf, int m, double* __restrict__ u,
+                                               const double* __restrict__ w) {
+    __shared__ double sh_s[1024], sh_t[1024];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < k; c += 256) {
+        sh_s[c] = cf[c];
+        sh_t[c] = cf[m + c];
+    }
+    __syncthreads();
+    const double ib = cf[2 * m], cl = cf[2 * m + 1];
+    const int64_t r = (int64_t)blockIdx.x * AX_ROWS + 2 * tid;
+    double2 as = {0.0, 0.0}, at = {0.0, 0.0};
+    int c = 0;
+    for (; c + 8 <= k; c += 8) {
+        double2 q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = ld2(V + (int64_t)(c + j) * ldv, r, n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            as.x += sh_s[c + j] * q[j].x;
+            as.y += sh_s[c + j] * q[j].y;
+            at.x += sh_t[c + j] * q[j].x;
+            at.y += sh_t[c + j] * q[j].y;
+        }
+    }
+    for (; c < k; ++c) {
+        const double2 q = ld2(V + (int64_t)c * ldv, r, n);
+        as.x += sh_s[c] * q.x;
+        as.y += sh_s[c] * q.y;
+        at.x += sh_t[c] * q.x;
+        at.y += sh_t[c] * q.y;
+    }
+    const double2 uu = ld2(u, r, n), ww = ld2(w, r, n);
+    double2 vn, un;
+    vn.x = (uu.x - as.x) * ib;
+    vn.y = (uu.y - as.y) * ib;
+    un.x = (ww.x - at.x) * ib - vn.x * cl;
+    un.y = (ww.y - at.y) * ib - vn.y * cl;
+    double* vk = V + (int64_t)k * ldv;
+    if (r + 1 < n) {
+        *reinterpret_cast<double2*>(vk + r) = vn;
+        *reinterpret_cast<double2*>(u + r) = un;
+    } else if (r < n) {
+        vk[r] = vn.x;
+        u[r] = un.x;
+    }
+}
+
 __global__ void k_axpby(double a, const double* __restrict__ x, double b, const double* __restrict__ y,
                         double* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,8 +491,166 @@ int allreduce_sum(fedd_ctx* c, double* d_buf, int n) {
     return 0;
 }
 
+// GMRES with the delayed second Gram-Schmidt pass (kernels and formulas above).  Same iterates as
+// the two-pass variant below in exact arithmetic; one operator application more per restart cycle
+// (the lag), half the passes over the basis and one all-reduce per iteration.
+static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart,
+                             int use_prec, int* its_out, double* relres_out) {
+    const int64_t n = c->n_rows;
+    const int m = std::min(restart, max_it);
+    const int64_t ldv = (n + 15) & ~(int64_t)15;
+    FEDD_CHECK(m + 2 <= 1024, "gmres: restart length above 1022 is not supported");
+    const int nblk = (int)((n + MD_ROWS - 1) / MD_ROWS), nblk2 = (int)((n + AX_ROWS - 1) / AX_ROWS);
+    FEDD_TRY(c->d_V.ensure((size_t)(m + 1) * ldv));
+    FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)2 * n, c->d_w.cap)));   // u | w~
+    FEDD_TRY(c->d_Z.ensure((size_t)n * 2));
+    FEDD_TRY(c->d_part.ensure(std::max((size_t)(2 * m + 4) * nblk, (size_t)nblk2)));
+    Off o;
+    Off2 o2;
+    int p = 0;
+    o.H = p; p += (m + 1) * m;
+    o.cs = p; p += m;
+    o.sn = p; p += m;
+    o.g = p; p += m + 1;
+    o.h1 = p; p += m + 2;
+    o.h2 = p; p += m + 2;
+    o.nrm = p; p += 4;
+    o.y = p; p += m;
+    o.misc = p; p += 8;
+    o2.Hraw = p; p += (m + 1) * m;
+    o2.hp = p; p += m + 2;
+    o2.st = p; p += 2 * m + 4;
+    o2.cf = p; p += 2 * m + 4;
+    FEDD_TRY(c->d_small.ensure((size_t)p + 8));
+    double* S = c->d_small.p;
+    double* V = c->d_V.p;
+    double* u = c->d_w.p;        // first-pass result / next basis vector before its second pass
+    double* wt = c->d_w.p + n;   // B u
+    double* z = c->d_Z.p;        // M^-1 v
+    double* r = c->d_Z.p + n;    // residual / V y
+    const dim3 gn((unsigned)((n + 255) / 256)), blk(256);
+    hipStream_t st = c->stream;
+
+    auto norm2_into = [&](const double* v, double* out) -> int {
+        hipLaunchKernelGGL(k_multidot, dim3(nblk, 1), blk, 0, st, v, ldv, n, 0, v, c->d_part.p, nblk, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, out, nblk, (const int32_t*)nullptr);
+        return allreduce_sum(c, out, 1);
+    };
+    auto apply_B = [&](const double* in, double* out) -> int {  // out = A M^-1 in
+        if (use_prec) FEDD_TRY(schwarz_apply(c, in, z));
+        return spmv_owned(c, use_prec ? z : in, out);
+    };
+
+    FEDD_HIP(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), st));  // "Zero Initial Guess" (LinearSolver_def.hpp:76-78)
+    FEDD_HIP(hipMemcpyAsync(r, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    FEDD_TRY(norm2_into(r, S + o.nrm + 3));
+    FEDD_HIP(hipMemcpyAsync(c->h_pinned, S + o.nrm + 3, sizeof(double), hipMemcpyDeviceToHost, st));
+    FEDD_HIP(hipStreamSynchronize(st));
+    const double beta0 = std::sqrt(c->h_pinned[0]);
+    int its = 0;
+    double relres = beta0 > 0 ? 1.0 : 0.0;
+    if (!(beta0 > 0)) {
+        if (its_out) *its_out = 0;
+        if (relres_out) *relres_out = 0.0;
+        return 0;
+    }
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int q = 0; q < 2; ++q) FEDD_HIP(hipEventCreateWithFlags(&ev[q], hipEventDisableTiming));
+    struct EvGuard {
+        hipEvent_t* e;
+        ~EvGuard() {
+            for (int q = 0; q < 2; ++q)
+                if (e[q]) (void)hipEventDestroy(e[q]);
+        }
+    } ev_guard{ev};
+    bool converged = false;
+    while (!converged && its < max_it) {
+        // v_1 = r / ||r||, then the (not delayed) first pass of B v_1: hp = v_1 . w, u = w - v_1 hp
+        hipLaunchKernelGGL(k_cycle_init, dim3(1), dim3(1), 0, st, S, o, m, (const double*)(S + o.nrm + 3));
+        hipLaunchKernelGGL(k_scale_to, gn, blk, 0, st, (const double*)r, (const double*)(S + o.misc + 1), V, n);
+        FEDD_TRY(apply_B(V, u));
+        {
+            ScopedTimer t(c, FEDD_T_ORTHO);
+            hipLaunchKernelGGL(k_multidot, dim3(nblk, 1), blk, 0, st, (const double*)V, ldv, n, 1, (const double*)u,
+                               c->d_part.p, nblk, (const int32_t*)nullptr);
+            hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, S + o2.hp, nblk,
+                               (const int32_t*)nullptr);
+            FEDD_TRY(allreduce_sum(c, S + o2.hp, 1));
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk2), blk, 0, st, (const double*)V, ldv, n, 1, (const double*)(S + o2.hp),
+                               u, c->d_part.p, (const int32_t*)nullptr);
+            t.stop();
+        }
+        int kfin = 0;  // finalised columns of this cycle
+        int issued = its, checked = 0, queued = 0;
+        auto check = [&](int jj) -> int {
+            if (hipEventSynchronize(ev[jj & 1]) != hipSuccess) return -1;
+            const double* hp = c->h_pinned + 4 * (jj & 1);
+            ++its;
+            ++checked;
+            kfin = jj + 1;
+            relres = hp[0] / beta0;
+            const bool breakdown = !(hp[2] > 0.0);
+            return (relres <= rtol || breakdown) ? 1 : 0;
+        };
+        for (int j = 0; j < m && issued < max_it; ++j) {
+            const int k = j + 1;  // basis vectors final before this step; the step finalises column j of H
+            FEDD_TRY(apply_B(u, wt));
+            {
+                ScopedTimer t(c, FEDD_T_ORTHO);
+                hipLaunchKernelGGL(k_multidot2, dim3(nblk, (k + 1 + MD_CG - 1) / MD_CG), blk, 0, st, (const double*)V, ldv, n,
+                                   k, (const double*)u, (const double*)wt, c->d_part.p, nblk);
+                hipLaunchKernelGGL(k_reduce_cols, dim3(2 * k + 2), blk, 0, st, (const double*)c->d_part.p, S + o2.st, nblk,
+                                   (const int32_t*)nullptr);
+                FEDD_TRY(allreduce_sum(c, S + o2.st, 2 * k + 2));
+                hipLaunchKernelGGL(k_dcgs2_small, dim3(1), blk, (size_t)(6 * m + 8) * sizeof(double), st, S, o, o2, k, m);
+                if (k < m)  // the last step of a cycle needs no further basis vector
+                    hipLaunchKernelGGL(k_axpy2, dim3(nblk2), blk, 0, st, V, ldv, n, k, (const double*)(S + o2.cf), m, u,
+                                       (const double*)wt);
+                t.stop();
+            }
+            FEDD_HIP(hipMemcpyAsync(c->h_pinned + 4 * (j & 1), S + o.misc, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            FEDD_HIP(hipEventRecord(ev[j & 1], st));
+            ++issued;
+            ++queued;
+            if (j > 0) {
+                const int rc = check(j - 1);
+                FEDD_CHECK(rc >= 0, "gmres: waiting for iteration %d failed", j - 1);
+                if (rc) {
+                    converged = true;
+                    break;
+                }
+            }
+        }
+        if (!converged && checked < queued) {
+            const int rc = check(queued - 1);
+            FEDD_CHECK(rc >= 0, "gmres: waiting for iteration %d failed", queued - 1);
+            converged = rc != 0;
+        }
+        // x += M^-1 (V y) with the kfin finalised columns
+        hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(kfin + 1) * sizeof(double), st, S, o, kfin, m);
+        hipLaunchKernelGGL(k_combine, gn, blk, 0, st, (const double*)V, ldv, n, kfin, (const double*)(S + o.y), r);
+        if (use_prec) {
+            FEDD_TRY(schwarz_apply(c, r, z));
+            hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)z, d_x, n);
+        } else {
+            hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)r, d_x, n);
+        }
+        if (!converged && its < max_it) {
+            FEDD_TRY(spmv_owned(c, d_x, r));
+            hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, d_b, -1.0, (const double*)r, r, n);
+            FEDD_TRY(norm2_into(r, S + o.nrm + 3));
+        }
+    }
+    FEDD_HIP(hipGetLastError());
+    FEDD_HIP(hipStreamSynchronize(st));
+    if (its_out) *its_out = its;
+    if (relres_out) *relres_out = relres;
+    return 0;
+}
+
 int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart, int use_prec,
                 int* its_out, double* relres_out) {
+    if (c->gmres_kind == 0) return gmres_solve_dcgs2(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
     const int64_t n = c->n_rows;
     const int m = std::min(restart, max_it);
     const int64_t ldv = (n + 15) & ~(int64_t)15;  // 128-byte aligned basis columns
