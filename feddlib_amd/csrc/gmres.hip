@@ -6,10 +6,13 @@
 // orthogonalisation, relative residual tolerance, maximum iterations) and the preconditioner
 // attached as Thyra "unspecified" side = right.  Belos is not in the reference tree; this is the
 // published algorithm (Saad, Iterative Methods, Alg. 9.5):
-//   - classical Gram-Schmidt as one fused multi-dot + one fused multi-axpy over the Krylov basis,
-//     second pass only when ||w_new|| < ||w_old|| / sqrt(2) (the DGKS test), decided on the device;
+//   - classical Gram-Schmidt with two passes (what Belos' DGKS / ICGS managers do), default
+//     formulation: the second pass of a basis vector is delayed and fused with the first pass of
+//     the next Krylov vector (DCGS2, see k_multidot2 below): two sweeps over the basis and one
+//     reduction per iteration.  fedd_set_option("gmres_kind", 1) selects the plain two-pass form
+//     (fused multi-dot + multi-axpy twice, second pass gated by the DGKS test on the device);
 //   - Givens QR of the Hessenberg matrix on the device (single lane), the host reads one double
-//     per iteration (implicit relative residual) to decide convergence;
+//     per iteration (implicit relative residual) to decide convergence, one iteration behind;
 //   - x = x0 + M^-1 (V y) at the end of a cycle (M is a fixed linear operator, so Z is not stored).
 // All sums run in a fixed order: results are bitwise reproducible run to run.
 #include "fedd_internal.hpp"
@@ -22,6 +25,7 @@ namespace {
 
 constexpr int MD_ROWS = 2048;  // rows per workgroup of the multi-dot (256 lanes x 4 x double2)
 constexpr int MD_CG = 8;       // basis columns per workgroup of the multi-dot
+constexpr int MD2_CG = 8;      // basis columns per workgroup of the two-vector multi-dot (16: 13 % slower)
 constexpr int AX_ROWS = 512;   // rows per workgroup of the multi-axpy (256 lanes x double2)
 
 __device__ __forceinline__ double2 ld2(const double* __restrict__ p, int64_t r, int64_t n) {
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256) void k_combine(const double* __restrict__ V, i
 __global__ __launch_bounds__(256) void k_multidot2(const double* __restrict__ V, int64_t ldv, int64_t n, int ncolsV,
                                                    const double* __restrict__ u, const double* __restrict__ w,
                                                    double* __restrict__ partial, int nblk) {
-    __shared__ double sh[4][2 * MD_CG];
+    __shared__ double sh[4][2 * MD2_CG];
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * MD_ROWS + 2 * tid;
     double2 uv[4], wv[4];
@@ -281,10 +285,10 @@ __global__ __launch_bounds__(256) void k_multidot2(const double* __restrict__ V,
         uv[k] = ld2(u, r0 + 512 * k, n);
         wv[k] = ld2(w, r0 + 512 * k, n);
     }
-    double au[MD_CG], aw[MD_CG];
+    double au[MD2_CG], aw[MD2_CG];
 #pragma unroll
-    for (int cc = 0; cc < MD_CG; ++cc) {
-        const int col = blockIdx.y * MD_CG + cc;
+    for (int cc = 0; cc < MD2_CG; ++cc) {
+        const int col = blockIdx.y * MD2_CG + cc;
         double su = 0.0, sw = 0.0;
         if (col <= ncolsV) {
             const double* __restrict__ a = col < ncolsV ? V + (int64_t)col * ldv : u;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256) void k_multidot2(const double* __restrict__ V,
         aw[cc] = sw;
     }
 #pragma unroll
-    for (int cc = 0; cc < MD_CG; ++cc) {
+    for (int cc = 0; cc < MD2_CG; ++cc) {
         double su = au[cc], sw = aw[cc];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -312,8 +316,8 @@ __global__ __launch_bounds__(256) void k_multidot2(const double* __restrict__ V,
         }
     }
     __syncthreads();
-    if (tid < 2 * MD_CG) {
-        const int col = blockIdx.y * MD_CG + (tid >> 1);
+    if (tid < 2 * MD2_CG) {
+        const int col = blockIdx.y * MD2_CG + (tid >> 1);
         if (col <= ncolsV)
             partial[(int64_t)(2 * col + (tid & 1)) * nblk + blockIdx.x] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
     }
@@ -374,8 +378,18 @@ __global__ __launch_bounds__(256) void k_dcgs2_small(double* __restrict__ S, Off
     __syncthreads();
     // Hs = Hbar_k s  (rows 0..k, columns 0..kc; entries below the sub-diagonal are zero)
     for (int i = tid; i <= k; i += 256) {
+        // (eight independent loads in flight: the Hessenberg matrix is read from L2, and a chain of
+        // dependent-latency loads was the whole cost of this kernel)
         double a = 0.0;
-        for (int c = (i > 0 ? i - 1 : 0); c < kc; ++c) a += Hraw[(int64_t)c * ldh + i] * s[c];
+        int c = i > 0 ? i - 1 : 0;
+        for (; c + 8 <= kc; c += 8) {
+            double hv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hv[q] = Hraw[(int64_t)(c + q) * ldh + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a += hv[q] * s[c + q];
+        }
+        for (; c < kc; ++c) a += Hraw[(int64_t)c * ldh + i] * s[c];
         a += hc[i] * s[kc];  // the column written above, taken from LDS
         Hs[i] = a;
     }
@@ -597,7 +611,7 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
             FEDD_TRY(apply_B(u, wt));
             {
                 ScopedTimer t(c, FEDD_T_ORTHO);
-                hipLaunchKernelGGL(k_multidot2, dim3(nblk, (k + 1 + MD_CG - 1) / MD_CG), blk, 0, st, (const double*)V, ldv, n,
+                hipLaunchKernelGGL(k_multidot2, dim3(nblk, (k + 1 + MD2_CG - 1) / MD2_CG), blk, 0, st, (const double*)V, ldv, n,
                                    k, (const double*)u, (const double*)wt, c->d_part.p, nblk);
                 hipLaunchKernelGGL(k_reduce_cols, dim3(2 * k + 2), blk, 0, st, (const double*)c->d_part.p, S + o2.st, nblk,
                                    (const int32_t*)nullptr);

@@ -148,3 +148,29 @@ def test_repeated_setup_on_one_context(fedd_lib, ctx):
     ctx.schwarz_set_coarse(8)
     with pytest.raises(fedd_lib.FeddError, match="27 coarse dofs for 8 free dofs"):
         ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
+
+
+@pytest.mark.parametrize("two_level", [0, 1])
+def test_delayed_and_plain_gram_schmidt_give_the_same_iterates(fedd_lib, ctx, two_level):
+    """gmres_kind 0 (DCGS2, delayed second pass) and 1 (plain two-pass CGS2) are the same method in
+    exact arithmetic: same iteration count, same residual history end point, same solution."""
+    m, A_bc, rhs_bc, _ = laplace(fedd_lib, ctx, 3, 14)
+    ctx.schwarz_set_target(27, 1.0)
+    ctx.schwarz_set_coarse(27)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=two_level, coarse_kind=fedd_lib.COARSE_Q1 if two_level else 0)
+    res = {}
+    for kind in (0, 1):
+        ctx.set_option("gmres_kind", kind)
+        for rtol, restart in ((1e-8, 100), (1e-12, 7)):
+            res[(kind, rtol)] = ctx.gmres(None, rtol=rtol, max_it=500, restart=restart, use_prec=True)
+    ctx.set_option("gmres_kind", 0)
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    for rtol in (1e-8, 1e-12):
+        x0, its0, rel0 = res[(0, rtol)]
+        x1, its1, rel1 = res[(1, rtol)]
+        assert abs(its0 - its1) <= 1 and rel0 <= rtol and rel1 <= rtol
+        np.testing.assert_allclose(x0, x1, rtol=0, atol=10 * rtol * np.abs(xd).max())
+    np.testing.assert_allclose(res[(0, 1e-12)][0], xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+    # explicit residual of the delayed variant (the lagged recurrences must not drift from b - A x)
+    x0 = res[(0, 1e-12)][0]
+    assert np.linalg.norm(rhs_bc - A_bc @ x0) / np.linalg.norm(rhs_bc) < 1e-10
