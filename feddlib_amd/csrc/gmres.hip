@@ -285,41 +285,45 @@ __global__ __launch_bounds__(256) void k_multidot2(const double* __restrict__ V,
         uv[k] = ld2(u, r0 + 512 * k, n);
         wv[k] = ld2(w, r0 + 512 * k, n);
     }
-    double au[MD2_CG], aw[MD2_CG];
+    // column groups cg = blockIdx.y, blockIdx.y + gridDim.y, ...: u and w stay in registers across them
+    for (int cg = blockIdx.y; cg * MD2_CG <= ncolsV; cg += gridDim.y) {
+        double au[MD2_CG], aw[MD2_CG];
 #pragma unroll
-    for (int cc = 0; cc < MD2_CG; ++cc) {
-        const int col = blockIdx.y * MD2_CG + cc;
-        double su = 0.0, sw = 0.0;
-        if (col <= ncolsV) {
-            const double* __restrict__ a = col < ncolsV ? V + (int64_t)col * ldv : u;
+        for (int cc = 0; cc < MD2_CG; ++cc) {
+            const int col = cg * MD2_CG + cc;
+            double su = 0.0, sw = 0.0;
+            if (col <= ncolsV) {
+                const double* __restrict__ a = col < ncolsV ? V + (int64_t)col * ldv : u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double2 v = ld2(a, r0 + 512 * k, n);
-                su += v.x * uv[k].x + v.y * uv[k].y;
-                sw += v.x * wv[k].x + v.y * wv[k].y;
+                for (int k = 0; k < 4; ++k) {
+                    const double2 v = ld2(a, r0 + 512 * k, n);
+                    su += v.x * uv[k].x + v.y * uv[k].y;
+                    sw += v.x * wv[k].x + v.y * wv[k].y;
+                }
+            }
+            au[cc] = su;
+            aw[cc] = sw;
+        }
+#pragma unroll
+        for (int cc = 0; cc < MD2_CG; ++cc) {
+            double su = au[cc], sw = aw[cc];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                su += __shfl_down(su, off, 64);
+                sw += __shfl_down(sw, off, 64);
+            }
+            if ((tid & 63) == 0) {
+                sh[tid >> 6][2 * cc] = su;
+                sh[tid >> 6][2 * cc + 1] = sw;
             }
         }
-        au[cc] = su;
-        aw[cc] = sw;
-    }
-#pragma unroll
-    for (int cc = 0; cc < MD2_CG; ++cc) {
-        double su = au[cc], sw = aw[cc];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            su += __shfl_down(su, off, 64);
-            sw += __shfl_down(sw, off, 64);
+        __syncthreads();
+        if (tid < 2 * MD2_CG) {
+            const int col = cg * MD2_CG + (tid >> 1);
+            if (col <= ncolsV)
+                partial[(int64_t)(2 * col + (tid & 1)) * nblk + blockIdx.x] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
         }
-        if ((tid & 63) == 0) {
-            sh[tid >> 6][2 * cc] = su;
-            sh[tid >> 6][2 * cc + 1] = sw;
-        }
-    }
-    __syncthreads();
-    if (tid < 2 * MD2_CG) {
-        const int col = blockIdx.y * MD2_CG + (tid >> 1);
-        if (col <= ncolsV)
-            partial[(int64_t)(2 * col + (tid & 1)) * nblk + blockIdx.x] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+        __syncthreads();
     }
 }
 
@@ -577,6 +581,7 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
                 if (e[q]) (void)hipEventDestroy(e[q]);
         }
     } ev_guard{ev};
+    const int md2_gy = 1024;  // column groups per grid row of k_multidot2: all of them (1, 2, 4 measured: no gain)
     bool converged = false;
     while (!converged && its < max_it) {
         // v_1 = r / ||r||, then the (not delayed) first pass of B v_1: hp = v_1 . w, u = w - v_1 hp
@@ -611,7 +616,7 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
             FEDD_TRY(apply_B(u, wt));
             {
                 ScopedTimer t(c, FEDD_T_ORTHO);
-                hipLaunchKernelGGL(k_multidot2, dim3(nblk, (k + 1 + MD2_CG - 1) / MD2_CG), blk, 0, st, (const double*)V, ldv, n,
+                hipLaunchKernelGGL(k_multidot2, dim3(nblk, std::min(md2_gy, (k + 1 + MD2_CG - 1) / MD2_CG)), blk, 0, st, (const double*)V, ldv, n,
                                    k, (const double*)u, (const double*)wt, c->d_part.p, nblk);
                 hipLaunchKernelGGL(k_reduce_cols, dim3(2 * k + 2), blk, 0, st, (const double*)c->d_part.p, S + o2.st, nblk,
                                    (const int32_t*)nullptr);
