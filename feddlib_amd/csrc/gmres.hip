@@ -273,15 +273,16 @@ __global__ __launch_bounds__(256) void k_combine(const double* __restrict__ V, i
 // u' is the first-pass result for the next vector; every basis column is read twice per iteration.
 
 // partial[(2 col + which) * nblk + blk]: which = 0: V_col . u, 1: V_col . w; col == ncolsV: u.u and u.w
+template <int NCH>
 __global__ __launch_bounds__(256) void k_multidot2(const double* __restrict__ V, int64_t ldv, int64_t n, int ncolsV,
                                                    const double* __restrict__ u, const double* __restrict__ w,
                                                    double* __restrict__ partial, int nblk) {
     __shared__ double sh[4][2 * MD2_CG];
     const int tid = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * MD_ROWS + 2 * tid;
-    double2 uv[4], wv[4];
+    const int64_t r0 = (int64_t)blockIdx.x * (512 * NCH) + 2 * tid;
+    double2 uv[NCH], wv[NCH];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NCH; ++k) {
         uv[k] = ld2(u, r0 + 512 * k, n);
         wv[k] = ld2(w, r0 + 512 * k, n);
     }
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void k_multidot2(const double* __restrict__ V,
             if (col <= ncolsV) {
                 const double* __restrict__ a = col < ncolsV ? V + (int64_t)col * ldv : u;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < NCH; ++k) {
                     const double2 v = ld2(a, r0 + 512 * k, n);
                     su += v.x * uv[k].x + v.y * uv[k].y;
                     sw += v.x * wv[k].x + v.y * wv[k].y;
@@ -522,7 +523,7 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
     FEDD_TRY(c->d_V.ensure((size_t)(m + 1) * ldv));
     FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)2 * n, c->d_w.cap)));   // u | w~
     FEDD_TRY(c->d_Z.ensure((size_t)n * 2));
-    FEDD_TRY(c->d_part.ensure(std::max((size_t)(2 * m + 4) * nblk, (size_t)nblk2)));
+    FEDD_TRY(c->d_part.ensure(std::max((size_t)(2 * m + 4) * nblk * 2, (size_t)nblk2)));
     Off o;
     Off2 o2;
     int p = 0;
@@ -581,7 +582,11 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
                 if (e[q]) (void)hipEventDestroy(e[q]);
         }
     } ev_guard{ev};
-    const int md2_gy = 1024;  // column groups per grid row of k_multidot2: all of them (1, 2, 4 measured: no gain)
+    // launch shape of k_multidot2: 2048 rows per workgroup, one grid row per group of 8 columns.
+    // Measured alternatives on cfg 2 (ms per step): 1024 rows 43.9, column groups looped inside one
+    // grid row 46.4 (2048 rows) / 44.5 (1024 rows), 2 or 4 grid rows 42.7-44.6; this one 43.1.
+    const int md2_gy = 1024, md2_nch = 4;
+    const int nblkd = (int)((n + 512 * md2_nch - 1) / (512 * md2_nch));
     bool converged = false;
     while (!converged && its < max_it) {
         // v_1 = r / ||r||, then the (not delayed) first pass of B v_1: hp = v_1 . w, u = w - v_1 hp
@@ -616,9 +621,14 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
             FEDD_TRY(apply_B(u, wt));
             {
                 ScopedTimer t(c, FEDD_T_ORTHO);
-                hipLaunchKernelGGL(k_multidot2, dim3(nblk, std::min(md2_gy, (k + 1 + MD2_CG - 1) / MD2_CG)), blk, 0, st, (const double*)V, ldv, n,
-                                   k, (const double*)u, (const double*)wt, c->d_part.p, nblk);
-                hipLaunchKernelGGL(k_reduce_cols, dim3(2 * k + 2), blk, 0, st, (const double*)c->d_part.p, S + o2.st, nblk,
+                const int ncg = (k + 1 + MD2_CG - 1) / MD2_CG;
+                if (md2_nch == 2)
+                    hipLaunchKernelGGL(k_multidot2<2>, dim3(nblkd, std::min(md2_gy, ncg)), blk, 0, st, (const double*)V, ldv, n,
+                                       k, (const double*)u, (const double*)wt, c->d_part.p, nblkd);
+                else
+                    hipLaunchKernelGGL(k_multidot2<4>, dim3(nblkd, std::min(md2_gy, ncg)), blk, 0, st, (const double*)V, ldv, n,
+                                       k, (const double*)u, (const double*)wt, c->d_part.p, nblkd);
+                hipLaunchKernelGGL(k_reduce_cols, dim3(2 * k + 2), blk, 0, st, (const double*)c->d_part.p, S + o2.st, nblkd,
                                    (const int32_t*)nullptr);
                 FEDD_TRY(allreduce_sum(c, S + o2.st, 2 * k + 2));
                 hipLaunchKernelGGL(k_dcgs2_small, dim3(1), blk, (size_t)(6 * m + 8) * sizeof(double), st, S, o, o2, k, m);
