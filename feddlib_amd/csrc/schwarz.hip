@@ -530,7 +530,14 @@ __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ 
     const int last = ((total + 1) & ~1) - 2;
     double2 a[AP_BATCH];
 #pragma unroll
-    for (int k = 0; k < AP_BATCH; ++k) a[k] = *reinterpret_cast<const double2*>(slab + min(2 * tid + 512 * k, last));
+    for (int k = 0; k < AP_BATCH; ++k) {
+        // streamed once per application: non-temporal, so that 0.8 GB of slabs do not push the system
+        // matrix and the vectors out of the Infinity Cache between two SpMVs
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(slab + min(2 * tid + 512 * k, last)));
+        a[k].x = t.x;
+        a[k].y = t.y;
+    }
     const double rv = r[d];
     if (tid < n) {
         sdof[tid] = d;

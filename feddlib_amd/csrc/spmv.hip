@@ -51,6 +51,8 @@ __global__ void k_spmv_block_rows(const int32_t* __restrict__ rowptr, int32_t n_
     block_row[b] = lo;
 }
 
+// (non-temporal loads of the matrix stream were tried: slower in the solver, 41.9 vs 40.8 ms per step;
+// the slabs of the Schwarz apply and the Krylov basis are the streams that are loaded non-temporally)
 __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ colind,
                                                      const double* __restrict__ val, const double* __restrict__ x,
