@@ -28,6 +28,15 @@ constexpr int MD_CG = 8;       // basis columns per workgroup of the multi-dot
 constexpr int MD2_CG = 8;      // basis columns per workgroup of the two-vector multi-dot (16: 13 % slower)
 constexpr int AX_ROWS = 512;   // rows per workgroup of the multi-axpy (256 lanes x double2)
 
+// cached load for the work vectors (u, w): every column group of the multi-dot re-reads them
+__device__ __forceinline__ double2 ld2c(const double* __restrict__ p, int64_t r, int64_t n) {
+    if (r + 1 < n) return *reinterpret_cast<const double2*>(p + r);
+    double2 v;
+    v.x = r < n ? p[r] : 0.0;
+    v.y = 0.0;
+    return v;
+}
+
 __device__ __forceinline__ double2 ld2(const double* __restrict__ p, int64_t r, int64_t n) {
     // basis columns are streamed (each is read twice per iteration, 0.8 GB apart): non-temporal loads
     // keep them from displacing the vectors and the matrix in L2 / Infinity Cache (-1.5 ms per step)
@@ -57,7 +66,7 @@ __global__ __launch_bounds__(256) void k_multidot(const double* __restrict__ V, 
     const int64_t r0 = (int64_t)blockIdx.x * MD_ROWS + 2 * tid;
     double2 wv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) wv[k] = ld2(w, r0 + 512 * k, n);
+    for (int k = 0; k < 4; ++k) wv[k] = ld2c(w, r0 + 512 * k, n);
     double acc[MD_CG];
 #pragma unroll
     for (int cc = 0; cc < MD_CG; ++cc) {
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(256) void k_multiaxpy(const double* __restrict__ V,
     for (int c = tid; c < ncols; c += 256) sh_h[c] = h[c];
     __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * AX_ROWS + 2 * tid;
-    double2 v = ld2(w, r, n);
+    double2 v = ld2c(w, r, n);
     int c = 0;
     for (; c + 8 <= ncols; c += 8) {
         double2 t[8];
@@ -292,8 +301,8 @@ __global__ __launch_bounds__(256) void k_multidot2(const double* __restrict__ V,
     double2 uv[NCH], wv[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-        uv[k] = ld2(u, r0 + 512 * k, n);
-        wv[k] = ld2(w, r0 + 512 * k, n);
+        uv[k] = ld2c(u, r0 + 512 * k, n);
+        wv[k] = ld2c(w, r0 + 512 * k, n);
     }
     // column groups cg = blockIdx.y, blockIdx.y + gridDim.y, ...: u and w stay in registers across them
     for (int cg = blockIdx.y; cg * MD2_CG <= ncolsV; cg += gridDim.y) {
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(256) void k_axpy2(double* __restrict__ V, int64_t l
         at.x += sh_t[c] * q.x;
         at.y += sh_t[c] * q.y;
     }
-    const double2 uu = ld2(u, r, n), ww = ld2(w, r, n);
+    const double2 uu = ld2c(u, r, n), ww = ld2c(w, r, n);
     double2 vn, un;
     vn.x = (uu.x - as.x) * ib;
     vn.y = (uu.y - as.y) * ib;
