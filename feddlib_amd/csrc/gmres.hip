@@ -494,7 +494,13 @@ __global__ __launch_bounds__(256) void k_axpy2(double* __restrict__ V, int64_t l
     un.y = (ww.y - at.y) * ib - vn.y * cl;
     double* vk = V + (int64_t)k * ldv;
     if (r + 1 < n) {
-        *reinterpret_cast<double2*>(vk + r) = vn;
+        {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d tv;
+            tv.x = vn.x;
+            tv.y = vn.y;
+            __builtin_nontemporal_store(tv, reinterpret_cast<v2d*>(vk + r));  // next read is a basis sweep
+        }
         *reinterpret_cast<double2*>(u + r) = un;
     } else if (r < n) {
         vk[r] = vn.x;

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
 #pragma unroll
         for (int bb = 0; bb < T; ++bb) {
             const int j = tx + 16 * bb;
-            if (j < n) slab[(int64_t)j * rp + i] = i < nrow ? A[a][bb] : 0.0;
+            if (j < n) __builtin_nontemporal_store(i < nrow ? A[a][bb] : 0.0, slab + (int64_t)j * rp + i);
         }
     }
 }
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ 
     const int n = sub_n[b], nrow = sub_nown[b];
     const int total = n * nrow;
     const double* __restrict__ slab = inv + inv_ptr[b];
-    const int32_t d = sub_dofs[(int64_t)b * NMAX + tid];  // entries past n hold dof 0 (k_sub_dofs)
+    const int32_t d = __builtin_nontemporal_load(sub_dofs + (int64_t)b * NMAX + tid);  // entries past n hold dof 0 (k_sub_dofs)
     // slabs are padded to a multiple of 16 doubles: the 16-byte load of an odd tail stays inside
     const int last = ((total + 1) & ~1) - 2;
     double2 a[AP_BATCH];
