@@ -212,7 +212,7 @@ __device__ __forceinline__ int bsearch_i32(const int32_t* a, int n, int32_t v) {
 // is a compile-time constant (outer loop unrolled), so no register array is indexed dynamically.
 // Rows/columns n..16T-1 are identity padding.  No pivoting: see k_invert's note.
 template <int T>
-__global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict__ sub_n,
+__global__ __launch_bounds__(256, (T <= 7 ? 4 : 2)) void k_invert_reg(const int32_t* __restrict__ sub_n,
                                                        const int32_t* __restrict__ sub_nown,
                                                        const int32_t* __restrict__ sub_dofs,
                                                        const int32_t* __restrict__ rowptr,
@@ -329,27 +329,24 @@ __global__ __launch_bounds__(256, 2) void k_invert_reg(const int32_t* __restrict
             double pinv = __builtin_amdgcn_rcp(piv);
             pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);
             pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);
-            double cc[T], rr[T];
+            double cc[T];
 #pragma unroll
             for (int a = 0; a < T; ++a) cc[a] = colbuf[buf][ty + 16 * a];
+            const bool prow = ty == kc;
+            const bool pcol = col_wave && tx == kc;
+            if (prow) cc[kb] = -1.0;
 #pragma unroll
-            for (int bb = 0; bb < T; ++bb) rr[bb] = rowbuf[buf][tx + 16 * bb] * pinv;
-            if (ty == kc) {
-                cc[kb] = -1.0;
+            for (int bb = 0; bb < T; ++bb) {
+                double r_b = rowbuf[buf][tx + 16 * bb] * pinv;
+                if (bb == kb) r_b = pcol ? pinv : r_b;
 #pragma unroll
-                for (int bb = 0; bb < T; ++bb) A[kb][bb] = 0.0;
-            }
-            if (col_wave) {
-                if (tx == kc) {
-                    rr[kb] = pinv;
-#pragma unroll
-                    for (int a = 0; a < T; ++a) A[a][kb] = 0.0;
+                for (int a = 0; a < T; ++a) {
+                    double av = A[a][bb];
+                    if (a == kb) av = prow ? 0.0 : av;
+                    if (bb == kb) av = pcol ? 0.0 : av;
+                    A[a][bb] = fma(-cc[a], r_b, av);
                 }
             }
-#pragma unroll
-            for (int a = 0; a < T; ++a)
-#pragma unroll
-                for (int bb = 0; bb < T; ++bb) A[a][bb] = fma(-cc[a], rr[bb], A[a][bb]);
         }
     }
     }
