@@ -62,18 +62,35 @@ __global__ __launch_bounds__(64) void k_node_pattern(const int32_t* __restrict__
     const int32_t r = blockIdx.x * 64 + lane;
     if (r >= n_own) return;
     int len = 0;
-    for (int32_t p = n2e_ptr[r]; p < n2e_ptr[r + 1]; ++p) {
-        const int32_t e = n2e[p] / nen;
-        for (int j = 0; j < nen; ++j) {
-            const int32_t col = conn[(int64_t)e * nen + j];
-            int pos = 0;
-            while (pos < len && lst[pos * 64 + lane] < col) ++pos;
-            if (pos < len && lst[pos * 64 + lane] == col) continue;
-            if (len < cap) {
-                for (int k = len; k > pos; --k) lst[k * 64 + lane] = lst[(k - 1) * 64 + lane];
-                lst[pos * 64 + lane] = col;
-                ++len;
-            }
+    auto insert = [&](int32_t col) {
+        int pos = 0;
+        while (pos < len && lst[pos * 64 + lane] < col) ++pos;
+        if (pos < len && lst[pos * 64 + lane] == col) return;
+        if (len < cap) {
+            for (int k = len; k > pos; --k) lst[k * 64 + lane] = lst[(k - 1) * 64 + lane];
+            lst[pos * 64 + lane] = col;
+            ++len;
+        }
+    };
+    // The incident elements are taken eight at a time: their ids, then their first four node ids, are
+    // loaded as independent requests (two memory latencies per batch instead of two per element);
+    // nodes beyond the fourth (P2) follow one by one.  Insertion order is unchanged.
+    const int32_t pb = n2e_ptr[r], pe = n2e_ptr[r + 1];
+    for (int32_t p0 = pb; p0 < pe; p0 += 8) {
+        int32_t ee[8], c4[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ee[u] = p0 + u < pe ? n2e[p0 + u] / nen : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c4[u][j] = (ee[u] >= 0 && j < nen) ? conn[(int64_t)ee[u] * nen + j] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (ee[u] < 0) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c4[u][j] >= 0) insert(c4[u][j]);
+            for (int j = 4; j < nen; ++j) insert(conn[(int64_t)ee[u] * nen + j]);
         }
     }
     if (!FILL) {
