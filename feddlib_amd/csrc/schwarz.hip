@@ -816,7 +816,9 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned) {
                                (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned);
         t.stop();
     } else {
-        FEDD_CHECK(c->nranks == 1, "schwarz apply: Averaging/Full combine across ranks needs the halo export (not built yet); use Restricted");
+        // Several ranks: what a rank's subdomains contribute to its ghost dofs is dropped (their rows
+        // are not stored here, so those entries of the local solutions are not Schwarz corrections),
+        // and the multiplicity counts this rank's subdomains only; no exchange is needed.
         double* z = c->d_ycol.p;
         FEDD_HIP(hipMemsetAsync(z, 0, (size_t)c->n_cols * sizeof(double), c->stream));
         {

@@ -58,7 +58,13 @@ def _worker(rank, world, port, dec, M, q):
         g, Kinv = c.schwarz_coarse()
         z2 = c.schwarz_apply(r)
         x2, its2, rel2 = c.gmres(None, rtol=1e-13, max_it=600, restart=100, use_prec=True)
-        two = dict(g=g, Kinv=Kinv, zc=z2 - z1, x=x2, its=its2, rel=rel2)
+        # the other combine modes run across ranks too (ghost contributions of a rank's subdomains are dropped)
+        x_alt = {}
+        for name, mode in (("averaging", capi.COMBINE_AVERAGING), ("full", capi.COMBINE_FULL)):
+            c.schwarz_setup(1, mode)
+            xa, ita, rela = c.gmres(None, rtol=1e-13, max_it=600, restart=100, use_prec=True)
+            x_alt[name] = (xa, ita, rela)
+        two = dict(g=g, Kinv=Kinv, zc=z2 - z1, x=x2, its=its2, rel=rel2, alt=x_alt)
         q.put((rank, m["gid_uni"], x, y, its, rel, rowptr, col, val, gid, rhs, two))
         c.close()
     finally:
@@ -115,6 +121,15 @@ def test_multirank_solve_on_one_gpu(fedd_lib, dec, M):
     np.testing.assert_allclose(xx, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
     assert len(its2_all) == 1
     np.testing.assert_allclose(xx2, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
+    for name in ("averaging", "full"):
+        xa = np.zeros_like(xd)
+        its_a = set()
+        for rank, gu, x, y, its, rel, rowptr, col, val, gid, rhs, two in res:
+            xa[gu] = two["alt"][name][0]
+            its_a.add(two["alt"][name][1])
+            assert two["alt"][name][2] <= 1e-13
+        assert len(its_a) == 1
+        np.testing.assert_allclose(xa, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
 
 
 def _worker_elasticity(rank, world, port, dec, M, q):
