@@ -554,6 +554,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "apply_kind") c->apply_kind = (int)value;
     else if (k == "inv_kind") c->inv_kind = (int)value;
     else if (k == "gmres_kind") c->gmres_kind = (int)value;
+    else if (k == "ghost_overlap") c->ghost_overlap = (int)value;
     else FEDD_CHECK(false, "fedd_set_option: unknown key '%s'", key);
     return 0;
 }

@@ -118,14 +118,13 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
                                                   const int32_t* __restrict__ bin_nodes,
                                                   const int32_t* __restrict__ node_bin,
                                                   const int32_t* __restrict__ rowptr,
-                                                  const int32_t* __restrict__ colind, int32_t n_rows, int dofs,
+                                                  const int32_t* __restrict__ colind, int32_t n_rows, int ghost_overlap,
                                                   int overlap, int32_t* __restrict__ sub_n,
                                                   int32_t* __restrict__ sub_nown, int32_t* __restrict__ sub_dofs) {
     __shared__ int32_t tab[HS];
     __shared__ int32_t lst[HS];
     __shared__ int32_t s_cnt, s_prev;
     const int b = blockIdx.x, tid = threadIdx.x;
-    (void)dofs;
     const int32_t nb = bin_ptr[b];
     const int n_own = bin_ptr[b + 1] - nb;   // the box lists dofs
     int32_t* out = sub_dofs + (int64_t)b * NMAX;
@@ -145,6 +144,7 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
             for (int32_t p = rowptr[src]; p < rowptr[src + 1]; ++p) {
                 const int32_t col = colind[p];
                 if (col < n_rows && node_bin[col] == b) continue;
+                if (!ghost_overlap && col >= n_rows) continue;  // another rank's dof: its row is not stored here
                 uint32_t h = ((uint32_t)col * 2654435761u) % HS;
                 for (int probe = 0; probe < HS; ++probe) {
                     const int32_t old = atomicCAS(&tab[h], -1, col);
@@ -696,7 +696,7 @@ int schwarz_setup(fedd_ctx* c) {
     // ---- overlapping dof lists ----
     hipLaunchKernelGGL(k_sub_dofs, dim3((unsigned)nsub), blk, 0, c->stream, (const int32_t*)c->d_bin_ptr.p,
                        (const int32_t*)c->d_bin_nodes.p, (const int32_t*)c->d_node_bin.p, (const int32_t*)c->d_rowptr.p,
-                       (const int32_t*)c->d_colind.p, n_rows, dofs, c->sw_overlap, c->d_sub_n.p, c->d_sub_nown.p,
+                       (const int32_t*)c->d_colind.p, n_rows, c->ghost_overlap, c->sw_overlap, c->d_sub_n.p, c->d_sub_nown.p,
                        c->d_sub_dofs.p);
     int32_t max_n = 0;
     FEDD_TRY(reduce_max_i32(c, c->d_sub_n.p, nsub, &max_n));
