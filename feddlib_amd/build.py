@@ -69,14 +69,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
-def build_driver(verbose: bool = True) -> str:
-    """The C++ host-facade driver (mirrors feddlib/problems/tests/laplace/main.cpp), g++ against the C ABI."""
+def build_driver(verbose: bool = True, which: str = "laplace") -> str:
+    """The C++ host-facade drivers (mirror feddlib/problems/tests/laplace/main.cpp and
+    steadyLinElas_Perf/main.cpp), g++ against the C ABI."""
     gxx = shutil.which("g++")
     if gxx is None:
         raise RuntimeError("g++ not found")
     host = os.path.join(HERE, "host")
-    out = os.path.join(host, "bin", "laplace_driver")
-    src = os.path.join(host, "drivers", "laplace_main.cpp")
+    out = os.path.join(host, "bin", which + "_driver")
+    src = os.path.join(host, "drivers", which + "_main.cpp")
     deps = [src, os.path.join(host, "feddlib", "fedd_facade.hpp"), os.path.join(host, "Teuchos_shim.hpp"), LIB]
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
@@ -94,3 +95,4 @@ def build_driver(verbose: bool = True) -> str:
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
     print(build_driver())
+    print(build_driver(which="linelas"))

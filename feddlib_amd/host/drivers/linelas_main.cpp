@@ -1,0 +1,115 @@
+// Steady linear elasticity driver on the MI355X path, written against the FEDD:: operator surface
+// the way the reference's performance driver is
+// (feddlib/problems/tests/steadyLinElas_Perf/main.cpp:69-252): same XML parameter files
+// (parametersProblem / parametersPrec / parametersSolver), same call sequence
+//   Domain::buildMesh -> BCBuilder::addBC(zero Dirichlet on "Homogeneous Dirichlet Flag") ->
+//   LinElas(...) -> addRhsFunction -> addBoundaries -> addParemeterRhs(force, degree) ->
+//   initializeProblem -> assemble -> setBoundaries -> solve.
+// Output: iteration count and relative residual on stdout, the displacement as text (the reference
+// writes HDF5/XDMF through ExporterParaView and prints a Teuchos::StackedTimer report, both out of
+// scope here; a wall-clock time of the assemble + solve section is printed instead).
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+
+#include "feddlib/core/FEDDCore.hpp"
+#include "feddlib/core/FE/Domain.hpp"
+#include "feddlib/core/General/BCBuilder.hpp"
+#include "feddlib/problems/specific/LinElas.hpp"
+
+void zeroDirichlet2D(double* x, double* res, double t, const double* parameters) { res[0] = 0.; res[1] = 0.; }
+void zeroDirichlet3D(double* x, double* res, double t, const double* parameters) { res[0] = 0.; res[1] = 0.; res[2] = 0.; }
+// parameters[0] is the time, parameters[1] the volume force
+void rhs2D(double* x, double* res, double* parameters) { res[0] = 0.; res[1] = parameters[1]; }
+void rhs3D(double* x, double* res, double* parameters) { res[0] = 0.; res[1] = parameters[1]; res[2] = 0.; }
+
+typedef default_sc SC;
+typedef default_lo LO;
+typedef default_go GO;
+typedef default_no NO;
+
+using namespace FEDD;
+
+int main(int argc, char* argv[]) {
+    std::string xmlProblemFile = "parametersProblem.xml", xmlPrecFile = "parametersPrec.xml", xmlSolverFile = "parametersSolver.xml";
+    std::string outFile = "solutionLinElas.txt";
+    for (int i = 1; i < argc; ++i) {
+        std::string a(argv[i]);
+        auto val = [&](const char* key, std::string& dst) {
+            const std::string k = std::string("--") + key + "=";
+            if (a.compare(0, k.size(), k) == 0) { dst = a.substr(k.size()); return true; }
+            return false;
+        };
+        if (val("problemfile", xmlProblemFile) || val("precfile", xmlPrecFile) || val("solverfile", xmlSolverFile) || val("out", outFile)) continue;
+        std::cerr << "unknown option " << a << std::endl;
+        return 2;
+    }
+    try {
+        Teuchos::RCP<const Teuchos::Comm<int> > comm = Teuchos::rcp(new Teuchos::Comm<int>(0, 1));
+        ParameterListPtr_Type parameterListProblem = Teuchos::getParametersFromXmlFile(xmlProblemFile);
+        ParameterListPtr_Type parameterListPrec = Teuchos::getParametersFromXmlFile(xmlPrecFile);
+        ParameterListPtr_Type parameterListSolver = Teuchos::getParametersFromXmlFile(xmlSolverFile);
+        ParameterListPtr_Type parameterListAll(new Teuchos::ParameterList(*parameterListProblem));
+        parameterListAll->setParameters(*parameterListPrec);
+        parameterListAll->setParameters(*parameterListSolver);
+
+        int dim = parameterListProblem->sublist("Parameter").get("Dimension", 2);
+        int m = parameterListProblem->sublist("Parameter").get("H/h", 5);
+        int zeroDirID = parameterListProblem->sublist("Parameter").get("Homogeneous Dirichlet Flag", 1);
+        std::string discType = parameterListProblem->sublist("Parameter").get("Discretization", "P2");
+        int numProcsCoarseSolve = parameterListProblem->sublist("General").get("Mpi Ranks Coarse", 0);
+        int size = comm->getSize() - numProcsCoarseSolve;
+
+        Teuchos::RCP<Domain<SC, LO, GO, NO> > domain;
+        int n;
+        if (dim == 2) {
+            n = (int)(std::pow(size, 1 / 2.) + 100. * 2.220446049250313e-16);
+            std::vector<double> x(2);
+            x[0] = 0.0; x[1] = 0.0;
+            domain = Teuchos::rcp(new Domain<SC, LO, GO, NO>(x, 1., 1., comm));
+            domain->buildMesh(1, "Square", dim, discType, n, m, 0);
+        } else {
+            n = (int)(std::pow(size, 1 / 3.) + 100. * 2.220446049250313e-16);
+            std::vector<double> x(3);
+            x[0] = 0.0; x[1] = 0.0; x[2] = 0.0;
+            domain = Teuchos::rcp(new Domain<SC, LO, GO, NO>(x, 1., 1., 1., comm));
+            domain->buildMesh(1, "Square", dim, discType, n, m, numProcsCoarseSolve);
+        }
+
+        Teuchos::RCP<BCBuilder<SC, LO, GO, NO> > bcFactory(new BCBuilder<SC, LO, GO, NO>());
+        bcFactory->addBC(dim == 2 ? zeroDirichlet2D : zeroDirichlet3D, zeroDirID, 0, domain, "Dirichlet", dim);
+
+        LinElas<SC, LO, GO, NO> linElas(domain, discType, parameterListAll);
+        linElas.addRhsFunction(dim == 2 ? rhs2D : rhs3D);
+        int its;
+        const auto t0 = std::chrono::steady_clock::now();
+        {
+            linElas.addBoundaries(bcFactory);
+            const double force = parameterListAll->sublist("Parameter").get("Volume force", 0.);
+            const double degree = 0;
+            linElas.addParemeterRhs(force);
+            linElas.addParemeterRhs(degree);
+
+            linElas.initializeProblem();
+            linElas.assemble();
+            linElas.setBoundaries();
+            its = linElas.solve();
+        }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::cout << "iterations " << its << " relres " << linElas.getLastRelativeResidual() << std::endl;
+        std::cout << "Solve Problem " << secs << " s" << std::endl;
+
+        Teuchos::RCP<const MultiVector<SC, LO, GO, NO> > exportSolution = linElas.getSolution()->getBlock(0);
+        std::ofstream out(outFile);
+        out << std::setprecision(17);
+        auto map = exportSolution->getMap();
+        auto data = exportSolution->getData(0);
+        for (size_t i = 0; i < data.size(); ++i) out << map->getGlobalElement((LO)i) << " " << data[i] << "\n";
+    } catch (const std::exception& e) {
+        std::cerr << "exception: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

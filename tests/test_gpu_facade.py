@@ -68,3 +68,50 @@ def test_3d_tight_tolerance_matches_oracle(driver, tmp_path):
     xd = fo.direct_solve(A_bc, rhs_bc)
     np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
     assert rel <= 1e-13
+
+
+LINELAS_XML = os.path.join(ROOT, "tests", "golden", "linelas_xml")
+
+
+@pytest.fixture(scope="module")
+def linelas_driver(fedd_lib):
+    from feddlib_amd import build
+    return build.build_driver(verbose=False, which="linelas")
+
+
+def test_reference_steady_linelas_perf_xml_files(linelas_driver, tmp_path):
+    """The reference's steadyLinElas_Perf parameter files, unchanged (3D, P1, H/h = 4, mu = 2e6,
+    nu = 0.4, volume force 1, Dirichlet on flag 2, one-level FROSch, Block GMRES 1e-6): the driver's
+    displacement against a direct solve of the oracle's system."""
+    x, its, rel, log = run_driver(linelas_driver, tmp_path, os.path.join(LINELAS_XML, "parametersProblem.xml"),
+                                  os.path.join(LINELAS_XML, "parametersPrec.xml"),
+                                  os.path.join(LINELAS_XML, "parametersSolver.xml"))
+    m = fo.build_mesh_structured(3, 1, 4)
+    A_bc, rhs_bc, _, _, _ = fo.linelas_problem(m, 2.0e6, 0.4, f=(0.0, 1.0, 0.0), bc_flags=(2,))
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    assert rel <= 1e-6 and 0 < its <= 100
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-4 * np.abs(xd).max())      # tolerance-limited (1e-6 residual)
+    assert "Solve Problem" in log
+
+
+def test_linelas_two_level_tight_tolerance(linelas_driver, tmp_path):
+    prob = tmp_path / "p.xml"
+    prob.write_text(open(os.path.join(LINELAS_XML, "parametersProblem.xml")).read()
+                    .replace('name="H/h"							    	type="int"   	value="4"', 'name="H/h" type="int" value="8"'))
+    assert 'name="H/h" type="int" value="8"' in prob.read_text()
+    prec = tmp_path / "c.xml"
+    prec.write_text(open(os.path.join(LINELAS_XML, "parametersPrec.xml")).read()
+                    .replace('name="TwoLevel"                                          type="bool"     value="false"',
+                             'name="TwoLevel" type="bool" value="true"'))
+    assert 'name="TwoLevel" type="bool" value="true"' in prec.read_text()
+    sol = tmp_path / "s.xml"
+    sol.write_text(open(os.path.join(LINELAS_XML, "parametersSolver.xml")).read()
+                   .replace('"Convergence Tolerance" type="double" value="1e-6"', '"Convergence Tolerance" type="double" value="1e-13"')
+                   .replace('"Maximum Iterations" type="int" value="100"', '"Maximum Iterations" type="int" value="500"'))
+    x, its, rel, log = run_driver(linelas_driver, tmp_path, prob, prec, sol)
+    m = fo.build_mesh_structured(3, 1, 8)
+    A_bc, rhs_bc, _, _, _ = fo.linelas_problem(m, 2.0e6, 0.4, f=(0.0, 1.0, 0.0), bc_flags=(2,))
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    assert rel <= 1e-13
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+    assert "Q1-lattice coarse space" in log
