@@ -16,7 +16,7 @@ c.mesh_set_dict(m)
 mu, nu = 2.0e6, 0.4
 lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
 c.timing_enable(True)
-for two in (0, 1, 0, 1):
+for two in ((1, 1) if len(sys.argv) > 3 else (0, 1, 0, 1)):
     c.timing_reset()
     c.sync()
     t0 = time.perf_counter()
