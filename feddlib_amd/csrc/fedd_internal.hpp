@@ -160,7 +160,7 @@ struct fedd_ctx {
     int sw_overlap = 1, sw_combine = 0;
     int64_t sw_nsub = 0, sw_max_size = 0, sw_max_own = 0, sw_inv_elems = 0;
     int apply_kind = 0;                         // restricted apply: 0 = flat streaming kernel, 1 = strided (A/B)
-    int inv_kind = 0;                           // local inverses: 0 = scalar-pivot kernel, 1 = MFMA block sweep (A/B)
+    int inv_kind = 0;                           // local inverses: 0 = scalar-pivot kernel (drops finished rows), 1 = MFMA block sweep, 2 = scalar-pivot, all rows (A/B)
     int ghost_overlap = 1;                      // subdomains may contain ghost dofs (identity rows): 1 = yes (A/B)
     int gmres_kind = 0;                         // Gram-Schmidt: 0 = delayed second pass (DCGS2), 1 = two passes (CGS2)
     fedd::DevBuf<int32_t> d_node_bin;           // [n_own] compact bin id of each owned node

@@ -18,7 +18,7 @@ c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
 c.timing_enable(True)
 r = np.random.default_rng(0).standard_normal(m["gid_uni"].shape[0])
 z = {}
-for kind in (0, 1, 0, 1):
+for kind in (2, 0, 2, 0):
     c.set_option("inv_kind", kind)
     c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
     c.timing_reset()
@@ -28,5 +28,5 @@ for kind in (0, 1, 0, 1):
     t = c.timing_get()["schwarz_setup"]
     print("inv_kind", kind, "schwarz_setup ms", t[0] / t[1], flush=True)
     z[kind] = c.schwarz_apply(r)
-print("max |z0 - z1| / max |z|", np.abs(z[0] - z[1]).max() / np.abs(z[1]).max())
+print("max |z0 - z1| / max |z|", np.abs(z[0] - z[2]).max() / np.abs(z[2]).max())
 c.close()
