@@ -533,7 +533,11 @@ __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ 
     __shared__ double part[256];
     __shared__ int32_t sdof[NMAX];
     extern __shared__ double prod[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    // bijective XCD remap (workgroups i and i + 8 share an XCD and its L2): XCD k takes a contiguous
+    // eighth of the subdomains, so the part of r that neighbouring subdomains gather stays in one L2
+    const int nb_ = gridDim.x, q_ = nb_ >> 3, rem_ = nb_ & 7, xcd_ = blockIdx.x & 7, within_ = blockIdx.x >> 3;
+    const int b = (xcd_ < rem_ ? xcd_ * (q_ + 1) : rem_ * (q_ + 1) + (xcd_ - rem_) * q_) + within_;
     const int n = sub_n[b], nrow = sub_nown[b];
     const int total = n * nrow;
     const double* __restrict__ slab = inv + inv_ptr[b];
