@@ -625,7 +625,9 @@ int coarse_setup(fedd_ctx* c) {
     }
     // ---- lattice: g_d = max(1, floor(L_d / H + 0.5)), H = (V / cells_target)^(1/dim) ----
     double target = c->co_cells_target;
-    if (!(target > 0)) target = std::min(3375.0, std::max(1.0, std::floor(n_global / 1000.0)));
+    // default: one cell per 1000 nodes, at most 12^3 cells (K0 is dense and replicated: 2197^2 doubles
+    // = 38 MB to all-reduce and 21 GFLOP to invert per setup; 15^3 cells would be 134 MB and 137 GFLOP)
+    if (!(target > 0)) target = std::min(1728.0, std::max(1.0, std::floor(n_global / 1000.0)));
     CoarseGeom cg;
     cg.dim = dim;
     double V = 1.0;

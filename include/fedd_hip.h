@@ -197,7 +197,7 @@ int fedd_schwarz_setup(fedd_ctx* ctx, int overlap, int combine, int two_level, i
 /* target_nodes = 0 (the default): 27 nodes for scalar problems, 27 / dofs-per-node for vector ones */
 int fedd_schwarz_set_target(fedd_ctx* ctx, int target_nodes, double scale);
 /* number of lattice cells the coarse level aims at (0 = default: global nodes / 1000, clamped to
- * [1, 3375]); call before fedd_schwarz_setup */
+ * [1, 1728]); call before fedd_schwarz_setup */
 int fedd_schwarz_set_coarse(fedd_ctx* ctx, double cells_target);
 /* coarse level read-back (parity): lattice cells per direction, coarse dofs n0, K0^-1 row-major */
 int fedd_schwarz_coarse_sizes(fedd_ctx* ctx, int32_t cells[3], int64_t* n0);
