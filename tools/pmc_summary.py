@@ -14,7 +14,7 @@ def load(d, name):
 
 fe = load(sys.argv[1], "FETCH_SIZE"); wr = load(sys.argv[2], "WRITE_SIZE")
 classes = {"spmv": "k_spmv_stream", "schwarz_apply": "k_apply", "assemble": "k_assemble_pairs<", "multidot": "k_multidot(",
-           "multiaxpy": "k_multiaxpy(", "multidot2": "k_multidot2", "axpy2": "k_axpy2", "invert": "k_invert_reg<7>"}
+           "multiaxpy": "k_multiaxpy(", "multidot2": "k_multidot2", "axpy2": "k_axpy2", "invert": "k_invert_reg<7"}
 out = {}
 for key, pat in classes.items():
     fk = [v for k, vs in fe.items() if pat in k for v in vs]
