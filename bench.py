@@ -10,10 +10,13 @@ GMRES(100) to 1e-8 (feddlib/problems/tests/laplace/main.cpp:199-208 with 3D/P1/s
 parameters).  The mesh (connectivity, coordinates, flags) is generated on the host and uploaded
 BEFORE the timed region (metric definition).
 
-Workload: N = 1 -> BASELINE.json configs[1]: unit cube, 100^3 cells, 1 030 301 dofs.
-          N > 1 -> weak scaling: every GPU owns a 100^3-cell block (1x1x2, 1x2x2, 2x2x2 blocks);
-                   the reference generator has no 2/4-rank cube (laplace/main.cpp:132), the slab /
-                   pencil splits of the same lattice are this repo's extension.
+Workload (default): the grid of BASELINE.md's headline cfg 3 at every N -- unit cube, 214^3 cells,
+          9 938 375 dofs, 147 968 803 nonzeros -- split into 1x1x1, 1x1x2, 1x2x2, 2x2x2 blocks
+          (strong scaling; N = 8 is the reference's N = 2, M = 107 decomposition, the 2- and 4-block
+          splits of the same grid are BASELINE.md section 2's stated extension: the reference
+          generator needs N^3 ranks, laplace/main.cpp:132).  At N = 1 the line also carries
+          `cfg2_one_gpu`: the same path on BASELINE.json configs[1] (100^3 cells, 1 030 301 dofs).
+          --cells M switches to M^3 cells per GPU (weak scaling; development and rehearsals).
 """
 from __future__ import annotations
 
@@ -37,7 +40,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cells", type=int, default=100, help="cells per direction and GPU (M = H/h)")
+    ap.add_argument("--global-cells", type=int, default=214, help="cells per direction of the whole cube (strong scaling)")
+    ap.add_argument("--cells", type=int, default=0,
+                    help="cells per direction and GPU (M = H/h): weak scaling instead of the fixed global grid")
+    ap.add_argument("--no-cfg2", action="store_true", help="N = 1: skip the extra configs[1] (100^3 cells) measurement")
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--restart", type=int, default=100)
     ap.add_argument("--max-it", type=int, default=2000)
@@ -67,7 +73,7 @@ def one_step(c, capi, a, two_level=False):
     return its, rel
 
 
-def cpu_baseline(a):
+def cpu_baseline(a, full_cells):
     """The CPU restatement (oracle, kind 'port') timed on this box's host cores on a bounded
     sample of the same workload: same driver sequence, same preconditioner definition, same
     tolerance, smaller cube.  Reported beside the GPU number; never the thing measured as `value`."""
@@ -78,7 +84,7 @@ def cpu_baseline(a):
     except Exception:
         have_c = False
     if have_c:
-        M = a.cpu_cells or a.cells
+        M = a.cpu_cells
         # the GPU box gives a 1-GPU job a 16-core share; more OpenMP threads only oversubscribe it
         nthr = int(os.environ.get("FEDD_CPU_THREADS", "0")) or min(16, os.cpu_count() or 1)
         r = oracle_c.run_laplace3d(M, a.target, a.rtol, a.restart, a.max_it, threads=nthr)
@@ -86,10 +92,10 @@ def cpu_baseline(a):
                 "sample": "%s workload, %d^3-cell cube (%d dofs), one pass of the same path (assemble %.2f s, "
                           "Dirichlet %.2f s, Schwarz setup %.2f s, GMRES %.2f s / %d its): oracle/oracle.c "
                           "(C/OpenMP restatement, not Trilinos), one-level RAS with %d-node subdomains"
-                          % ("the full" if M == a.cells else "reduced", M, r["dofs"], r["t_assemble"], r["t_bc"],
+                          % ("the full" if M == full_cells else "reduced (%d^3 in the GPU run)" % full_cells, M, r["dofs"], r["t_assemble"], r["t_bc"],
                              r["t_prec"], r["t_gmres"], r["its"], a.target)}
     import fedd_oracle as fo
-    M = a.cpu_cells or 32
+    M = min(a.cpu_cells, 32)
     t0 = time.perf_counter()
     m = fo.build_mesh_structured(3, 1, M)
     t_mesh = time.perf_counter() - t0
@@ -148,9 +154,57 @@ def main():
         torch.cuda.synchronize()
 
     dec = DECOMP[N]
-    cells = [a.cells] * 3
+    weak = a.cells > 0
+    if weak:
+        cells = [a.cells] * 3
+        # cells stay cubes for every decomposition: the domain is dec / max(dec) of the unit cube
+        dom = [d / float(max(dec)) for d in dec]
+    else:
+        if any(a.global_cells % d for d in dec):
+            raise SystemExit("--global-cells %d is not divisible by the %s decomposition" % (a.global_cells, dec))
+        cells = [a.global_cells // d for d in dec]
+        dom = [1.0, 1.0, 1.0]
+    if not a.cpu_cells:
+        a.cpu_cells = min(128, max(cells))
+
+    def measure(c, n_global, two_level):
+        """W warm-up steps, then exactly K timed steps between barriers; max over ranks."""
+        for _ in range(a.warmup if not two_level else 1):
+            one_step(c, capi, a, two_level)
+        c.sync()
+        # HIP events on the library's stream, live in the timed region; the per-iteration kernels are
+        # sampled every 8th launch (an event pair around every launch costs 3-6 % of the step)
+        c.timing_enable(8)
+        c.timing_reset()
+        barrier()
+        t0 = time.perf_counter()
+        its = rel = None
+        for _ in range(a.steps):
+            its, rel = one_step(c, capi, a, two_level)
+        c.sync()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        return dt, its, rel, c.timing_get()
+
+    def kernel_table(tm, m, nr, nnz, info):
+        # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md), this rank's share
+        models = {
+            "spmv": 12.0 * nnz + 20.0 * nr,
+            "schwarz_apply": info["inverse_bytes"] + 3 * 8.0 * nr,
+            "assemble": 4.0 * m["conn"].size + 8.0 * 3 * m["xyz"].shape[0] + 12.0 * nnz + 4.0 * (nr + 1),
+        }
+        kern = {}
+        for k, b in models.items():
+            ms, nl = tm[k]
+            if nl:
+                kern[k] = dict(ms_per_launch=ms / nl, launches=nl, total_ms=ms, GBs=b / (ms / nl) / 1e6, bytes=b)
+        return kern
+
+    def rounded(kern):
+        return {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()}
+
     t0 = time.perf_counter()
-    m = capi.structured_mesh(3, dec, cells, rank, ghosts=N > 1)
+    m = capi.structured_mesh(3, dec, cells, rank, size=dom, ghosts=N > 1)
     t_mesh = time.perf_counter() - t0
     c = capi.Context(device=dev, rank=rank, nranks=N, nccl_id=nccl_id)
     t0 = time.perf_counter()
@@ -165,43 +219,18 @@ def main():
     t_upload = time.perf_counter() - t0
     n_global = m["n_global"]
 
-    for _ in range(a.warmup):
-        one_step(c, capi, a)
-    c.sync()
-    # HIP events on the library's stream, live in the timed region; the per-iteration kernels are
-    # sampled every 8th launch (an event pair around every launch costs 3-6 % of the step)
-    c.timing_enable(8)
-    c.timing_reset()
-    barrier()
-    t0 = time.perf_counter()
-    its = rel = None
-    for _ in range(a.steps):
-        its, rel = one_step(c, capi, a)
-    c.sync()
-    barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
-    tm = c.timing_get()
+    dt, its, rel, tm = measure(c, n_global, False)
     nr, ncol, nnz = c.csr_sizes()
     info = c.schwarz_info()
 
     # ---- extra, outside the headline number: the same step with the coarse level switched on ----
     two = None
     if not a.no_two_level:
-        one_step(c, capi, a, two_level=True)
-        c.sync()
-        c.timing_reset()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            its2, rel2 = one_step(c, capi, a, two_level=True)
-        c.sync()
-        barrier()
-        dt2 = max_over_ranks(time.perf_counter() - t0)
-        g2, _ = c.schwarz_coarse_sizes()
-        tm2 = c.timing_get()
+        dt2, its2, rel2, tm2 = measure(c, n_global, True)
+        g2, n02 = c.schwarz_coarse_sizes()
         two = {"value": n_global * a.steps / dt2, "unit": "DoF/s", "ms_per_step": dt2 / a.steps * 1e3,
                "gmres_iterations": its2, "relres": rel2, "coarse_cells": [int(v) for v in g2],
-               "coarse_dofs": int(c.schwarz_coarse_sizes()[1]),
+               "coarse_dofs": int(n02),
                "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in tm2.items()},
                "note": "same step with fedd_schwarz_setup(two_level=1, FEDD_COARSE_Q1); not the headline config"}
 
@@ -214,36 +243,62 @@ def main():
         c.spmv_device(50)
         c.sync()
         ms, nl = c.timing_get()["spmv"]
-        spmv_b2b = {"ms_per_launch": ms / nl, "GBs": (12.0 * nnz + 20.0 * nr) / (ms / nl) / 1e6,
-                    "frac_hbm_peak": (12.0 * nnz + 20.0 * nr) / (ms / nl) / 1e6 / HBM_PEAK_GBS,
-                    "note": "50 launches back to back: the 203 MB matrix stays in the 256 MB Infinity Cache between "
-                            "launches, so this is not a pure HBM figure; spmv_frac_hbm_peak is the in-solver one"}
+        b = 12.0 * nnz + 20.0 * nr
+        spmv_b2b = {"ms_per_launch": ms / nl, "GBs": b / (ms / nl) / 1e6, "frac_hbm_peak": b / (ms / nl) / 1e6 / HBM_PEAK_GBS,
+                    "note": "50 launches back to back on resident vectors" +
+                            ("; the matrix (%.0f MB) fits the 256 MB Infinity Cache, so this is not a pure HBM figure"
+                             % (b / 1e6) if b < 256e6 else "")}
+    kern = kernel_table(tm, m, nr, nnz, info) if rank == 0 else None
+    c.close()
+    del m
+
+    # ---- extra (N = 1, fixed-grid mode): the same path on BASELINE.json configs[1], 100^3 cells ----
+    cfg2 = None
+    if N == 1 and not weak and not a.no_cfg2:
+        m2 = capi.structured_mesh(3, dec, [100] * 3, 0)
+        c2 = capi.Context(device=dev, rank=0, nranks=1, nccl_id=None)
+        c2.mesh_set_dict(m2)
+        c2.sync()
+        d1, i1, r1, t1 = measure(c2, m2["n_global"], False)
+        nr2, _, nnz2 = c2.csr_sizes()
+        k2 = kernel_table(t1, m2, nr2, nnz2, c2.schwarz_info())
+        cfg2 = {"workload": "BASELINE.json configs[1]: unit cube, 100^3 cells, %d dofs, nnz %d, same solver settings"
+                            % (m2["n_global"], nnz2),
+                "value": m2["n_global"] * a.steps / d1, "unit": "DoF/s", "ms_per_step": d1 / a.steps * 1e3,
+                "gmres_iterations": i1, "relres": r1, "kernels": rounded(k2),
+                "spmv_frac_hbm_peak": k2["spmv"]["GBs"] / HBM_PEAK_GBS,
+                "schwarz_apply_frac_hbm_peak": k2["schwarz_apply"]["GBs"] / HBM_PEAK_GBS,
+                "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in t1.items()}}
+        if not a.no_two_level:
+            d2, i2, r2, _ = measure(c2, m2["n_global"], True)
+            cfg2["two_level_variant"] = {"value": m2["n_global"] * a.steps / d2, "unit": "DoF/s",
+                                         "ms_per_step": d2 / a.steps * 1e3, "gmres_iterations": i2, "relres": r2}
+        c2.close()
+        del m2
 
     if rank == 0:
-        # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md), this rank's share
-        models = {
-            "spmv": 12.0 * nnz + 20.0 * nr,
-            "schwarz_apply": info["inverse_bytes"] + 3 * 8.0 * nr,
-            "assemble": 4.0 * m["conn"].size + 8.0 * 3 * m["xyz"].shape[0] + 12.0 * nnz + 4.0 * (nr + 1),
-        }
-        kern = {}
-        for k, b in models.items():
-            ms, nl = tm[k]
-            if nl:
-                kern[k] = dict(ms_per_launch=ms / nl, launches=nl, total_ms=ms, GBs=b / (ms / nl) / 1e6, bytes=b)
-        # GMRES orthogonalisation: 2 passes over the basis per DGKS pass; total bytes over the solve
-        ms, nl = tm["ortho"]
         dominant = max(kern, key=lambda k: kern[k]["total_ms"])
         d = kern[dominant]
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": d["GBs"] / HBM_PEAK_GBS, "traffic": None,
                     "ms_per_launch": d["ms_per_launch"], "algorithmic_bytes_per_launch": d["bytes"]}
+        # HBM bytes per launch from the committed PMC passes of this same workload (tools/pmc_summary.py);
+        # only quoted when the passes were taken on the grid this run used
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                roofline["traffic"] = json.load(open(pmc)).get(dominant)
+                pj = json.load(open(pmc))
+                if pj.get("cells_per_gpu") == cells and pj.get("n_gpus", 1) == N:
+                    roofline["traffic"] = pj.get(dominant)
             except Exception:
                 pass
+        split = "x".join(map(str, dec))
+        if weak:
+            wl = ("3D P1 Laplace, structured box %s (cubic cells), %s blocks x %d^3 cells per GPU, %d dofs"
+                  % ("x".join("%g" % v for v in dom), split, a.cells, n_global))
+        else:
+            wl = ("3D P1 Laplace, unit cube, %d^3 cells = %d dofs (BASELINE cfg 3 grid), %s blocks of %s cells"
+                  % (a.global_cells, n_global, split, "x".join(map(str, cells))))
         out = {
             "metric": "DoF/s assemble+solve, 3D P1-Laplace cube",
             "value": n_global * a.steps / dt,
@@ -251,17 +306,16 @@ def main():
             "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (structured unit cube, f=1, homogeneous Dirichlet; reference generator semantics)",
-            "config": {"workload": "3D P1 Laplace, structured cube, %s blocks x %d^3 cells, %d dofs, nnz %d/GPU; "
-                                   "GMRES(%d) rtol %g + one-level RAS (overlap 1, %d-node subdomains, exact local solves)"
-                                   % ("x".join(map(str, dec)), a.cells, n_global, nnz, a.restart, a.rtol, a.target),
+            "config": {"workload": wl + ", nnz %d/GPU; GMRES(%d) rtol %g + one-level RAS (overlap 1, %d-node subdomains, "
+                                        "exact local solves)" % (nnz, a.restart, a.rtol, a.target),
                        "dofs": n_global, "gmres_iterations": its, "relres": rel,
                        "subdomains_per_gpu": info["n_subdomains"], "max_subdomain_size": info["max_size"]},
             "roofline": roofline,
-            "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()},
+            "kernels": rounded(kern),
             "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in tm.items()},
             "spmv_frac_hbm_peak": kern["spmv"]["GBs"] / HBM_PEAK_GBS if "spmv" in kern else None,
             "mesh_generation_s": t_mesh, "mesh_upload_s": t_upload,
@@ -270,10 +324,11 @@ def main():
             out["spmv_back_to_back"] = spmv_b2b
         if two is not None:
             out["two_level_variant"] = two
+        if cfg2 is not None:
+            out["cfg2_one_gpu"] = cfg2
         if N == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a)
+            out["cpu_baseline"] = cpu_baseline(a, cells[0])
         print(json.dumps(out), flush=True)
-    c.close()
     if N > 1:
         dist.destroy_process_group()
 

@@ -143,7 +143,7 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_xcol, d_ycol;        // [n_cols] work vectors with ghost tail
     fedd::DevBuf<int32_t> d_isdir;              // [n_rows] 1 = Dirichlet row
     bool have_pattern = false;
-    int spmv_kind = 0;                          // 0 = CSR-stream kernel, 1 = row-per-lane-group kernel
+    int spmv_kind = 0;                          // 0 = CSR-window / automatic, 1 = row-per-lane-group, 2 = CSR-stream
     int asm_kind = 0;                           // 0 = pair-parallel assembly, 1 = lane-per-row gather
     fedd::DevBuf<int32_t> d_pat_stash;          // pattern build: merged node lists of the count pass, [k][node]
     fedd::DevBuf<int32_t> d_spmv_rows;          // CSR-stream: first row of every nnz window

@@ -214,7 +214,7 @@ int fedd_schwarz_info(fedd_ctx* ctx, int64_t* n_subdomains, int64_t* max_size, i
 int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rtol, int max_it,
                int restart, int use_prec, int* its_out, double* relres_out);
 
-/* tuning knobs (A/B tests), 0 is the default of each: "spmv_kind" 0 = CSR-stream, 1 = row-per-lane-group;
+/* tuning knobs (A/B tests), 0 is the default of each: "spmv_kind" 0 = CSR-window (CSR-stream when a row has more than 256 entries), 1 = row-per-lane-group, 2 = CSR-stream;
  * "asm_kind" 0 = pair-parallel assembly, 1 = lane-per-row gather; "apply_kind" 0 = flat streaming Schwarz
  * apply, 1 = strided; "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
  * matrix cores, 2 = scalar-pivot without dropping rows;

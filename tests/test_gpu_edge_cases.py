@@ -174,3 +174,22 @@ def test_delayed_and_plain_gram_schmidt_give_the_same_iterates(fedd_lib, ctx, tw
     # explicit residual of the delayed variant (the lagged recurrences must not drift from b - A x)
     x0 = res[(0, 1e-12)][0]
     assert np.linalg.norm(rhs_bc - A_bc @ x0) / np.linalg.norm(rhs_bc) < 1e-10
+
+
+@pytest.mark.parametrize("dim,M", [(3, 13), (2, 50), (3, 1), (3, 2)])
+def test_spmv_kernels_agree(fedd_lib, ctx, dim, M):
+    """The three SpMV kernels (`spmv_kind` 0 = CSR-window, 1 = row-per-lane-group, 2 = CSR-stream) on matrices of
+    less than one window, one window and many windows: against the oracle, and the two windowed kernels
+    bit for bit (same products, same summation order)."""
+    m, A_bc, rhs_bc, flags = laplace(fedd_lib, ctx, dim, M)
+    x = np.random.default_rng(11).standard_normal(A_bc.shape[0])
+    yo = fo.spmv(A_bc, x)
+    ys = {}
+    try:
+        for kind in (0, 1, 2):
+            ctx.set_option("spmv_kind", kind)
+            ys[kind] = ctx.spmv(x)
+            np.testing.assert_allclose(ys[kind], yo, rtol=0, atol=1e-13 * np.abs(yo).max())
+    finally:
+        ctx.set_option("spmv_kind", 0)
+    assert np.array_equal(ys[0], ys[2])

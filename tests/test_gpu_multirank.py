@@ -218,3 +218,44 @@ def test_bench_contract_n2_rehearsal(fedd_lib):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["config"]["dofs"] == 13 * 13 * 25 and d["config"]["relres"] <= 1e-8
     assert d["two_level_variant"]["gmres_iterations"] <= d["config"]["gmres_iterations"]
+
+
+def test_bench_contract_n2_fixed_grid_rehearsal(fedd_lib):
+    """The default mode of bench.py (one global grid split over the ranks, "scaling": "strong"), at a small
+    grid: 24^3 cells as 1x1x2 blocks of 24x24x12."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "0", "--global-cells", "24", "--rehearse-one-gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["dofs"] == 25 ** 3 and d["config"]["relres"] <= 1e-8
+    assert "1x1x2 blocks of 24x24x12 cells" in d["config"]["workload"]
+
+
+def test_bench_contract_one_gpu(fedd_lib):
+    """`python bench.py` end to end at a reduced grid: one JSON line with every contract key, the roofline and
+    cpu_baseline objects, and the configs[1] extra."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--global-cells", "20"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["dofs"] == 21 ** 3
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"]
+    assert d["roofline"]["traffic"] is None              # PMC passes are of the full grid only
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"]
+    assert d["cfg2_one_gpu"]["gmres_iterations"] > 0 and "1030301 dofs" in d["cfg2_one_gpu"]["workload"]

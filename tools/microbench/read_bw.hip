@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256) void k_read_blocks(const double2* __restrict__
     if (s == 12345.678) out[0] = s;
 }
 
-int main() {
-    const size_t bytes = (size_t)800 << 20;
+int main(int argc, char** argv) {
+    const size_t bytes = (size_t)(argc > 1 ? atoi(argv[1]) : 800) << 20;   // MiB streamed per launch
+    printf("footprint %zu MiB\n", bytes >> 20);
     double* d;
     double* out;
     hipMalloc(&d, bytes);
