@@ -36,6 +36,7 @@ SIGNATURES = {
     "fedd_mesh_structured_build": [C.c_int, _ip, _ip, C.c_int, _f64p, _f64p, C.c_int, C.c_int, _i32p, _f64p,
                                    _i64p, _i32p, _i64p, _i32p],
     "fedd_mesh_structured_owner": [C.c_int, _ip, _ip, C.c_int64, _i64p, _i32p],
+    "fedd_mesh_structured_row_ghosts": [C.c_int, _ip, _ip, C.c_int, _f64p, _f64p, C.c_int, _i64p, _i64p, _i32p],
     "fedd_mesh_read_sizes": [C.c_char_p, C.c_int, _i64p, _i64p, _i64p],
     "fedd_mesh_read": [C.c_char_p, C.c_int, _f64p, _i32p, _i32p, _i32p, _i32p, _i32p],
     "fedd_mesh_p2_sizes": [C.c_int, C.c_int64, _i32p, _i64p],
@@ -43,6 +44,8 @@ SIGNATURES = {
                            _i32p, _f64p, _i32p],
     "fedd_mesh_set": [C.c_void_p, C.c_int, C.c_int, C.c_int64, _i32p, C.c_int64, _f64p, _i64p, C.c_int64,
                       _i64p, _i32p],
+    "fedd_mesh_set_rows": [C.c_void_p, C.c_int, C.c_int, C.c_int64, _i32p, C.c_int64, _f64p, _i64p, C.c_int64,
+                           _i64p, _i32p, C.c_int64, _i64p, _i32p],
     "fedd_pattern_build": [C.c_void_p, C.c_int, C.c_int, _i64p],
     "fedd_assemble": [C.c_void_p, C.c_int, _f64p],
     "fedd_assemble_rhs": [C.c_void_p, C.c_int, _f64p, C.c_int],
@@ -88,6 +91,40 @@ SIGNATURES = {
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _i32p, _i64p, _f64p, _i64p, _f64p, C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _f64p, C.c_int)
 
+
+class ThreadGroup:
+    """In-process stand-in for a communicator: `world` threads of one process, one rank (and one
+    fedd_ctx) each.  Lets the complete N > 1 path run with more ranks than a one-GPU box admits
+    processes (the 2 x 2 x 2 decomposition: 8 ranks).  Functional tests only."""
+
+    def __init__(self, world, timeout=120.0):
+        import collections
+        import threading
+        self.world = world
+        self.timeout = timeout
+        self._barrier = threading.Barrier(world)
+        self._slots = [None] * world
+        self._cv = threading.Condition()
+        self._box = collections.defaultdict(collections.deque)
+
+    def allgather(self, rank, obj):
+        self._slots[rank] = obj
+        self._barrier.wait(self.timeout)
+        out = list(self._slots)
+        self._barrier.wait(self.timeout)
+        return out
+
+    def send(self, src, dst, arr):
+        with self._cv:
+            self._box[(src, dst)].append(np.array(arr, copy=True))
+            self._cv.notify_all()
+
+    def recv(self, src, dst):
+        with self._cv:
+            if not self._cv.wait_for(lambda: len(self._box[(src, dst)]) > 0, self.timeout):
+                raise TimeoutError("ThreadGroup.recv %d <- %d" % (dst, src))
+            return self._box[(src, dst)].popleft()
+
 _lib = None
 
 
@@ -130,7 +167,10 @@ def _decomp(dim, N):
 
 
 def structured_mesh(dim, N, M, rank=0, origin=None, size=None, flags_option=1, ghosts=False):
-    """Product-side structured generator (host code in the library).  N, M: ints or per-direction lists."""
+    """Product-side structured generator (host code in the library).  N, M: ints or per-direction lists.
+    ghosts: False / 0 = the reference's block, True / 1 = plus the elements that complete the owned rows,
+    2 = plus the layer that completes the rows of the first ghost nodes (the dict then carries
+    row_ghost_gid / row_ghost_flag, which Context.mesh_set_dict hands to fedd_mesh_set_rows)."""
     L = lib()
     dec, cel = _decomp(dim, N), _decomp(dim, M)
     ne, nr, nu, ng = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
@@ -147,8 +187,18 @@ def structured_mesh(dim, N, M, rank=0, origin=None, size=None, flags_option=1, g
     _chk(L.fedd_mesh_structured_build(dim, _ints(dec), _ints(cel), rank, _p(o, _f64p), _p(s, _f64p), flags_option,
                                       int(ghosts), _p(conn, _i32p), _p(xyz, _f64p), _p(gid_rep, _i64p),
                                       _p(flag_rep, _i32p), _p(gid_uni, _i64p), _p(flag_uni, _i32p)))
-    return dict(dim=dim, nen=dim + 1, conn=conn, xyz=xyz, gid_rep=gid_rep, flag_rep=flag_rep, gid_uni=gid_uni,
-                flag_uni=flag_uni, n_global=ng.value, decomp=dec, cells=cel, rank=rank)
+    out = dict(dim=dim, nen=dim + 1, conn=conn, xyz=xyz, gid_rep=gid_rep, flag_rep=flag_rep, gid_uni=gid_uni,
+               flag_uni=flag_uni, n_global=ng.value, decomp=dec, cells=cel, rank=rank)
+    if int(ghosts) == 2:
+        nrg = C.c_int64()
+        _chk(L.fedd_mesh_structured_row_ghosts(dim, _ints(dec), _ints(cel), rank, _p(o, _f64p), _p(s, _f64p), flags_option,
+                                               C.byref(nrg), None, None))
+        rg = np.zeros(nrg.value, dtype=np.int64)
+        rf = np.zeros(nrg.value, dtype=np.int32)
+        _chk(L.fedd_mesh_structured_row_ghosts(dim, _ints(dec), _ints(cel), rank, _p(o, _f64p), _p(s, _f64p), flags_option,
+                                               C.byref(nrg), _p(rg, _i64p), _p(rf, _i32p)))
+        out["row_ghost_gid"], out["row_ghost_flag"] = rg, rf
+    return out
 
 
 def read_mesh(path, dim):
@@ -228,19 +278,27 @@ class Context:
     def sync(self):
         _chk(self._L.fedd_sync(self._h))
 
-    def mesh_set(self, dim, conn, xyz, gid_rep, gid_uni, flag_uni):
+    def mesh_set(self, dim, conn, xyz, gid_rep, gid_uni, flag_uni, row_ghost_gid=None, row_ghost_flag=None):
         conn = np.ascontiguousarray(conn, dtype=np.int32)
         xyz = np.ascontiguousarray(xyz, dtype=np.float64)
         gid_rep = np.ascontiguousarray(gid_rep, dtype=np.int64)
         gid_uni = np.ascontiguousarray(gid_uni, dtype=np.int64)
         flag_uni = None if flag_uni is None else np.ascontiguousarray(flag_uni, dtype=np.int32)
-        _chk(self._L.fedd_mesh_set(self._h, dim, conn.shape[1], conn.shape[0], _p(conn, _i32p), xyz.shape[0],
-                                   _p(xyz, _f64p), _p(gid_rep, _i64p), gid_uni.shape[0], _p(gid_uni, _i64p),
-                                   _p(flag_uni, _i32p)))
+        if row_ghost_gid is not None and len(row_ghost_gid):
+            rg = np.ascontiguousarray(row_ghost_gid, dtype=np.int64)
+            rf = None if row_ghost_flag is None else np.ascontiguousarray(row_ghost_flag, dtype=np.int32)
+            _chk(self._L.fedd_mesh_set_rows(self._h, dim, conn.shape[1], conn.shape[0], _p(conn, _i32p), xyz.shape[0],
+                                            _p(xyz, _f64p), _p(gid_rep, _i64p), gid_uni.shape[0], _p(gid_uni, _i64p),
+                                            _p(flag_uni, _i32p), rg.shape[0], _p(rg, _i64p), _p(rf, _i32p)))
+        else:
+            _chk(self._L.fedd_mesh_set(self._h, dim, conn.shape[1], conn.shape[0], _p(conn, _i32p), xyz.shape[0],
+                                       _p(xyz, _f64p), _p(gid_rep, _i64p), gid_uni.shape[0], _p(gid_uni, _i64p),
+                                       _p(flag_uni, _i32p)))
         self.n_own = gid_uni.shape[0]
 
     def mesh_set_dict(self, m):
-        self.mesh_set(m["dim"], m["conn"], m["xyz"], m["gid_rep"], m["gid_uni"], m["flag_uni"])
+        self.mesh_set(m["dim"], m["conn"], m["xyz"], m["gid_rep"], m["gid_uni"], m["flag_uni"],
+                      m.get("row_ghost_gid"), m.get("row_ghost_flag"))
 
     def pattern_build(self, dofs=1, block_mode=BLOCK_SCALAR) -> int:
         nnz = C.c_int64()
@@ -480,6 +538,52 @@ class Context:
         for r in reqs:
             r.wait()
         self.halo_requests_set(from_me, np.concatenate([t.numpy() for t in recv]) if from_me.sum() else np.zeros(0, np.int64))
+
+    def comm_set_thread_group(self, group):
+        """Host-staged transport between the threads of a `ThreadGroup` (see there); finalises the halo
+        plan over it.  Sums of the all-reduce are formed in rank order on every rank (same bits everywhere)."""
+        rank = self.rank
+
+        def exchange(user, n_peers, peers, send_ptr, send_buf, recv_ptr, recv_buf, dofs):
+            try:
+                if n_peers == 0:
+                    return 0
+                sb = np.ctypeslib.as_array(send_buf, shape=(max(1, send_ptr[n_peers] * dofs),))
+                out = np.ctypeslib.as_array(recv_buf, shape=(max(1, recv_ptr[n_peers] * dofs),))
+                for k in range(n_peers):
+                    s0, s1 = send_ptr[k] * dofs, send_ptr[k + 1] * dofs
+                    if s1 > s0:
+                        group.send(rank, int(peers[k]), sb[s0:s1])
+                for k in range(n_peers):
+                    r0, r1 = recv_ptr[k] * dofs, recv_ptr[k + 1] * dofs
+                    if r1 > r0:
+                        out[r0:r1] = group.recv(int(peers[k]), rank)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("exchange callback failed:", repr(e), flush=True)
+                return 1
+
+        def allreduce(user, buf, n):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(n,))
+                parts = group.allgather(rank, a.copy())
+                tot = parts[0].copy()
+                for q in parts[1:]:
+                    tot += q
+                a[:] = tot
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("allreduce callback failed:", repr(e), flush=True)
+                return 1
+
+        self._cb = (EXCHANGE_FN(exchange), ALLREDUCE_FN(allreduce))     # keep alive
+        _chk(self._L.fedd_comm_set_host_callbacks(self._h, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None))
+        cnt, gids = self.halo_requests()
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        everyone = group.allgather(rank, (cnt.copy(), gids.copy(), off))
+        from_me = np.array([int(everyone[p][0][rank]) for p in range(group.world)], dtype=np.int64)
+        lists = [everyone[p][1][everyone[p][2][rank]:everyone[p][2][rank + 1]] for p in range(group.world)]
+        self.halo_requests_set(from_me, np.concatenate(lists).astype(np.int64) if from_me.sum() else np.zeros(0, np.int64))
 
     def halo_exchange_setup(self):
         _chk(self._L.fedd_halo_exchange_setup(self._h))

@@ -147,9 +147,9 @@ extern "C" int fedd_sync(fedd_ctx* c) {
     return 0;
 }
 
-extern "C" int fedd_mesh_set(fedd_ctx* c, int dim, int nen, int64_t n_elem, const int32_t* conn,
-                             int64_t n_rep, const double* xyz, const int64_t* gid_rep, int64_t n_uni,
-                             const int64_t* gid_uni, const int32_t* bcflag_uni) {
+static int mesh_set_impl(fedd_ctx* c, int dim, int nen, int64_t n_elem, const int32_t* conn, int64_t n_rep,
+                         const double* xyz, const int64_t* gid_rep, int64_t n_uni, const int64_t* gid_uni,
+                         const int32_t* bcflag_uni, int64_t n_rg, const int64_t* rg_gid, const int32_t* rg_flag) {
     FEDD_CHECK(c, "fedd_mesh_set: null context");
     FEDD_CHECK(dim == 2 || dim == 3, "fedd_mesh_set: dimension must be 2 or 3");
     const bool okel = (dim == 2 && (nen == 3 || nen == 6)) || (dim == 3 && (nen == 4 || nen == 10));
@@ -163,6 +163,7 @@ extern "C" int fedd_mesh_set(fedd_ctx* c, int dim, int nen, int64_t n_elem, cons
     c->nen = nen;
     c->n_elem = n_elem;
     c->n_own = n_uni;
+    c->n_rowg = 0;
     c->have_adj = c->have_pattern = c->have_schwarz = c->have_coarse = false;
     c->halo = fedd::HaloPlan();
 
@@ -173,6 +174,15 @@ extern "C" int fedd_mesh_set(fedd_ctx* c, int dim, int nen, int64_t n_elem, cons
         auto ins = own.emplace(gid_uni[i], (int32_t)i);
         FEDD_CHECK(ins.second, "fedd_mesh_set: global id %lld listed twice in the unique map", (long long)gid_uni[i]);
     }
+    // row ghosts (nodes of other ranks whose rows are complete here) are numbered before the other ghosts
+    std::unordered_map<int64_t, int32_t> rowg;
+    rowg.reserve((size_t)n_rg * 2);
+    for (int64_t i = 0; i < n_rg; ++i) {
+        FEDD_CHECK(own.find(rg_gid[i]) == own.end(), "fedd_mesh_set_rows: node %lld is owned by this rank", (long long)rg_gid[i]);
+        auto ins = rowg.emplace(rg_gid[i], rg_flag ? rg_flag[i] : 0);
+        FEDD_CHECK(ins.second, "fedd_mesh_set_rows: global id %lld listed twice", (long long)rg_gid[i]);
+    }
+    const int64_t CLASS2 = (int64_t)1 << 62;        // sort key offset of the ghosts without rows
     std::vector<int32_t> col_of_rep((size_t)n_rep, -1);
     std::vector<std::pair<int64_t, int32_t>> ghosts;
     std::vector<char> seen((size_t)n_uni, 0);
@@ -182,21 +192,32 @@ extern "C" int fedd_mesh_set(fedd_ctx* c, int dim, int nen, int64_t n_elem, cons
             col_of_rep[i] = it->second;
             seen[it->second] = 1;
         } else {
-            ghosts.emplace_back(gid_rep[i], (int32_t)i);
+            FEDD_CHECK(gid_rep[i] >= 0 && gid_rep[i] < CLASS2, "fedd_mesh_set: global id %lld out of range", (long long)gid_rep[i]);
+            ghosts.emplace_back(gid_rep[i] + (rowg.count(gid_rep[i]) ? 0 : CLASS2), (int32_t)i);
         }
     }
     for (int64_t i = 0; i < n_uni; ++i)
         FEDD_CHECK(seen[i], "fedd_mesh_set: unique node %lld is missing from the repeated map", (long long)gid_uni[i]);
     std::sort(ghosts.begin(), ghosts.end());
-    int64_t ng = 0;
+    int64_t ng = 0, ng_rows = 0;
     std::vector<int64_t> ghost_gid;
+    std::vector<int32_t> flags_rg;
     for (size_t k = 0; k < ghosts.size(); ++k) {
         if (k == 0 || ghosts[k].first != ghosts[k - 1].first) {
-            ghost_gid.push_back(ghosts[k].first);
+            const bool with_rows = ghosts[k].first < CLASS2;
+            const int64_t g = with_rows ? ghosts[k].first : ghosts[k].first - CLASS2;
+            ghost_gid.push_back(g);
+            if (with_rows) {
+                flags_rg.push_back(rowg[g]);
+                ++ng_rows;
+            }
             ++ng;
         }
         col_of_rep[ghosts[k].second] = (int32_t)(n_uni + ng - 1);
     }
+    FEDD_CHECK(ng_rows == n_rg, "fedd_mesh_set_rows: %lld of the %lld row ghosts are not in the repeated map",
+               (long long)(n_rg - ng_rows), (long long)n_rg);
+    c->n_rowg = ng_rows;
     c->n_node = n_uni + ng;
     c->h_node_gid.assign(gid_uni, gid_uni + n_uni);
     c->h_node_gid.insert(c->h_node_gid.end(), ghost_gid.begin(), ghost_gid.end());
@@ -214,15 +235,33 @@ extern "C" int fedd_mesh_set(fedd_ctx* c, int dim, int nen, int64_t n_elem, cons
     FEDD_HIP(hipSetDevice(c->device));
     FEDD_TRY(c->d_conn.ensure(conn2.size()));
     FEDD_TRY(c->d_xyz.ensure(xyz2.size()));
-    FEDD_TRY(c->d_flag.ensure((size_t)n_uni));
+    FEDD_TRY(c->d_flag.ensure((size_t)(n_uni + ng_rows)));
     FEDD_HIP(hipMemcpyAsync(c->d_conn.p, conn2.data(), conn2.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     FEDD_HIP(hipMemcpyAsync(c->d_xyz.p, xyz2.data(), xyz2.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (bcflag_uni)
         FEDD_HIP(hipMemcpyAsync(c->d_flag.p, bcflag_uni, (size_t)n_uni * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     else
         FEDD_HIP(hipMemsetAsync(c->d_flag.p, 0, (size_t)n_uni * sizeof(int32_t), c->stream));
+    if (ng_rows)
+        FEDD_HIP(hipMemcpyAsync(c->d_flag.p + n_uni, flags_rg.data(), (size_t)ng_rows * sizeof(int32_t), hipMemcpyHostToDevice,
+                                c->stream));
     FEDD_HIP(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+extern "C" int fedd_mesh_set(fedd_ctx* c, int dim, int nen, int64_t n_elem, const int32_t* conn,
+                             int64_t n_rep, const double* xyz, const int64_t* gid_rep, int64_t n_uni,
+                             const int64_t* gid_uni, const int32_t* bcflag_uni) {
+    return mesh_set_impl(c, dim, nen, n_elem, conn, n_rep, xyz, gid_rep, n_uni, gid_uni, bcflag_uni, 0, nullptr, nullptr);
+}
+
+extern "C" int fedd_mesh_set_rows(fedd_ctx* c, int dim, int nen, int64_t n_elem, const int32_t* conn, int64_t n_rep,
+                                  const double* xyz, const int64_t* gid_rep, int64_t n_uni, const int64_t* gid_uni,
+                                  const int32_t* bcflag_uni, int64_t n_row_ghosts, const int64_t* row_ghost_gid,
+                                  const int32_t* row_ghost_bcflag) {
+    FEDD_CHECK(n_row_ghosts >= 0 && (n_row_ghosts == 0 || row_ghost_gid), "fedd_mesh_set_rows: null row-ghost list");
+    return mesh_set_impl(c, dim, nen, n_elem, conn, n_rep, xyz, gid_rep, n_uni, gid_uni, bcflag_uni, n_row_ghosts,
+                         row_ghost_gid, row_ghost_bcflag);
 }
 
 extern "C" int fedd_pattern_build(fedd_ctx* c, int dofs_per_node, int block_mode, int64_t* nnz_out) {
@@ -550,6 +589,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     FEDD_CHECK(c && key, "fedd_set_option: null");
     const std::string k(key);
     if (k == "spmv_kind") c->spmv_kind = (int)value;
+    else if (k == "box_kind") c->box_kind = (int)value;
     else if (k == "asm_kind") c->asm_kind = (int)value;
     else if (k == "apply_kind") c->apply_kind = (int)value;
     else if (k == "inv_kind") c->inv_kind = (int)value;

@@ -570,9 +570,9 @@ int launch_pairs(fedd_ctx* c, const AsmArgs& a, int ntab, int64_t n_rows, int ro
 template <int DIM, int NEN>
 int launch_assemble(fedd_ctx* c, int kform, const AsmArgs& a, int ntab) {
     if (c->asm_kind == 0) {
-        if (kform == F_LAPLACE) return launch_pairs<DIM, NEN, F_LAPLACE>(c, a, ntab, c->n_rows, c->max_row_nnz);
-        if (kform == F_MASS) return launch_pairs<DIM, NEN, F_MASS>(c, a, ntab, c->n_rows, c->max_row_nnz);
-        return launch_pairs<DIM, NEN, F_LINELAS>(c, a, ntab, c->n_rows, c->max_row_nnz);
+        if (kform == F_LAPLACE) return launch_pairs<DIM, NEN, F_LAPLACE>(c, a, ntab, c->n_rows_ext, c->max_row_nnz);
+        if (kform == F_MASS) return launch_pairs<DIM, NEN, F_MASS>(c, a, ntab, c->n_rows_ext, c->max_row_nnz);
+        return launch_pairs<DIM, NEN, F_LINELAS>(c, a, ntab, c->n_rows_ext, c->max_row_nnz);
     }
     const int rowcap = std::max(1, c->max_row_nnz);
     int bs = 256;
@@ -580,7 +580,7 @@ int launch_assemble(fedd_ctx* c, int kform, const AsmArgs& a, int ntab) {
     while (bs > 64 && need(bs) > 64 * 1024) bs >>= 1;
     const size_t lds = need(bs);
     FEDD_CHECK(lds <= 160 * 1024, "assembly: a CSR row with %d entries does not fit the LDS row buffer", rowcap);
-    const dim3 grid((unsigned)((c->n_rows + bs - 1) / bs)), block(bs);
+    const dim3 grid((unsigned)((c->n_rows_ext + bs - 1) / bs)), block(bs);
     auto go = [&](auto kern) -> int {
         if (lds > 64 * 1024)
             FEDD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -761,7 +761,7 @@ int assemble_matrix(fedd_ctx* c, int form, const double* params) {
     AsmArgs a;
     a.conn = c->d_conn.p; a.n2e_ptr = c->d_n2e_ptr.p; a.n2e = c->d_n2e.p; a.rowptr = c->d_rowptr.p;
     a.colind = c->d_colind.p; a.xyz = c->d_xyz.p; a.val = c->d_val.p; a.tab = c->d_dtmp0.p;
-    a.nq = nq; a.n_rows = (int32_t)c->n_rows; a.dofs = c->dofs;
+    a.nq = nq; a.n_rows = (int32_t)c->n_rows_ext; a.dofs = c->dofs;
     a.p0 = params ? params[0] : 0.0;
     a.p1 = params ? params[1] : 0.0;
     c->have_schwarz = false;
@@ -810,7 +810,7 @@ int apply_dirichlet_nodes(fedd_ctx* c, int64_t n, const int32_t* nodes, const in
     if (n == 0) return 0;
     const int dofs = c->dofs;
     for (int64_t k = 0; k < n; ++k)
-        FEDD_CHECK(nodes[k] >= 0 && nodes[k] < c->n_own, "fedd_dirichlet_nodes: node %d is not an owned node", nodes[k]);
+        FEDD_CHECK(nodes[k] >= 0 && nodes[k] < c->n_own + c->n_rowg, "fedd_dirichlet_nodes: node %d has no rows on this rank", nodes[k]);
     FEDD_TRY(c->d_itmp0.ensure(std::max<size_t>((size_t)n * (1 + dofs), c->d_itmp0.cap)));
     FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>((size_t)n * dofs, c->d_dtmp0.cap)));
     int32_t* d_nodes = c->d_itmp0.p;
@@ -863,10 +863,11 @@ int apply_dirichlet(fedd_ctx* c, int n_bc, const int32_t* flags, const int32_t* 
             b.value[k * c->dofs + d] = values[k * c->dofs + d];
         }
     }
-    const dim3 grid((unsigned)((c->n_rows + 255) / 256)), block(256);
+    // row-ghost rows get the same treatment as owned ones (their flags follow the owned flags in d_flag)
+    const dim3 grid((unsigned)((c->n_rows_ext + 255) / 256)), block(256);
     ScopedTimer t(c, FEDD_T_DIRICHLET);
     hipLaunchKernelGGL(k_dirichlet, grid, block, 0, c->stream, b, c->d_flag.p, c->d_rowptr.p, c->d_colind.p,
-                       c->d_val.p, c->d_rhs.p, c->d_isdir.p, (int32_t)c->n_rows);
+                       c->d_val.p, c->d_rhs.p, c->d_isdir.p, (int32_t)c->n_rows_ext);
     t.stop();
     FEDD_HIP(hipGetLastError());
     c->have_schwarz = false;

@@ -135,8 +135,10 @@ int block_merge(fedd_ctx* c, int slot_a, int slot_bt, int slot_b, int slot_c) {
     FEDD_TRY(c->d_dof_node.ensure((size_t)n));
     hipLaunchKernelGGL(k_dof_node, grid, blk, 0, c->stream, (int32_t)nA, (int32_t)nB, dofsA, c->d_dof_node.p);
     c->n_rows = n;
+    c->n_rows_ext = n;
     c->n_cols = n;
     c->nnz = nnz;
+    c->nnz_ext = nnz;
     c->max_row_nnz = mx;
     c->merged = true;
     c->merged_nA = nA;

@@ -606,31 +606,8 @@ int coarse_setup(fedd_ctx* c) {
     FEDD_CHECK(c->n_rows == (int64_t)dofs * c->n_own, "coarse setup: the system is not node-interleaved");
     // ---- global bounding box and node count ----
     double lo[3], hi[3];
-    FEDD_TRY(bounding_box(c, n_own, lo, hi));
     double n_global = (double)n_own;
-    if (c->nranks > 1) {
-        // min / max over ranks through the sum transport: every rank fills its own slots
-        const int nr = c->nranks, len = nr * 7;
-        std::vector<double> h((size_t)len, 0.0);
-        for (int d = 0; d < 3; ++d) {
-            h[(size_t)c->rank * 7 + d] = lo[d];
-            h[(size_t)c->rank * 7 + 3 + d] = hi[d];
-        }
-        h[(size_t)c->rank * 7 + 6] = (double)n_own;
-        FEDD_TRY(c->d_co_r0.ensure(std::max<size_t>((size_t)len, c->d_co_r0.cap)));
-        FEDD_HIP(hipMemcpyAsync(c->d_co_r0.p, h.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, len));
-        FEDD_HIP(hipMemcpyAsync(h.data(), c->d_co_r0.p, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        FEDD_HIP(hipStreamSynchronize(c->stream));
-        n_global = 0.0;
-        for (int r = 0; r < nr; ++r) {
-            for (int d = 0; d < 3; ++d) {
-                lo[d] = std::min(lo[d], h[(size_t)r * 7 + d]);
-                hi[d] = std::max(hi[d], h[(size_t)r * 7 + 3 + d]);
-            }
-            n_global += h[(size_t)r * 7 + 6];
-        }
-    }
+    FEDD_TRY(global_box(c, n_own, lo, hi, &n_global));
     // ---- lattice: g_d = max(1, floor(L_d / H + 0.5)), H = (V / cells_target)^(1/dim) ----
     double target = c->co_cells_target;
     // default: one cell per 1000 nodes, at most 12^3 cells (K0 is dense and replicated: 2197^2 doubles
@@ -731,6 +708,7 @@ int coarse_setup(fedd_ctx* c) {
     if (c->nranks > 1) {
         // every rank must take the same decision: share the flags (and add up the free dofs)
         double hb[3] = {(double)bad[0], (double)bad[1], n_free};
+        FEDD_TRY(c->d_co_r0.ensure(std::max<size_t>(3, c->d_co_r0.cap)));
         FEDD_HIP(hipMemcpyAsync(c->d_co_r0.p, hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
         FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, 3));
         FEDD_HIP(hipMemcpyAsync(hb, c->d_co_r0.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));

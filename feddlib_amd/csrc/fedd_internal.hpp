@@ -122,6 +122,7 @@ struct fedd_ctx {
     //      sorted by global id) ----
     int dim = 0, nen = 0;
     int64_t n_elem = 0, n_own = 0, n_node = 0;  // n_node = owned + ghost
+    int64_t n_rowg = 0;                         // ghost nodes [n_own, n_own + n_rowg) whose rows are complete here (fedd_mesh_set_rows)
     std::vector<int64_t> h_node_gid;            // [n_node]
     std::vector<int32_t> h_ghost_owner;         // [n_node - n_own]
     fedd::DevBuf<int32_t> d_conn;               // [n_elem*nen]
@@ -136,6 +137,9 @@ struct fedd_ctx {
     // ---- CSR (dof level, owned rows) ----
     int dofs = 0, block_mode = 0;
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    // with row ghosts the CSR arrays continue past the owned rows: rows [n_rows, n_rows_ext) are those of the
+    // row-ghost nodes (read by the Schwarz local matrices only); n_rows / nnz stay the owned part
+    int64_t n_rows_ext = 0, nnz_ext = 0;
     int max_row_nnz = 0;
     fedd::DevBuf<int32_t> d_rowptr, d_colind;
     fedd::DevBuf<double> d_val;
@@ -143,6 +147,7 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_xcol, d_ycol;        // [n_cols] work vectors with ghost tail
     fedd::DevBuf<int32_t> d_isdir;              // [n_rows] 1 = Dirichlet row
     bool have_pattern = false;
+    int box_kind = 0;                           // Schwarz boxes: 0 = one lattice over all ranks' nodes, 1 = per-rank lattice
     int spmv_kind = 0;                          // 0 = CSR-window / automatic, 1 = row-per-lane-group, 2 = CSR-stream
     int asm_kind = 0;                           // 0 = pair-parallel assembly, 1 = lane-per-row gather
     fedd::DevBuf<int32_t> d_pat_stash;          // pattern build: merged node lists of the count pass, [k][node]
@@ -272,6 +277,7 @@ int halo_import(fedd_ctx* c, double* d_xcol, int dofs);                    // fi
 int schwarz_setup(fedd_ctx* c);
 int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned);
 int bounding_box(fedd_ctx* c, int64_t n_nodes, double lo[3], double hi[3]);   // of d_xyz[0, n_nodes)
+int global_box(fedd_ctx* c, int64_t n_own, double lo[3], double hi[3], double* n_global);   // over all ranks
 
 // invert_mfma.hip: local inverses of plain systems, n <= 128, on the f64 matrix cores
 int schwarz_invert_mfma(fedd_ctx* c, int restricted, int32_t* d_bad, int max_n);

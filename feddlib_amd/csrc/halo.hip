@@ -98,9 +98,12 @@ extern "C" int fedd_halo_set_owners(fedd_ctx* c, int64_t n_rep, const int64_t* g
                    "fedd_halo_set_owners: ghost node %lld has owner %d", (long long)gid_rep[i], owner_rep[i]);
         owner[it->second - c->n_own] = owner_rep[i];
     }
+    // with row ghosts declared (fedd_mesh_set_rows) only they are imported: the owned rows and the Schwarz
+    // subdomains reach no further, the outer ghost layer exists for its elements only
+    const int64_t ng_req = c->n_rowg > 0 ? c->n_rowg : ng;
     std::vector<std::pair<int32_t, int64_t>> order;  // (owner, gid)
-    order.reserve((size_t)ng);
-    for (int64_t k = 0; k < ng; ++k) {
+    order.reserve((size_t)ng_req);
+    for (int64_t k = 0; k < ng_req; ++k) {
         FEDD_CHECK(owner[k] >= 0, "fedd_halo_set_owners: no owner given for ghost node %lld", (long long)c->h_node_gid[c->n_own + k]);
         order.emplace_back(owner[k], c->h_node_gid[c->n_own + k]);
     }

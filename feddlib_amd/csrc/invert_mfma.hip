@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void k_invert_mfma(const int32_t* __restric
 // size classes n <= 16 T, T = 2, 4, 6, 7, 8; subdomains above 128 dofs are left to the caller
 int schwarz_invert_mfma(fedd_ctx* c, int restricted, int32_t* d_bad, int max_n) {
     const dim3 grid((unsigned)c->sw_nsub), blk(256);
-    const int32_t n_rows = (int32_t)c->n_rows;
+    const int32_t n_rows = (int32_t)c->n_rows_ext;   // rows the local matrices can read (owned + row ghosts)
 #define INV_MFMA(T, LO, HI)                                                                                    \
     if (max_n > (LO))                                                                                          \
         hipLaunchKernelGGL(k_invert_mfma<T>, grid, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,            \

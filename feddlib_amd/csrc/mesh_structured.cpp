@@ -6,7 +6,11 @@
 //   setStructuredMeshFlags(1)               feddlib/core/Mesh/MeshStructured_def.hpp:2974-3203
 //   Map::buildUniqueMap                     feddlib/core/LinearAlgebra/Map_def.hpp:184-210
 // Layout differences: flat SoA arrays instead of vector<vector<>>, per-direction block counts
-// (the reference only knows N x N x N), optional ghost-element layer, lowest-rank owner rule.
+// (the reference only knows N x N x N), optional ghost-element layers, lowest-rank owner rule.
+// Ghost modes: 0 = the reference's block; 1 = plus the layer of cells above the block that completes the
+// rows of the owned nodes; 2 = plus one more layer on every side that has a neighbour, which completes the
+// rows of the first layer of ghost nodes as well ("row ghosts": the Schwarz local matrices then hold true
+// rows for the overlap nodes that belong to other ranks).
 #include "fedd_internal.hpp"
 #include <cmath>
 #include <limits>
@@ -16,15 +20,22 @@ namespace {
 struct Block {
     int dim;
     int N[3], M[3], off[3];
-    int up[3];        // 1 if a neighbour block exists in +d
+    int up[3];        // layers of ghost lattice planes above the block in d (0, 1 or 2)
+    int dn[3];        // layers below (0 or 1; mode 2 with a lower neighbour)
+    int mode;
     int lo_owned[3];  // first owned lattice index in d (0, or 1 when a lower neighbour owns the face)
     int64_t P[3];     // global points per direction
     int n1[3];        // own lattice points per direction (M+1)
-    int ne[3];        // extended lattice points per direction (M+1+up)
+    int ne[3];        // extended lattice points per direction (dn + M+1 + up)
 };
 
-int make_block(int dim, const int* decomp, const int* cells, int rank, bool ghosts, Block& b) {
+int make_block(int dim, const int* decomp, const int* cells, int rank, int ghosts, Block& b) {
     b.dim = dim;
+    b.mode = ghosts;
+    if (ghosts < 0 || ghosts > 2) {
+        fedd::set_error("structured mesh: ghost mode %d (0, 1 or 2)", ghosts);
+        return 1;
+    }
     int64_t nr = 1;
     for (int d = 0; d < 3; ++d) {
         b.N[d] = d < dim ? decomp[d] : 1;
@@ -46,35 +57,59 @@ int make_block(int dim, const int* decomp, const int* cells, int rank, bool ghos
     for (int d = 0; d < 3; ++d) {
         b.P[d] = d < dim ? (int64_t)b.N[d] * b.M[d] + 1 : 1;
         b.n1[d] = d < dim ? b.M[d] + 1 : 1;
-        b.up[d] = (d < dim && ghosts && b.off[d] + 1 < b.N[d]) ? 1 : 0;
-        b.ne[d] = b.n1[d] + b.up[d];
+        b.up[d] = (d < dim && ghosts && b.off[d] + 1 < b.N[d]) ? ghosts : 0;
+        b.dn[d] = (d < dim && ghosts == 2 && b.off[d] > 0) ? 1 : 0;
+        b.ne[d] = b.dn[d] + b.n1[d] + b.up[d];
         b.lo_owned[d] = (d < dim && b.off[d] > 0) ? 1 : 0;
+        if (ghosts == 2 && d < dim && b.N[d] > 1 && b.M[d] < 2) {
+            fedd::set_error("structured mesh: two ghost layers need at least 2 cells per block and direction");
+            return 1;
+        }
     }
     return 0;
 }
 
-// local repeated id of extended-lattice point (r,s,t): the reference's (M+1)^dim block first in
-// its own order (r fastest), then the extra points in extended-lattice order.
+// lattice indices run over [-dn, M + up] per direction (0 .. M = the reference's own block)
+inline bool in_own_lattice(const Block& b, int r, int s, int t) {
+    return r >= 0 && r < b.n1[0] && s >= 0 && s < b.n1[1] && t >= 0 && t < b.n1[2];
+}
+// own lattice plus the first plane above it: the nodes whose rows are complete in mode 2
+inline bool in_row_box(const Block& b, int r, int s, int t) {
+    return r >= 0 && r < b.n1[0] + (b.up[0] ? 1 : 0) && s >= 0 && s < b.n1[1] + (b.up[1] ? 1 : 0) && t >= 0 &&
+           t < b.n1[2] + (b.up[2] ? 1 : 0);
+}
+
+// local repeated id of lattice point (r,s,t): the reference's (M+1)^dim block first in its own order
+// (r fastest), then the extra points of the first plane above the block, then (mode 2) the outer layer,
+// each class in extended-lattice order.
 struct Numbering {
     const Block& b;
     std::vector<int32_t> ext_id;  // only for points outside the own lattice
     int64_t n_own_lattice;
+    int64_t n_first = 0;          // extra points of the first class
     explicit Numbering(const Block& blk) : b(blk) {
         n_own_lattice = (int64_t)b.n1[0] * b.n1[1] * b.n1[2];
         ext_id.assign((size_t)b.ne[0] * b.ne[1] * b.ne[2], -1);
         int32_t next = (int32_t)n_own_lattice;
-        for (int t = 0; t < b.ne[2]; ++t)
-            for (int s = 0; s < b.ne[1]; ++s)
-                for (int r = 0; r < b.ne[0]; ++r)
-                    if (r >= b.n1[0] || s >= b.n1[1] || t >= b.n1[2])
-                        ext_id[((size_t)t * b.ne[1] + s) * b.ne[0] + r] = next++;
+        for (int cls = 0; cls < 2; ++cls) {
+            for (int t = -b.dn[2]; t < b.n1[2] + b.up[2]; ++t)
+                for (int s = -b.dn[1]; s < b.n1[1] + b.up[1]; ++s)
+                    for (int r = -b.dn[0]; r < b.n1[0] + b.up[0]; ++r) {
+                        if (in_own_lattice(b, r, s, t)) continue;
+                        if ((cls == 0) != in_row_box(b, r, s, t)) continue;
+                        ext_id[slot(r, s, t)] = next++;
+                    }
+            if (cls == 0) n_first = next - n_own_lattice;
+        }
         n_rep = next;
     }
     int64_t n_rep = 0;
+    size_t slot(int r, int s, int t) const {
+        return ((size_t)(t + b.dn[2]) * b.ne[1] + (size_t)(s + b.dn[1])) * b.ne[0] + (size_t)(r + b.dn[0]);
+    }
     int32_t id(int r, int s, int t) const {
-        if (r < b.n1[0] && s < b.n1[1] && t < b.n1[2])
-            return (int32_t)(r + (int64_t)b.n1[0] * (s + (int64_t)b.n1[1] * t));
-        return ext_id[((size_t)t * b.ne[1] + s) * b.ne[0] + r];
+        if (in_own_lattice(b, r, s, t)) return (int32_t)(r + (int64_t)b.n1[0] * (s + (int64_t)b.n1[1] * t));
+        return ext_id[slot(r, s, t)];
     }
 };
 
@@ -91,19 +126,20 @@ inline bool owned_pt(const Block& b, int r, int s, int t) {
            t >= b.lo_owned[2] && t < b.n1[2];
 }
 
-// visit every element: own cells first in the reference order, then ghost cells (any index == M)
+// visit every element: own cells first in the reference order, then the ghost cells that touch an owned
+// point (mode 1) or a point of the row box (mode 2)
 template <class F>
 void for_each_element(const Block& b, F&& f) {
     const int dim = b.dim;
     const int nsub = dim == 3 ? 6 : 2;
     for (int pass = 0; pass < 2; ++pass) {
-        const int ct = dim == 3 ? b.M[2] + (pass ? b.up[2] : 0) : 1;
-        const int cs = b.M[1] + (pass ? b.up[1] : 0);
-        const int cr = b.M[0] + (pass ? b.up[0] : 0);
-        for (int t = 0; t < ct; ++t)
-            for (int s = 0; s < cs; ++s)
-                for (int r = 0; r < cr; ++r) {
-                    const bool ghost_cell = r >= b.M[0] || s >= b.M[1] || (dim == 3 && t >= b.M[2]);
+        const int t0 = pass ? -b.dn[2] : 0, t1 = dim == 3 ? b.M[2] + (pass ? b.up[2] : 0) : 1;
+        const int s0 = pass ? -b.dn[1] : 0, s1 = b.M[1] + (pass ? b.up[1] : 0);
+        const int r0 = pass ? -b.dn[0] : 0, r1 = b.M[0] + (pass ? b.up[0] : 0);
+        for (int t = t0; t < t1; ++t)
+            for (int s = s0; s < s1; ++s)
+                for (int r = r0; r < r1; ++r) {
+                    const bool ghost_cell = r < 0 || s < 0 || t < 0 || r >= b.M[0] || s >= b.M[1] || (dim == 3 && t >= b.M[2]);
                     if ((pass == 0) == ghost_cell) continue;
                     for (int k = 0; k < nsub; ++k) {
                         int pr[4], ps[4], pt[4];
@@ -118,7 +154,8 @@ void for_each_element(const Block& b, F&& f) {
                                 ps[v] = s + TRIS[k][v][1];
                                 pt[v] = 0;
                             }
-                            touches = touches || owned_pt(b, pr[v], ps[v], pt[v]);
+                            touches = touches || (b.mode == 2 ? in_row_box(b, pr[v], ps[v], pt[v])
+                                                              : owned_pt(b, pr[v], ps[v], pt[v]));
                         }
                         if (ghost_cell && !touches) continue;
                         f(pr, ps, pt, ghost_cell);
@@ -157,7 +194,7 @@ extern "C" int fedd_mesh_structured_sizes(int dim, const int* decomp, const int*
                                           int64_t* n_uni, int64_t* n_global) {
     FEDD_CHECK(dim == 2 || dim == 3, "structured mesh: dimension must be 2 or 3");
     Block b;
-    FEDD_TRY(make_block(dim, decomp, cells, rank, with_ghost_elements != 0, b));
+    FEDD_TRY(make_block(dim, decomp, cells, rank, with_ghost_elements, b));
     int64_t ne = 0;
     for_each_element(b, [&](const int*, const int*, const int*, bool) { ++ne; });
     int64_t nrep = (int64_t)b.n1[0] * b.n1[1] * b.n1[2];
@@ -179,7 +216,7 @@ extern "C" int fedd_mesh_structured_build(int dim, const int* decomp, const int*
     FEDD_CHECK(dim == 2 || dim == 3, "structured mesh: dimension must be 2 or 3");
     FEDD_CHECK(flags_option == 0 || flags_option == 1, "structured mesh: flags option %d not supported", flags_option);
     Block b;
-    FEDD_TRY(make_block(dim, decomp, cells, rank, with_ghost_elements != 0, b));
+    FEDD_TRY(make_block(dim, decomp, cells, rank, with_ghost_elements, b));
     Numbering num(b);
     double o[3] = {0, 0, 0}, sz[3] = {1, 1, 1}, h[3] = {0, 0, 0}, H[3] = {0, 0, 0};
     for (int d = 0; d < dim; ++d) {
@@ -191,9 +228,9 @@ extern "C" int fedd_mesh_structured_build(int dim, const int* decomp, const int*
     const double eps = std::numeric_limits<double>::epsilon();
     const double snap = dim == 3 ? eps : 100 * eps;  // :727-734 vs :371-374
     int64_t nu = 0;
-    for (int t = 0; t < b.ne[2]; ++t)
-        for (int s = 0; s < b.ne[1]; ++s)
-            for (int r = 0; r < b.ne[0]; ++r) {
+    for (int t = -b.dn[2]; t < b.n1[2] + b.up[2]; ++t)
+        for (int s = -b.dn[1]; s < b.n1[1] + b.up[1]; ++s)
+            for (int r = -b.dn[0]; r < b.n1[0] + b.up[0]; ++r) {
                 const int32_t id = num.id(r, s, t);
                 const int l[3] = {r, s, t};
                 double p[3] = {0, 0, 0};
@@ -204,6 +241,9 @@ extern "C" int fedd_mesh_structured_build(int dim, const int* decomp, const int*
                     if (ll >= b.n1[d]) {
                         ll -= b.M[d];
                         oo += 1;
+                    } else if (ll < 0) {
+                        ll += b.M[d];
+                        oo -= 1;
                     }
                     double c = ll * h[d] + oo * H[d];
                     if (c < snap && c > -snap) c = 0.0;
@@ -242,5 +282,58 @@ extern "C" int fedd_mesh_structured_build(int dim, const int* decomp, const int*
         for (int v = 0; v < nen; ++v) conn[e * nen + v] = num.id(pr[v], ps[v], pt[v]);
         ++e;
     });
+    return 0;
+}
+
+/* Mode 2: the repeated-map nodes whose matrix rows are complete on this rank although another rank owns
+ * them (own-lattice points of lower neighbours and the first plane above the block): count, or with
+ * arrays their global ids and boundary flags -- the arguments of fedd_mesh_set_rows. */
+extern "C" int fedd_mesh_structured_row_ghosts(int dim, const int* decomp, const int* cells, int rank, const double* origin,
+                                               const double* size, int flags_option, int64_t* n_out, int64_t* gid,
+                                               int32_t* flag) {
+    FEDD_CHECK(dim == 2 || dim == 3, "structured mesh: dimension must be 2 or 3");
+    Block b;
+    FEDD_TRY(make_block(dim, decomp, cells, rank, 2, b));
+    double o[3] = {0, 0, 0}, sz[3] = {1, 1, 1}, h[3] = {0, 0, 0}, H[3] = {0, 0, 0};
+    for (int d = 0; d < dim; ++d) {
+        if (origin) o[d] = origin[d];
+        if (size) sz[d] = size[d];
+        h[d] = sz[d] / (b.M[d] * b.N[d]);
+        H[d] = sz[d] / b.N[d];
+    }
+    const double eps = std::numeric_limits<double>::epsilon();
+    const double snap = dim == 3 ? eps : 100 * eps;
+    int64_t n = 0;
+    for (int t = 0; t < b.n1[2] + (b.up[2] ? 1 : 0); ++t)
+        for (int s = 0; s < b.n1[1] + (b.up[1] ? 1 : 0); ++s)
+            for (int r = 0; r < b.n1[0] + (b.up[0] ? 1 : 0); ++r) {
+                if (owned_pt(b, r, s, t)) continue;
+                if (gid || flag) {
+                    const int l[3] = {r, s, t};
+                    double p[3] = {0, 0, 0};
+                    int64_t g[3] = {0, 0, 0};
+                    for (int d = 0; d < dim; ++d) {
+                        int ll = l[d], oo = b.off[d];
+                        if (ll >= b.n1[d]) {
+                            ll -= b.M[d];
+                            oo += 1;
+                        }
+                        double c = ll * h[d] + oo * H[d];
+                        if (c < snap && c > -snap) c = 0.0;
+                        p[d] = c;
+                        g[d] = (int64_t)l[d] + (int64_t)b.off[d] * b.M[d];
+                    }
+                    if (gid) gid[n] = g[0] + b.P[0] * (g[1] + b.P[1] * g[2]);
+                    if (flag) {
+                        int32_t f = 0;
+                        for (int d = 0; d < dim; ++d)
+                            if (p[d] > o[d] + sz[d] - snap || p[d] < o[d] + snap) f = 1;
+                        if (flags_option == 1) f = flags_option1(dim, p, f, o, sz);
+                        flag[n] = f;
+                    }
+                }
+                ++n;
+            }
+    if (n_out) *n_out = n;
     return 0;
 }

@@ -113,12 +113,14 @@ __global__ void k_sort_bins(const int32_t* __restrict__ ptr, int32_t nb, int32_t
 }
 
 // One workgroup per bin: owned dofs first (sorted), then the dofs reached by `overlap` graph
-// layers (sorted).  Layers only grow through owned rows (a ghost row is not stored on this rank).
+// layers (sorted).  Layers grow through stored rows: the owned ones and those of the row ghosts
+// (n_stored >= n_rows; without row ghosts a ghost row is not stored on this rank).
 __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bin_ptr,
                                                   const int32_t* __restrict__ bin_nodes,
                                                   const int32_t* __restrict__ node_bin,
                                                   const int32_t* __restrict__ rowptr,
-                                                  const int32_t* __restrict__ colind, int32_t n_rows, int ghost_overlap,
+                                                  const int32_t* __restrict__ colind, int32_t n_rows, int32_t n_stored,
+                                                  int ghost_overlap,
                                                   int overlap, int32_t* __restrict__ sub_n,
                                                   int32_t* __restrict__ sub_nown, int32_t* __restrict__ sub_dofs) {
     __shared__ int32_t tab[HS];
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
         const int nsrc = layer == 0 ? n_own : s_prev;
         for (int k = tid; k < nsrc; k += 256) {
             const int32_t src = layer == 0 ? bin_nodes[nb + k] : lst[k];
-            if (src >= n_rows) continue;
+            if (src >= n_stored) continue;
             for (int32_t p = rowptr[src]; p < rowptr[src + 1]; ++p) {
                 const int32_t col = colind[p];
                 if (col < n_rows && node_bin[col] == b) continue;
@@ -648,18 +650,51 @@ int bounding_box(fedd_ctx* c, int64_t n_nodes, double lo[3], double hi[3]) {
     return 0;
 }
 
+// bounding box of the owned nodes of ALL ranks and their number (min / max through the sum transport:
+// every rank fills its own slots); every rank gets the same numbers
+int global_box(fedd_ctx* c, int64_t n_own, double lo[3], double hi[3], double* n_global) {
+    FEDD_TRY(bounding_box(c, n_own, lo, hi));
+    *n_global = (double)n_own;
+    if (c->nranks == 1) return 0;
+    const int nr = c->nranks, len = nr * 7;
+    std::vector<double> h((size_t)len, 0.0);
+    for (int d = 0; d < 3; ++d) {
+        h[(size_t)c->rank * 7 + d] = lo[d];
+        h[(size_t)c->rank * 7 + 3 + d] = hi[d];
+    }
+    h[(size_t)c->rank * 7 + 6] = (double)n_own;
+    FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>((size_t)len, c->d_dtmp0.cap)));
+    FEDD_HIP(hipMemcpyAsync(c->d_dtmp0.p, h.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    FEDD_TRY(allreduce_sum(c, c->d_dtmp0.p, len));
+    FEDD_HIP(hipMemcpyAsync(h.data(), c->d_dtmp0.p, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    *n_global = 0.0;
+    for (int r = 0; r < nr; ++r) {
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = std::min(lo[d], h[(size_t)r * 7 + d]);
+            hi[d] = std::max(hi[d], h[(size_t)r * 7 + 3 + d]);
+        }
+        *n_global += h[(size_t)r * 7 + 6];
+    }
+    return 0;
+}
+
 int schwarz_setup(fedd_ctx* c) {
     c->have_coarse = false;
     ScopedTimer timer(c, FEDD_T_SCHWARZ_SETUP);
     const int32_t n_own = (int32_t)c->n_own;
     const int dim = c->dim, dofs = c->dofs;
     const int32_t n_rows = (int32_t)c->n_rows;
+    const int32_t n_stored = (int32_t)c->n_rows_ext;   // rows the local matrices can read (owned + row ghosts)
     FEDD_CHECK(n_own > 0, "schwarz setup: no owned nodes");
-    // ---- bounding box of the owned nodes ----
+    // ---- bounding box and number of the owned nodes: of all ranks, so that the lattice of boxes is the
+    // one a single rank would lay over the whole mesh and a rank boundary only cuts the boxes it crosses
+    // (box_kind 1: each rank's own bounding box; costs iterations) ----
     BinGeom gm;
     gm.dim = dim;
-    double L[3] = {0, 0, 0}, bb_lo[3], bb_hi[3];
-    FEDD_TRY(bounding_box(c, n_own, bb_lo, bb_hi));
+    double L[3] = {0, 0, 0}, bb_lo[3], bb_hi[3], n_nodes = (double)n_own;
+    if (c->box_kind == 0) FEDD_TRY(global_box(c, n_own, bb_lo, bb_hi, &n_nodes));
+    else FEDD_TRY(bounding_box(c, n_own, bb_lo, bb_hi));
     for (int d = 0; d < dim; ++d) {
         gm.lo[d] = bb_lo[d];
         L[d] = bb_hi[d] - bb_lo[d];
@@ -670,7 +705,7 @@ int schwarz_setup(fedd_ctx* c) {
     // default target: 27 nodes for scalar problems, 27 / dofs for node-interleaved vector problems
     // (the dense local solver takes 256 dofs including the overlap)
     const int target = c->sw_target > 0 ? c->sw_target : (c->merged ? 27 : std::max(1, 27 / std::max(1, dofs)));
-    const double s = c->sw_scale * std::pow(V * (double)target / (double)n_own, 1.0 / dim);
+    const double s = c->sw_scale * std::pow(V * (double)target / n_nodes, 1.0 / dim);
     int64_t nraw = 1;
     for (int d = 0; d < 3; ++d) {
         gm.g[d] = 1;
@@ -715,7 +750,8 @@ int schwarz_setup(fedd_ctx* c) {
     // ---- overlapping dof lists ----
     hipLaunchKernelGGL(k_sub_dofs, dim3((unsigned)nsub), blk, 0, c->stream, (const int32_t*)c->d_bin_ptr.p,
                        (const int32_t*)c->d_bin_nodes.p, (const int32_t*)c->d_node_bin.p, (const int32_t*)c->d_rowptr.p,
-                       (const int32_t*)c->d_colind.p, n_rows, c->ghost_overlap, c->sw_overlap, c->d_sub_n.p, c->d_sub_nown.p,
+                       (const int32_t*)c->d_colind.p, n_rows, (int32_t)c->n_rows_ext, c->ghost_overlap, c->sw_overlap,
+                       c->d_sub_n.p, c->d_sub_nown.p,
                        c->d_sub_dofs.p);
     int32_t max_n = 0;
     FEDD_TRY(reduce_max_i32(c, c->d_sub_n.p, nsub, &max_n));
@@ -749,7 +785,7 @@ int schwarz_setup(fedd_ctx* c) {
         hipLaunchKernelGGL((k_invert_reg<T, TA>), grid, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,       \
                            (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,                   \
                            (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p,                       \
-                           (const double*)c->d_val.p, n_rows, restricted, (const int64_t*)c->d_inv_ptr.p,      \
+                           (const double*)c->d_val.p, n_stored, restricted, (const int64_t*)c->d_inv_ptr.p,      \
                            c->d_inv.p, d_bad, (LO), (HI), p_off, (OWN_LE))
         // restricted combine on a plain system: boxes with at most 32 owned dofs take the variant
         // that drops finished overlap rows from the update, the others the generic one
@@ -786,7 +822,7 @@ int schwarz_setup(fedd_ctx* c) {
         if (lds_nmax > n_skip)  // (the register-tiled classes now reach past what fits LDS)
         hipLaunchKernelGGL(k_invert<true>, dim3((unsigned)nsub), blk, lds, c->stream, (const int32_t*)c->d_sub_n.p,
                            (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const int32_t*)c->d_rowptr.p,
-                           (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, n_rows, restricted,
+                           (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, n_stored, restricted,
                            (const int64_t*)c->d_inv_ptr.p, c->d_inv.p, (double*)nullptr, (int64_t)0, lds_nmax, d_bad, 0, 0,
                            n_skip, p_off);
         if (max_n > lds_nmax) {
@@ -800,7 +836,7 @@ int schwarz_setup(fedd_ctx* c) {
                 hipLaunchKernelGGL(k_invert<false>, dim3(nb), blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
                                    (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
                                    (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p,
-                                   (const double*)c->d_val.p, n_rows, restricted, (const int64_t*)c->d_inv_ptr.p,
+                                   (const double*)c->d_val.p, n_stored, restricted, (const int64_t*)c->d_inv_ptr.p,
                                    c->d_inv.p, c->d_w.p, stride, lds_nmax, d_bad, (int)first, 1, n_skip, p_off);
             }
         }

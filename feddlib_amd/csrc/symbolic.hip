@@ -143,7 +143,7 @@ __global__ void k_expand_pattern(const int32_t* __restrict__ nptr, const int32_t
 
 int build_adjacency(fedd_ctx* c) {
     const int64_t n_ent = c->n_elem * c->nen;
-    const int32_t n_own = (int32_t)c->n_own;
+    const int32_t n_own = (int32_t)(c->n_own + c->n_rowg);   // every node that gets rows
     FEDD_TRY(c->d_n2e_ptr.ensure((size_t)n_own + 1));
     FEDD_TRY(c->d_itmp0.ensure((size_t)n_own + 1));
     int32_t* cnt = c->d_itmp0.p;
@@ -167,7 +167,7 @@ int build_adjacency(fedd_ctx* c) {
 }
 
 int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
-    const int32_t n_own = (int32_t)c->n_own;
+    const int32_t n_own = (int32_t)(c->n_own + c->n_rowg);   // every node that gets rows (owned, then row ghosts)
     const int nen = c->nen;
     // upper bound for the distinct columns of one node row
     int cap = c->max_deg * (nen - 1) + 1;
@@ -199,21 +199,30 @@ int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
     FEDD_CHECK(nnz < ((int64_t)1 << 31), "pattern build: %lld nonzeros exceed 32-bit local offsets", (long long)nnz);
     c->dofs = dofs;
     c->block_mode = block_mode;
-    c->n_rows = (int64_t)n_own * dofs;
+    c->n_rows = c->n_own * dofs;
+    c->n_rows_ext = (int64_t)n_own * dofs;
     c->n_cols = c->n_node * dofs;
+    c->nnz_ext = nnz;
     c->nnz = nnz;
+    if (c->n_rowg > 0) {   // nonzeros of the owned rows: the node row pointer at the first row ghost
+        int32_t owned_node_nnz = 0;
+        FEDD_HIP(hipMemcpyAsync(&owned_node_nnz, nptr + c->n_own, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        c->nnz = (int64_t)owned_node_nnz * mult;
+    }
     c->max_row_nnz = max_nn * (block_mode == FEDD_BLOCK_FULL ? dofs : 1);
-    FEDD_TRY(c->d_rowptr.ensure((size_t)c->n_rows + 1));
+    FEDD_TRY(c->d_rowptr.ensure((size_t)c->n_rows_ext + 1));
     FEDD_TRY(c->d_colind.ensure((size_t)nnz));
     FEDD_TRY(c->d_val.ensure((size_t)nnz));
-    FEDD_TRY(c->d_rhs.ensure((size_t)c->n_rows));
+    FEDD_TRY(c->d_rhs.ensure((size_t)c->n_rows_ext));      // the tail past n_rows is scratch of the Dirichlet kernels
     FEDD_TRY(c->d_x.ensure((size_t)c->n_rows));
     FEDD_TRY(c->d_xcol.ensure((size_t)c->n_cols));
-    FEDD_TRY(c->d_isdir.ensure((size_t)c->n_rows));
+    FEDD_TRY(c->d_isdir.ensure((size_t)c->n_rows_ext));
     FEDD_HIP(hipMemsetAsync(c->d_val.p, 0, (size_t)nnz * sizeof(double), c->stream));
-    FEDD_HIP(hipMemsetAsync(c->d_rhs.p, 0, (size_t)c->n_rows * sizeof(double), c->stream));
+    FEDD_HIP(hipMemsetAsync(c->d_rhs.p, 0, (size_t)c->n_rows_ext * sizeof(double), c->stream));
     FEDD_HIP(hipMemsetAsync(c->d_x.p, 0, (size_t)c->n_rows * sizeof(double), c->stream));
-    FEDD_HIP(hipMemsetAsync(c->d_isdir.p, 0, (size_t)c->n_rows * sizeof(int32_t), c->stream));
+    FEDD_HIP(hipMemsetAsync(c->d_xcol.p, 0, (size_t)c->n_cols * sizeof(double), c->stream));
+    FEDD_HIP(hipMemsetAsync(c->d_isdir.p, 0, (size_t)c->n_rows_ext * sizeof(int32_t), c->stream));
     int32_t* ncol = c->d_colind.p;
     if (!scalar) {
         FEDD_TRY(c->d_itmp2.ensure((size_t)node_nnz));
@@ -231,7 +240,7 @@ int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
     if (scalar) {
         FEDD_HIP(hipMemcpyAsync(c->d_rowptr.p, nptr, ((size_t)n_own + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     } else {
-        const int64_t nthreads = c->n_rows + 1;
+        const int64_t nthreads = c->n_rows_ext + 1;
         hipLaunchKernelGGL(k_expand_pattern, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream,
                            (const int32_t*)nptr, (const int32_t*)ncol, n_own, dofs,
                            block_mode == FEDD_BLOCK_FULL ? 1 : 0, c->d_rowptr.p, c->d_colind.p);

@@ -81,8 +81,12 @@ int  fedd_nccl_unique_id(void* id128);               /* rank 0 calls this, then 
  * decomp[3] = blocks per direction (the reference supports only N x N x N; {N,N,N} reproduces it
  * exactly, other shapes are the 1x1x2 / 1x2x2 splits of the same global grid used for the 2- and
  * 4-GPU scaling points).  cells[3] = cells per block and direction (the reference's M).
- * with_ghost_elements != 0 appends the neighbour blocks' elements that touch an owned node (and
+ * with_ghost_elements = 1 appends the neighbour blocks' elements that touch an owned node (and
  * their nodes), so that every owned row can be assembled without a matrix exchange.
+ * with_ghost_elements = 2 appends one more layer on every side with a neighbour: the elements around the
+ * first layer of ghost nodes, so that those nodes' rows are complete on this rank too (row ghosts, see
+ * fedd_mesh_set_rows; what FROSch obtains by importing the overlapping matrix rows from their owners).
+ * fedd_mesh_structured_row_ghosts lists them (count with NULL arrays first); needs >= 2 cells per block.
  * ---------------------------------------------------------------------------------------------- */
 int fedd_mesh_structured_sizes(int dim, const int* decomp, const int* cells, int rank,
                                int with_ghost_elements,
@@ -94,6 +98,9 @@ int fedd_mesh_structured_build(int dim, const int* decomp, const int* cells, int
                                double* xyz /*[n_rep*dim]*/, int64_t* gid_rep /*[n_rep]*/,
                                int32_t* flag_rep /*[n_rep]*/,
                                int64_t* gid_uni /*[n_uni]*/, int32_t* flag_uni /*[n_uni]*/);
+int fedd_mesh_structured_row_ghosts(int dim, const int* decomp, const int* cells, int rank,
+                                    const double* origin, const double* size, int flags_option,
+                                    int64_t* n_row_ghosts, int64_t* gid /*nullable*/, int32_t* flag /*nullable*/);
 
 /* ------------------------------------------------------------------------------------------------
  * unstructured input, host side, one rank: INRIA/medit ".mesh" reader (MeshFileReader.cpp:16-106,
@@ -121,6 +128,18 @@ int fedd_mesh_p2_build(int dim, int64_t n_vert, int64_t n_elem, const int32_t* c
 int fedd_mesh_set(fedd_ctx* ctx, int dim, int nen, int64_t n_elem, const int32_t* conn,
                   int64_t n_rep, const double* xyz, const int64_t* gid_rep,
                   int64_t n_uni, const int64_t* gid_uni, const int32_t* bcflag_uni);
+/* The same with row ghosts: nodes of the repeated map that another rank owns but ALL of whose elements are
+ * in this rank's mesh.  Their matrix rows are then built, assembled and given the Dirichlet treatment
+ * like owned rows (they follow the owned rows in the CSR arrays), and the overlapping Schwarz
+ * subdomains take the true rows of such nodes instead of identity rows -- the one-level preconditioner
+ * of a rank-boundary subdomain is then the same as that of an interior one.  Everything else (SpMV,
+ * vectors, fedd_csr_get, the coarse level) stays on the owned rows.  With row ghosts declared, only they
+ * are imported in the halo exchange (the owned rows and the subdomains reach no further).  Every
+ * ghost node adjacent to an owned node must be listed. */
+int fedd_mesh_set_rows(fedd_ctx* ctx, int dim, int nen, int64_t n_elem, const int32_t* conn,
+                       int64_t n_rep, const double* xyz, const int64_t* gid_rep,
+                       int64_t n_uni, const int64_t* gid_uni, const int32_t* bcflag_uni,
+                       int64_t n_row_ghosts, const int64_t* row_ghost_gid, const int32_t* row_ghost_bcflag);
 
 /* symbolic CSR on the owned (unique-map) rows: what Tpetra's dynamic insert + fillComplete
  * discover (feddlib/core/LinearAlgebra/Matrix_def.hpp:88-92,192-199). */
@@ -218,7 +237,8 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
  * "asm_kind" 0 = pair-parallel assembly, 1 = lane-per-row gather; "apply_kind" 0 = flat streaming Schwarz
  * apply, 1 = strided; "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
  * matrix cores, 2 = scalar-pivot without dropping rows;
- * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes. */
+ * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes;
+ * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank. */
 int fedd_set_option(fedd_ctx* ctx, const char* key, double value);
 
 /* device-time accounting (HIP events on the context's stream around each kernel class) */

@@ -242,3 +242,45 @@ def test_two_rank_halo_plan_over_gloo(fedd_lib, dim, dec, M):
         assert err < 1e-13
         assert npeers == 1
         np.testing.assert_allclose(dot, yy @ yy, rtol=1e-12)
+
+
+@pytest.mark.parametrize("dim,dec,cells", [(3, (2, 2, 2), [3, 3, 3]), (3, (1, 2, 2), [2, 2, 2]), (2, (3, 2), [2, 3]),
+                                           (3, (2, 2, 2), [4, 2, 3])])
+def test_two_layer_ghost_mesh_completes_the_rows_of_the_first_ghost_layer(dim, dec, cells):
+    """Ghost mode 2 of the structured generator (host code, no GPU): against the one-block mesh of the same
+    grid, every owned node AND every row ghost has exactly its global set of incident elements, the row
+    ghosts contain every ghost node adjacent to an owned one, coordinates / flags / owners agree."""
+    from collections import defaultdict
+    from feddlib_amd import capi
+    world = int(np.prod(dec))
+    ref = capi.structured_mesh(dim, [1] * dim, [d * c for d, c in zip(dec, cells)], 0)
+    ginc = defaultdict(set)
+    for e in map(tuple, np.sort(ref["gid_rep"][ref["conn"]], axis=1)):
+        for n in e:
+            ginc[n].add(e)
+    gxyz = {g: tuple(x) for g, x in zip(ref["gid_rep"], ref["xyz"])}
+    gflag = dict(zip(ref["gid_rep"], ref["flag_rep"]))
+    owned_all = []
+    for r in range(world):
+        m = capi.structured_mesh(dim, dec, cells, r, ghosts=2)
+        lconn = [tuple(e) for e in np.sort(m["gid_rep"][m["conn"]], axis=1)]
+        assert len(set(lconn)) == len(lconn)
+        linc = defaultdict(set)
+        for e in lconn:
+            for n in e:
+                linc[n].add(e)
+        for g, x, f in zip(m["gid_rep"], m["xyz"], m["flag_rep"]):
+            assert gxyz[g] == tuple(x) and gflag[g] == f
+        own, rg = set(m["gid_uni"]), set(m["row_ghost_gid"])
+        assert not (own & rg) and len(rg) == len(m["row_ghost_gid"])
+        for g in own | rg:
+            assert linc[g] == ginc[g]
+        for g, f in zip(m["row_ghost_gid"], m["row_ghost_flag"]):
+            assert gflag[g] == f
+        for g in own:
+            for e in ginc[g]:
+                assert all(n in own or n in rg for n in e)
+        owners = capi.structured_owner(dim, dec, cells, m["gid_rep"])
+        assert all((o == r) == (g in own) for g, o in zip(m["gid_rep"], owners))
+        owned_all += list(m["gid_uni"])
+    assert sorted(owned_all) == list(range(ref["n_global"]))

@@ -13,7 +13,7 @@ def load(d, name):
     return acc
 
 fe = load(sys.argv[1], "FETCH_SIZE"); wr = load(sys.argv[2], "WRITE_SIZE")
-classes = {"spmv": "k_spmv_stream", "schwarz_apply": "k_apply", "assemble": "k_assemble_pairs<", "multidot": "k_multidot(",
+classes = {"spmv": "k_spmv_win", "schwarz_apply": "k_apply", "assemble": "k_assemble_pairs<", "multidot": "k_multidot(",
            "multiaxpy": "k_multiaxpy(", "multidot2": "k_multidot2", "axpy2": "k_axpy2", "invert": "k_invert_reg<7"}
 out = {}
 for key, pat in classes.items():
@@ -28,5 +28,7 @@ for key, pat in classes.items():
     out[key] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wrt, "hbm_bytes_per_launch": rd + wrt,
                 "launches_sampled": len(fk2), "note": "FETCH_SIZE doubled (gfx950 128-B request correction), WRITE_SIZE as reported"}
 flat = {k: v["hbm_bytes_per_launch"] for k, v in out.items()}
-json.dump({"detail": out, **flat}, open(sys.argv[3], "w"), indent=1)
+# the grid the passes were taken on (bench.py quotes `traffic` only for the same one): argv[4] = "214,214,214"
+cells = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else None
+json.dump({"cells_per_gpu": cells, "n_gpus": 1, "detail": out, **flat}, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(flat, indent=1))
