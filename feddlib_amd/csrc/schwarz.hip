@@ -68,7 +68,13 @@ __global__ void k_bin_id(const double* __restrict__ xyz, int32_t n, int dofs, co
     const int32_t i = dof_node ? dof_node[r] : r / dofs;
     int32_t b = 0, mul = 1;
     for (int d = 0; d < gm.dim; ++d) {
-        int ix = (int)floor((xyz[(int64_t)i * gm.dim + d] - gm.lo[d]) / gm.w[d]);
+        // a node on a box boundary (within 1e-9 box widths) goes to the box on the centre side: with the odd
+        // number of boxes per direction the partition of a point set that is symmetric about the centre of
+        // its bounding box is then symmetric too
+        const double t = (xyz[(int64_t)i * gm.dim + d] - gm.lo[d]) / gm.w[d];
+        const double kb = floor(t + 0.5);
+        int ix = (int)floor(t);
+        if (fabs(t - kb) <= 1e-9) ix = 2 * (int)kb <= gm.g[d] - 1 ? (int)kb : (int)kb - 1;
         ix = min(gm.g[d] - 1, max(0, ix));
         b += mul * ix;
         mul *= gm.g[d];
@@ -714,6 +720,7 @@ int schwarz_setup(fedd_ctx* c) {
         const double Lp = L[d] > 0 ? L[d] : 1.0;
         int g = (int)std::ceil(Lp / s - 1e-9);
         if (g < 1 || !(L[d] > 0)) g = 1;
+        if (g % 2 == 0) ++g;   // odd: the lattice has a centre box (see k_bin_id)
         gm.g[d] = g;
         gm.w[d] = Lp / g;
         nraw *= g;

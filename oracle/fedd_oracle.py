@@ -839,9 +839,13 @@ def linelas_problem(m: Mesh, mu: float, nu: float, f=(0.0, 1.0, 0.0), bc_flags=(
 def schwarz_bins(xyz: np.ndarray, target: int, scale: float = 1.0):
     """Normative node -> subdomain ('bin') map of the product's batched one-level Schwarz:
     a regular grid of boxes over the bounding box of the owned nodes with
-    g_d = max(1, ceil(L_d / s - 1e-9)), s = scale * (V * target / n)^(1/dim) (V = product of the
-    non-degenerate extents), bin = ix + gx*(iy + gy*iz), i_d = min(g_d-1, floor((x_d-lo_d)/w_d)),
-    w_d = L_d / g_d.  Empty bins are dropped, the rest renumbered in increasing bin id."""
+    g_d = max(1, ceil(L_d / s - 1e-9)) made odd (+1 when even: the lattice has a centre box),
+    s = scale * (V * target / n)^(1/dim) (V = product of the non-degenerate extents),
+    bin = ix + gx*(iy + gy*iz), w_d = L_d / g_d, t = (x_d - lo_d) / w_d, i_d = floor(t) -- except for a
+    node on a box boundary (|t - k| <= 1e-9, k = floor(t + 0.5)), which goes to the box on the centre
+    side (k if 2k <= g_d - 1, else k - 1) -- clamped to [0, g_d - 1].  A point set that is symmetric about
+    the centre of its bounding box thus gets a symmetric partition.  Empty bins are dropped, the rest
+    renumbered in increasing bin id."""
     n, dim = xyz.shape
     lo = xyz.min(axis=0)
     L = xyz.max(axis=0) - lo
@@ -850,8 +854,15 @@ def schwarz_bins(xyz: np.ndarray, target: int, scale: float = 1.0):
     s = scale * (V * target / n) ** (1.0 / dim)
     g = np.maximum(1, np.ceil(Lpos / s - 1e-9).astype(np.int64))
     g = np.where(L > 0, g, 1)
+    g = np.where(g % 2 == 0, g + 1, g)
     w = Lpos / g
-    idx = np.minimum(g - 1, np.floor((xyz - lo) / w).astype(np.int64))
+    t = (xyz - lo) / w
+    kb = np.floor(t + 0.5)
+    idx = np.floor(t).astype(np.int64)
+    on = np.abs(t - kb) <= 1e-9
+    kbi = kb.astype(np.int64)
+    idx = np.where(on, np.where(2 * kbi <= g - 1, kbi, kbi - 1), idx)
+    idx = np.minimum(g - 1, idx)
     idx = np.maximum(idx, 0)
     b = idx[:, 0].copy()
     mul = g[0]

@@ -192,18 +192,19 @@ static int cmp_i32(const void* a, const void* b) { int32_t x = *(const int32_t*)
 
 static void ras_setup(const Problem* P, int target, Ras* R) {
     const int64_t n = P->n;
-    /* normative boxes (fedd_oracle.schwarz_bins): bounding box of the nodes, g_d = ceil(L_d/s - 1e-9) */
+    /* normative boxes (fedd_oracle.schwarz_bins): bounding box of the nodes, g_d = ceil(L_d/s - 1e-9) made odd,
+       boundary nodes to the centre side */
     double lo[3] = {1e300,1e300,1e300}, hi[3] = {-1e300,-1e300,-1e300};
     for (int64_t i = 0; i < n; ++i) for (int d = 0; d < 3; ++d) { double v = P->xyz[i*3+d]; if (v < lo[d]) lo[d] = v; if (v > hi[d]) hi[d] = v; }
     double L[3], V = 1.0; for (int d = 0; d < 3; ++d) { L[d] = hi[d] - lo[d]; V *= L[d] > 0 ? L[d] : 1.0; }
     double s = pow(V * target / (double)n, 1.0 / 3.0);
     int g[3]; double wd[3]; int64_t nraw = 1;
-    for (int d = 0; d < 3; ++d) { double Lp = L[d] > 0 ? L[d] : 1.0; g[d] = (int)ceil(Lp / s - 1e-9); if (g[d] < 1 || !(L[d] > 0)) g[d] = 1; wd[d] = Lp / g[d]; nraw *= g[d]; }
+    for (int d = 0; d < 3; ++d) { double Lp = L[d] > 0 ? L[d] : 1.0; g[d] = (int)ceil(Lp / s - 1e-9); if (g[d] < 1 || !(L[d] > 0)) g[d] = 1; if (g[d] % 2 == 0) ++g[d]; wd[d] = Lp / g[d]; nraw *= g[d]; }
     int32_t* bin = (int32_t*)malloc((size_t)n * sizeof(int32_t));
     int32_t* cnt = (int32_t*)calloc((size_t)nraw + 1, sizeof(int32_t));
     for (int64_t i = 0; i < n; ++i) {
         int64_t b = 0, mul = 1;
-        for (int d = 0; d < 3; ++d) { int ix = (int)floor((P->xyz[i*3+d] - lo[d]) / wd[d]); if (ix > g[d]-1) ix = g[d]-1; if (ix < 0) ix = 0; b += mul * ix; mul *= g[d]; }
+        for (int d = 0; d < 3; ++d) { double t = (P->xyz[i*3+d] - lo[d]) / wd[d], kb = floor(t + 0.5); int ix = (int)floor(t); if (fabs(t - kb) <= 1e-9) ix = 2 * (int)kb <= g[d] - 1 ? (int)kb : (int)kb - 1; if (ix > g[d]-1) ix = g[d]-1; if (ix < 0) ix = 0; b += mul * ix; mul *= g[d]; }
         bin[i] = (int32_t)b; cnt[b + 1]++;
     }
     int32_t* cid = (int32_t*)malloc((size_t)nraw * sizeof(int32_t)); int64_t nsub = 0;
