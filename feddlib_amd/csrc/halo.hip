@@ -35,8 +35,10 @@ __global__ void k_unpack(double* __restrict__ x, const int32_t* __restrict__ lid
 
 // x[ghost dofs] <- owners' values
 int halo_import(fedd_ctx* c, double* d_xcol, int dofs) {
-    if (c->nranks == 1 || c->n_node == c->n_own) return 0;
+    if (c->nranks == 1) return 0;
     HaloPlan& h = c->halo;
+    // a rank without ghost nodes may still have to send; only a rank without peers has nothing to do
+    if (h.ready && h.peers.empty()) return 0;
     FEDD_CHECK(h.ready && (c->comm || c->cb_exchange),
                "halo import: no exchange plan / transport; call fedd_halo_exchange_setup after fedd_mesh_set");
     const int64_t ns = (int64_t)h.send_lid.size(), nr = (int64_t)h.recv_lid.size();

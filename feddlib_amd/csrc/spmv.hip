@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ ro
 
 int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned) {
     const double* x = d_x_owned;
-    if (c->n_cols != c->n_rows) {
+    if (c->n_cols != c->n_rows || !c->halo.peers.empty()) {   // also a rank that only sends takes part
         FEDD_HIP(hipMemcpyAsync(c->d_xcol.p, d_x_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         FEDD_TRY(halo_import(c, c->d_xcol.p, c->dofs));
         x = c->d_xcol.p;
