@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__
 // and dropped: 16-byte loads (same), windows of 6 / 10 / 12 x 256 entries (same within 2 %), a persistent
 // variant that prefetches the next window behind the gathers (87 VGPRs, 5 workgroups per CU: slower),
 // gathering in the row phase with 1 / 2 / 4 lanes per row (coalesced gathers: same or slower).
+// Non-temporal loads of the matrix stream: 214^3 cells 406 -> 380 us back to back (x is no longer pushed out
+// of L2 between the visits of neighbouring node planes) but 388 us either way inside the solver; 100^3 cells
+// 31 -> 40 us (the 203 MB matrix is partly served by the Infinity Cache from one SpMV to the next): not used.
 __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                   const double* __restrict__ val, const double* __restrict__ x,
                                                   double* __restrict__ y, const int32_t* __restrict__ block_row,
