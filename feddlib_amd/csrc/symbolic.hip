@@ -181,10 +181,11 @@ int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
     int32_t* nptr = c->d_itmp1.p;
     if (lds > 64 * 1024)
         FEDD_HIP(hipFuncSetAttribute((const void*)k_node_pattern<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // the count pass stashes its merged lists (cap x n_own ints, <= 2 GiB) so the fill pass is a copy;
+    // the count pass stashes its merged lists (cap x n_own ints, <= 8 GiB of the 288; only the first
+    // max-row-length planes of it are ever touched) so the fill pass is a copy;
     // beyond that size the fill pass merges again
     int32_t* stash = nullptr;
-    if ((int64_t)cap * n_own <= ((int64_t)1 << 29)) {
+    if ((int64_t)cap * n_own <= ((int64_t)1 << 31)) {
         FEDD_TRY(c->d_pat_stash.ensure((size_t)cap * (size_t)n_own));
         stash = c->d_pat_stash.p;
     }
