@@ -204,9 +204,10 @@ def main():
         return {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()}
 
     t0 = time.perf_counter()
-    # N > 1: two ghost layers, so that the rows of the first ghost nodes are complete on the rank and the
-    # Schwarz subdomains at a rank boundary get true overlap rows (fedd_mesh_set_rows)
-    m = capi.structured_mesh(3, dec, cells, rank, size=dom, ghosts=2 if N > 1 else 0)
+    # N > 1: four ghost-element layers, so that the rows of the ghost nodes within three layers are complete on
+    # the rank (fedd_mesh_set_rows): every Schwarz box that a rank boundary crosses (3 node planes + 1 of overlap)
+    # is then built whole on both sides and the preconditioner is the one-rank preconditioner at any N
+    m = capi.structured_mesh(3, dec, cells, rank, size=dom, ghosts=4 if N > 1 else 0)
     t_mesh = time.perf_counter() - t0
     c = capi.Context(device=dev, rank=rank, nranks=N, nccl_id=nccl_id)
     t0 = time.perf_counter()

@@ -36,7 +36,7 @@ SIGNATURES = {
     "fedd_mesh_structured_build": [C.c_int, _ip, _ip, C.c_int, _f64p, _f64p, C.c_int, C.c_int, _i32p, _f64p,
                                    _i64p, _i32p, _i64p, _i32p],
     "fedd_mesh_structured_owner": [C.c_int, _ip, _ip, C.c_int64, _i64p, _i32p],
-    "fedd_mesh_structured_row_ghosts": [C.c_int, _ip, _ip, C.c_int, _f64p, _f64p, C.c_int, _i64p, _i64p, _i32p],
+    "fedd_mesh_structured_row_ghosts": [C.c_int, _ip, _ip, C.c_int, C.c_int, _f64p, _f64p, C.c_int, _i64p, _i64p, _i32p],
     "fedd_mesh_read_sizes": [C.c_char_p, C.c_int, _i64p, _i64p, _i64p],
     "fedd_mesh_read": [C.c_char_p, C.c_int, _f64p, _i32p, _i32p, _i32p, _i32p, _i32p],
     "fedd_mesh_p2_sizes": [C.c_int, C.c_int64, _i32p, _i64p],
@@ -169,8 +169,9 @@ def _decomp(dim, N):
 def structured_mesh(dim, N, M, rank=0, origin=None, size=None, flags_option=1, ghosts=False):
     """Product-side structured generator (host code in the library).  N, M: ints or per-direction lists.
     ghosts: False / 0 = the reference's block, True / 1 = plus the elements that complete the owned rows,
-    2 = plus the layer that completes the rows of the first ghost nodes (the dict then carries
-    row_ghost_gid / row_ghost_flag, which Context.mesh_set_dict hands to fedd_mesh_set_rows)."""
+    L >= 2 = L element layers around the owned nodes, which complete the rows of the ghost nodes within
+    L - 1 layers (the dict then carries row_ghost_gid / row_ghost_flag, which Context.mesh_set_dict hands
+    to fedd_mesh_set_rows)."""
     L = lib()
     dec, cel = _decomp(dim, N), _decomp(dim, M)
     ne, nr, nu, ng = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
@@ -189,14 +190,14 @@ def structured_mesh(dim, N, M, rank=0, origin=None, size=None, flags_option=1, g
                                       _p(flag_rep, _i32p), _p(gid_uni, _i64p), _p(flag_uni, _i32p)))
     out = dict(dim=dim, nen=dim + 1, conn=conn, xyz=xyz, gid_rep=gid_rep, flag_rep=flag_rep, gid_uni=gid_uni,
                flag_uni=flag_uni, n_global=ng.value, decomp=dec, cells=cel, rank=rank)
-    if int(ghosts) == 2:
+    if int(ghosts) >= 2:
         nrg = C.c_int64()
-        _chk(L.fedd_mesh_structured_row_ghosts(dim, _ints(dec), _ints(cel), rank, _p(o, _f64p), _p(s, _f64p), flags_option,
-                                               C.byref(nrg), None, None))
+        _chk(L.fedd_mesh_structured_row_ghosts(dim, _ints(dec), _ints(cel), rank, int(ghosts), _p(o, _f64p), _p(s, _f64p),
+                                               flags_option, C.byref(nrg), None, None))
         rg = np.zeros(nrg.value, dtype=np.int64)
         rf = np.zeros(nrg.value, dtype=np.int32)
-        _chk(L.fedd_mesh_structured_row_ghosts(dim, _ints(dec), _ints(cel), rank, _p(o, _f64p), _p(s, _f64p), flags_option,
-                                               C.byref(nrg), _p(rg, _i64p), _p(rf, _i32p)))
+        _chk(L.fedd_mesh_structured_row_ghosts(dim, _ints(dec), _ints(cel), rank, int(ghosts), _p(o, _f64p), _p(s, _f64p),
+                                               flags_option, C.byref(nrg), _p(rg, _i64p), _p(rf, _i32p)))
         out["row_ghost_gid"], out["row_ghost_flag"] = rg, rf
     return out
 

@@ -123,6 +123,8 @@ extern "C" void fedd_ctx_destroy(fedd_ctx* c) {
         c->d_inv_ptr.release();
         c->d_dof_node.release();
         c->d_pat_stash.release();
+        c->d_fbin_ptr.release();
+        c->d_fbin_nodes.release();
         fedd::DevBuf<int32_t>* cib[] = {&c->d_co_key[0], &c->d_co_key[1], &c->d_co_val[0], &c->d_co_val[1],
                                         &c->d_co_cell_ptr};
         for (auto* b : cib) b->release();
@@ -590,6 +592,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     const std::string k(key);
     if (k == "spmv_kind") c->spmv_kind = (int)value;
     else if (k == "box_kind") c->box_kind = (int)value;
+    else if (k == "whole_boxes") c->whole_boxes = (int)value;
     else if (k == "asm_kind") c->asm_kind = (int)value;
     else if (k == "apply_kind") c->apply_kind = (int)value;
     else if (k == "inv_kind") c->inv_kind = (int)value;

@@ -147,6 +147,8 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_xcol, d_ycol;        // [n_cols] work vectors with ghost tail
     fedd::DevBuf<int32_t> d_isdir;              // [n_rows] 1 = Dirichlet row
     bool have_pattern = false;
+    int whole_boxes = 1;                        // row ghosts: build boxes whole across rank boundaries where the stored rows reach
+    fedd::DevBuf<int32_t> d_fbin_ptr, d_fbin_nodes;   // [nsub+1], [row-ghost dofs] other ranks' dofs grouped by box
     int box_kind = 0;                           // Schwarz boxes: 0 = one lattice over all ranks' nodes, 1 = per-rank lattice
     int spmv_kind = 0;                          // 0 = CSR-window / automatic, 1 = row-per-lane-group, 2 = CSR-stream
     int asm_kind = 0;                           // 0 = pair-parallel assembly, 1 = lane-per-row gather

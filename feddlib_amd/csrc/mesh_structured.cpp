@@ -7,10 +7,10 @@
 //   Map::buildUniqueMap                     feddlib/core/LinearAlgebra/Map_def.hpp:184-210
 // Layout differences: flat SoA arrays instead of vector<vector<>>, per-direction block counts
 // (the reference only knows N x N x N), optional ghost-element layers, lowest-rank owner rule.
-// Ghost modes: 0 = the reference's block; 1 = plus the layer of cells above the block that completes the
-// rows of the owned nodes; 2 = plus one more layer on every side that has a neighbour, which completes the
-// rows of the first layer of ghost nodes as well ("row ghosts": the Schwarz local matrices then hold true
-// rows for the overlap nodes that belong to other ranks).
+// Ghost layers L: 0 = the reference's block; 1 = plus the layer of cells above the block that completes the
+// rows of the owned nodes; L >= 2 = L layers of cells around the owned nodes on every side that has a
+// neighbour, which completes the rows of the ghost nodes within L - 1 layers as well ("row ghosts": the
+// Schwarz local matrices then hold true rows for nodes that belong to other ranks).
 #include "fedd_internal.hpp"
 #include <cmath>
 #include <limits>
@@ -20,9 +20,9 @@ namespace {
 struct Block {
     int dim;
     int N[3], M[3], off[3];
-    int up[3];        // layers of ghost lattice planes above the block in d (0, 1 or 2)
-    int dn[3];        // layers below (0 or 1; mode 2 with a lower neighbour)
-    int mode;
+    int up[3];        // ghost lattice planes above the block in d (0 .. L, clipped to the grid)
+    int dn[3];        // planes below (0 .. L - 1, clipped to the grid)
+    int mode;         // L
     int lo_owned[3];  // first owned lattice index in d (0, or 1 when a lower neighbour owns the face)
     int64_t P[3];     // global points per direction
     int n1[3];        // own lattice points per direction (M+1)
@@ -32,8 +32,8 @@ struct Block {
 int make_block(int dim, const int* decomp, const int* cells, int rank, int ghosts, Block& b) {
     b.dim = dim;
     b.mode = ghosts;
-    if (ghosts < 0 || ghosts > 2) {
-        fedd::set_error("structured mesh: ghost mode %d (0, 1 or 2)", ghosts);
+    if (ghosts < 0 || ghosts > 8) {
+        fedd::set_error("structured mesh: %d ghost layers (0 .. 8)", ghosts);
         return 1;
     }
     int64_t nr = 1;
@@ -57,14 +57,13 @@ int make_block(int dim, const int* decomp, const int* cells, int rank, int ghost
     for (int d = 0; d < 3; ++d) {
         b.P[d] = d < dim ? (int64_t)b.N[d] * b.M[d] + 1 : 1;
         b.n1[d] = d < dim ? b.M[d] + 1 : 1;
-        b.up[d] = (d < dim && ghosts && b.off[d] + 1 < b.N[d]) ? ghosts : 0;
-        b.dn[d] = (d < dim && ghosts == 2 && b.off[d] > 0) ? 1 : 0;
+        // planes above: L, below: L - 1 (the lower neighbour owns the shared face), clipped to the grid
+        const int64_t above = d < dim ? (int64_t)(b.N[d] - 1 - b.off[d]) * b.M[d] : 0;
+        const int64_t below = d < dim ? (int64_t)b.off[d] * b.M[d] : 0;
+        b.up[d] = (int)std::min<int64_t>(ghosts, above);
+        b.dn[d] = (int)std::min<int64_t>(ghosts > 1 ? ghosts - 1 : 0, below);
         b.ne[d] = b.dn[d] + b.n1[d] + b.up[d];
         b.lo_owned[d] = (d < dim && b.off[d] > 0) ? 1 : 0;
-        if (ghosts == 2 && d < dim && b.N[d] > 1 && b.M[d] < 2) {
-            fedd::set_error("structured mesh: two ghost layers need at least 2 cells per block and direction");
-            return 1;
-        }
     }
     return 0;
 }
@@ -73,10 +72,17 @@ int make_block(int dim, const int* decomp, const int* cells, int rank, int ghost
 inline bool in_own_lattice(const Block& b, int r, int s, int t) {
     return r >= 0 && r < b.n1[0] && s >= 0 && s < b.n1[1] && t >= 0 && t < b.n1[2];
 }
-// own lattice plus the first plane above it: the nodes whose rows are complete in mode 2
+// the nodes whose rows are complete with L >= 2 layers: both cells around the plane are present (or the
+// plane is on the boundary of the grid) in every direction
 inline bool in_row_box(const Block& b, int r, int s, int t) {
-    return r >= 0 && r < b.n1[0] + (b.up[0] ? 1 : 0) && s >= 0 && s < b.n1[1] + (b.up[1] ? 1 : 0) && t >= 0 &&
-           t < b.n1[2] + (b.up[2] ? 1 : 0);
+    const int l[3] = {r, s, t};
+    for (int d = 0; d < b.dim; ++d) {
+        const int64_t gl = (int64_t)l[d] + (int64_t)b.off[d] * b.M[d];   // global plane index
+        const bool lo_ok = gl == 0 || l[d] - 1 >= -b.dn[d];
+        const bool hi_ok = gl == b.P[d] - 1 || l[d] <= b.M[d] + b.up[d] - 1;
+        if (!lo_ok || !hi_ok || l[d] < -b.dn[d] || l[d] > b.M[d] + b.up[d]) return false;
+    }
+    return true;
 }
 
 // local repeated id of lattice point (r,s,t): the reference's (M+1)^dim block first in its own order
@@ -154,7 +160,7 @@ void for_each_element(const Block& b, F&& f) {
                                 ps[v] = s + TRIS[k][v][1];
                                 pt[v] = 0;
                             }
-                            touches = touches || (b.mode == 2 ? in_row_box(b, pr[v], ps[v], pt[v])
+                            touches = touches || (b.mode >= 2 ? in_row_box(b, pr[v], ps[v], pt[v])
                                                               : owned_pt(b, pr[v], ps[v], pt[v]));
                         }
                         if (ghost_cell && !touches) continue;
@@ -238,10 +244,11 @@ extern "C" int fedd_mesh_structured_build(int dim, const int* decomp, const int*
                 for (int d = 0; d < dim; ++d) {
                     // a point beyond the own lattice gets the coordinate its owning block computes
                     int ll = l[d], oo = b.off[d];
-                    if (ll >= b.n1[d]) {
+                    while (ll >= b.n1[d]) {
                         ll -= b.M[d];
                         oo += 1;
-                    } else if (ll < 0) {
+                    }
+                    while (ll < 0) {
                         ll += b.M[d];
                         oo -= 1;
                     }
@@ -285,15 +292,16 @@ extern "C" int fedd_mesh_structured_build(int dim, const int* decomp, const int*
     return 0;
 }
 
-/* Mode 2: the repeated-map nodes whose matrix rows are complete on this rank although another rank owns
- * them (own-lattice points of lower neighbours and the first plane above the block): count, or with
- * arrays their global ids and boundary flags -- the arguments of fedd_mesh_set_rows. */
-extern "C" int fedd_mesh_structured_row_ghosts(int dim, const int* decomp, const int* cells, int rank, const double* origin,
-                                               const double* size, int flags_option, int64_t* n_out, int64_t* gid,
-                                               int32_t* flag) {
+/* L >= 2 ghost layers: the repeated-map nodes whose matrix rows are complete on this rank although another
+ * rank owns them (the ghost nodes within L - 1 layers of the owned ones): count, or with arrays their
+ * global ids and boundary flags -- the arguments of fedd_mesh_set_rows. */
+extern "C" int fedd_mesh_structured_row_ghosts(int dim, const int* decomp, const int* cells, int rank,
+                                               int with_ghost_elements, const double* origin, const double* size,
+                                               int flags_option, int64_t* n_out, int64_t* gid, int32_t* flag) {
     FEDD_CHECK(dim == 2 || dim == 3, "structured mesh: dimension must be 2 or 3");
+    FEDD_CHECK(with_ghost_elements >= 2, "structured mesh: row ghosts need at least 2 ghost layers");
     Block b;
-    FEDD_TRY(make_block(dim, decomp, cells, rank, 2, b));
+    FEDD_TRY(make_block(dim, decomp, cells, rank, with_ghost_elements, b));
     double o[3] = {0, 0, 0}, sz[3] = {1, 1, 1}, h[3] = {0, 0, 0}, H[3] = {0, 0, 0};
     for (int d = 0; d < dim; ++d) {
         if (origin) o[d] = origin[d];
@@ -304,19 +312,23 @@ extern "C" int fedd_mesh_structured_row_ghosts(int dim, const int* decomp, const
     const double eps = std::numeric_limits<double>::epsilon();
     const double snap = dim == 3 ? eps : 100 * eps;
     int64_t n = 0;
-    for (int t = 0; t < b.n1[2] + (b.up[2] ? 1 : 0); ++t)
-        for (int s = 0; s < b.n1[1] + (b.up[1] ? 1 : 0); ++s)
-            for (int r = 0; r < b.n1[0] + (b.up[0] ? 1 : 0); ++r) {
-                if (owned_pt(b, r, s, t)) continue;
+    for (int t = -b.dn[2]; t < b.n1[2] + b.up[2]; ++t)
+        for (int s = -b.dn[1]; s < b.n1[1] + b.up[1]; ++s)
+            for (int r = -b.dn[0]; r < b.n1[0] + b.up[0]; ++r) {
+                if (owned_pt(b, r, s, t) || !in_row_box(b, r, s, t)) continue;
                 if (gid || flag) {
                     const int l[3] = {r, s, t};
                     double p[3] = {0, 0, 0};
                     int64_t g[3] = {0, 0, 0};
                     for (int d = 0; d < dim; ++d) {
                         int ll = l[d], oo = b.off[d];
-                        if (ll >= b.n1[d]) {
+                        while (ll >= b.n1[d]) {
                             ll -= b.M[d];
                             oo += 1;
+                        }
+                        while (ll < 0) {
+                            ll += b.M[d];
+                            oo -= 1;
                         }
                         double c = ll * h[d] + oo * H[d];
                         if (c < snap && c > -snap) c = 0.0;

@@ -61,8 +61,10 @@ __global__ void k_minmax(const double* __restrict__ xyz, int32_t n, int dim, dou
 
 // box of every owned DOF = box of the node that carries it (dof / dofs, or the dof -> node map of a
 // merged block system)
-__global__ void k_bin_id(const double* __restrict__ xyz, int32_t n, int dofs, const int32_t* __restrict__ dof_node,
-                         BinGeom gm, int32_t* __restrict__ raw, int32_t* cnt) {
+// n dofs get a box, the first n_count of them (the owned ones) are counted: a box exists where it holds an
+// owned dof; the others are row-ghost dofs, which join the boxes of their position as foreign members
+__global__ void k_bin_id(const double* __restrict__ xyz, int32_t n, int32_t n_count, int dofs,
+                         const int32_t* __restrict__ dof_node, BinGeom gm, int32_t* __restrict__ raw, int32_t* cnt) {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const int32_t i = dof_node ? dof_node[r] : r / dofs;
@@ -80,7 +82,25 @@ __global__ void k_bin_id(const double* __restrict__ xyz, int32_t n, int dofs, co
         mul *= gm.g[d];
     }
     raw[r] = b;
-    atomicAdd(&cnt[b], 1);
+    if (r < n_count) atomicAdd(&cnt[b], 1);
+}
+
+// row-ghost dofs r in [n0, n1) whose box exists on this rank: count per box / fill the per-box lists
+// (cid = exclusive scan of the non-empty flags: a box exists iff cid[raw + 1] > cid[raw])
+__global__ void k_foreign_count(const int32_t* __restrict__ raw, const int32_t* __restrict__ cid, int32_t n0, int32_t n1,
+                                int32_t* cnt) {
+    const int32_t r = n0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n1) return;
+    const int32_t b = raw[r];
+    if (cid[b + 1] > cid[b]) atomicAdd(&cnt[cid[b]], 1);
+}
+
+__global__ void k_foreign_fill(const int32_t* __restrict__ raw, const int32_t* __restrict__ cid, int32_t n0, int32_t n1,
+                               int32_t* cursor, int32_t* __restrict__ nodes) {
+    const int32_t r = n0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n1) return;
+    const int32_t b = raw[r];
+    if (cid[b + 1] > cid[b]) nodes[atomicAdd(&cursor[cid[b]], 1)] = r;
 }
 
 __global__ void k_flag_nonempty(const int32_t* __restrict__ cnt, int32_t n, int32_t* __restrict__ flag) {
@@ -124,6 +144,8 @@ __global__ void k_sort_bins(const int32_t* __restrict__ ptr, int32_t nb, int32_t
 __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bin_ptr,
                                                   const int32_t* __restrict__ bin_nodes,
                                                   const int32_t* __restrict__ node_bin,
+                                                  const int32_t* __restrict__ fbin_ptr,
+                                                  const int32_t* __restrict__ fbin_nodes,
                                                   const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ colind, int32_t n_rows, int32_t n_stored,
                                                   int ghost_overlap,
@@ -131,43 +153,71 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
                                                   int32_t* __restrict__ sub_nown, int32_t* __restrict__ sub_dofs) {
     __shared__ int32_t tab[HS];
     __shared__ int32_t lst[HS];
-    __shared__ int32_t s_cnt, s_prev;
+    __shared__ int32_t s_cnt, s_prev, s_bad;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int32_t nb = bin_ptr[b];
     const int n_own = bin_ptr[b + 1] - nb;   // the box lists dofs
+    const int32_t fb = fbin_ptr ? fbin_ptr[b] : 0;
+    const int n_for = fbin_ptr ? fbin_ptr[b + 1] - fb : 0;   // dofs of other ranks' nodes in this box (rows stored here)
     int32_t* out = sub_dofs + (int64_t)b * NMAX;
     for (int k = tid; k < n_own && k < NMAX; k += 256) out[k] = bin_nodes[nb + k];
-    for (int k = tid; k < HS; k += 256) tab[k] = -1;
-    if (tid == 0) {
-        s_cnt = 0;
-        s_prev = 0;
-    }
-    __syncthreads();
-    for (int layer = 0; layer < overlap; ++layer) {
-        // sources: owned dofs (layer 0) or everything collected so far (later layers)
-        const int nsrc = layer == 0 ? n_own : s_prev;
-        for (int k = tid; k < nsrc; k += 256) {
-            const int32_t src = layer == 0 ? bin_nodes[nb + k] : lst[k];
-            if (src >= n_stored) continue;
-            for (int32_t p = rowptr[src]; p < rowptr[src + 1]; ++p) {
-                const int32_t col = colind[p];
-                if (col < n_rows && node_bin[col] == b) continue;
-                if (!ghost_overlap && col >= n_rows) continue;  // another rank's dof: its row is not stored here
-                uint32_t h = ((uint32_t)col * 2654435761u) % HS;
-                for (int probe = 0; probe < HS; ++probe) {
-                    const int32_t old = atomicCAS(&tab[h], -1, col);
-                    if (old == -1 || old == col) break;
-                    h = (h + 1) % HS;
-                }
-            }
+    auto insert = [&](int32_t col) {
+        uint32_t h = ((uint32_t)col * 2654435761u) % HS;
+        for (int probe = 0; probe < HS; ++probe) {
+            const int32_t old = atomicCAS(&tab[h], -1, col);
+            if (old == -1 || old == col) break;
+            h = (h + 1) % HS;
+        }
+    };
+    // First with the foreign members: the subdomain is then the WHOLE box plus its overlap, the same on every
+    // rank that holds a part of the box (each keeps the rows of its own nodes).  That needs a stored row for
+    // every dof of the subdomain; if the ghost layers of the mesh do not reach that far, second attempt with
+    // the owned part of the box alone (the rank boundary cuts the box).
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int nf = attempt == 0 ? n_for : 0;
+        for (int k = tid; k < HS; k += 256) tab[k] = -1;
+        if (tid == 0) {
+            s_cnt = 0;
+            s_prev = 0;
+            s_bad = 0;
         }
         __syncthreads();
-        if (tid == 0) s_cnt = 0;
+        for (int k = tid; k < nf; k += 256) insert(fbin_nodes[fb + k]);
         __syncthreads();
-        for (int k = tid; k < HS; k += 256)
-            if (tab[k] >= 0) lst[atomicAdd(&s_cnt, 1)] = tab[k];
+        for (int layer = 0; layer < overlap; ++layer) {
+            // sources: the box (layer 0) or everything collected so far (later layers)
+            const int nsrc = layer == 0 ? n_own + nf : s_prev;
+            for (int k = tid; k < nsrc; k += 256) {
+                const int32_t src = layer == 0 ? (k < n_own ? bin_nodes[nb + k] : fbin_nodes[fb + k - n_own]) : lst[k];
+                if (src >= n_stored) continue;
+                for (int32_t p = rowptr[src]; p < rowptr[src + 1]; ++p) {
+                    const int32_t col = colind[p];
+                    if (col < n_rows && node_bin[col] == b) continue;
+                    if (!ghost_overlap && col >= n_rows) continue;  // another rank's dof: its row is not stored here
+                    insert(col);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
+            for (int k = tid; k < HS; k += 256)
+                if (tab[k] >= 0) lst[atomicAdd(&s_cnt, 1)] = tab[k];
+            __syncthreads();
+            if (tid == 0) s_prev = s_cnt;
+            __syncthreads();
+        }
+        if (overlap == 0 && nf > 0) {   // no layer loop ran: list the foreign members
+            for (int k = tid; k < HS; k += 256)
+                if (tab[k] >= 0) lst[atomicAdd(&s_cnt, 1)] = tab[k];
+            __syncthreads();
+            if (tid == 0) s_prev = s_cnt;
+            __syncthreads();
+        }
+        if (nf == 0) break;
+        for (int k = tid; k < s_prev; k += 256)
+            if (lst[k] >= n_stored) s_bad = 1;
         __syncthreads();
-        if (tid == 0) s_prev = s_cnt;
+        if (!s_bad) break;
         __syncthreads();
     }
     const int n_ext = s_prev;
@@ -727,13 +777,18 @@ int schwarz_setup(fedd_ctx* c) {
     }
     FEDD_CHECK(nraw < ((int64_t)1 << 30), "schwarz setup: %lld boxes", (long long)nraw);
     // ---- dofs -> boxes (box of the carrying node), drop empty boxes, counting sort ----
-    FEDD_TRY(c->d_itmp0.ensure((size_t)n_rows));       // raw box of each dof
+    // with row ghosts (and "whole_boxes") the row-ghost dofs are binned too: a box that holds owned dofs also
+    // lists the other ranks' dofs inside it, and k_sub_dofs builds the whole box when the stored rows reach
+    const bool foreign = c->whole_boxes && c->box_kind == 0 && n_stored > n_rows && !c->merged;
+    const int32_t n_binned = foreign ? n_stored : n_rows;
+    FEDD_TRY(c->d_itmp0.ensure((size_t)n_binned));     // raw box of each dof
     FEDD_TRY(c->d_itmp1.ensure((size_t)nraw + 1));     // raw counts
     FEDD_TRY(c->d_itmp2.ensure((size_t)nraw + 1));     // flags -> compact ids
     FEDD_HIP(hipMemsetAsync(c->d_itmp1.p, 0, ((size_t)nraw + 1) * sizeof(int32_t), c->stream));
     const dim3 gn((n_rows + 255) / 256), gb((unsigned)((nraw + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(k_bin_id, gn, blk, 0, c->stream, (const double*)c->d_xyz.p, n_rows, dofs,
-                       (const int32_t*)(c->merged ? c->d_dof_node.p : nullptr), gm, c->d_itmp0.p, c->d_itmp1.p);
+    hipLaunchKernelGGL(k_bin_id, dim3((unsigned)((n_binned + 255) / 256)), blk, 0, c->stream, (const double*)c->d_xyz.p,
+                       n_binned, n_rows, dofs, (const int32_t*)(c->merged ? c->d_dof_node.p : nullptr), gm, c->d_itmp0.p,
+                       c->d_itmp1.p);
     hipLaunchKernelGGL(k_flag_nonempty, gb, blk, 0, c->stream, (const int32_t*)c->d_itmp1.p, (int32_t)nraw, c->d_itmp2.p);
     int64_t nsub = 0;
     FEDD_TRY(exclusive_scan_i32(c, c->d_itmp2.p, c->d_itmp2.p, nraw, &nsub));
@@ -754,9 +809,27 @@ int schwarz_setup(fedd_ctx* c) {
                        c->d_itmp1.p, c->d_node_bin.p, c->d_bin_nodes.p);
     hipLaunchKernelGGL(k_sort_bins, dim3((unsigned)((nsub + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_bin_ptr.p,
                        (int32_t)nsub, c->d_bin_nodes.p);
+    // ---- foreign members of the boxes (row-ghost dofs), same counting sort ----
+    if (foreign) {
+        const int32_t nfor = n_stored - n_rows;
+        const dim3 gf((unsigned)((nfor + 255) / 256));
+        FEDD_TRY(c->d_fbin_ptr.ensure((size_t)nsub + 1));
+        FEDD_TRY(c->d_fbin_nodes.ensure((size_t)nfor));
+        FEDD_HIP(hipMemsetAsync(c->d_fbin_ptr.p, 0, ((size_t)nsub + 1) * sizeof(int32_t), c->stream));
+        hipLaunchKernelGGL(k_foreign_count, gf, blk, 0, c->stream, (const int32_t*)c->d_itmp0.p, (const int32_t*)c->d_itmp2.p,
+                           n_rows, n_stored, c->d_fbin_ptr.p);
+        FEDD_TRY(exclusive_scan_i32(c, c->d_fbin_ptr.p, c->d_fbin_ptr.p, nsub, nullptr));
+        FEDD_HIP(hipMemcpyAsync(c->d_itmp1.p, c->d_fbin_ptr.p, (size_t)nsub * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_foreign_fill, gf, blk, 0, c->stream, (const int32_t*)c->d_itmp0.p, (const int32_t*)c->d_itmp2.p,
+                           n_rows, n_stored, c->d_itmp1.p, c->d_fbin_nodes.p);
+        hipLaunchKernelGGL(k_sort_bins, dim3((unsigned)((nsub + 255) / 256)), blk, 0, c->stream,
+                           (const int32_t*)c->d_fbin_ptr.p, (int32_t)nsub, c->d_fbin_nodes.p);
+    }
     // ---- overlapping dof lists ----
     hipLaunchKernelGGL(k_sub_dofs, dim3((unsigned)nsub), blk, 0, c->stream, (const int32_t*)c->d_bin_ptr.p,
-                       (const int32_t*)c->d_bin_nodes.p, (const int32_t*)c->d_node_bin.p, (const int32_t*)c->d_rowptr.p,
+                       (const int32_t*)c->d_bin_nodes.p, (const int32_t*)c->d_node_bin.p,
+                       (const int32_t*)(foreign ? c->d_fbin_ptr.p : nullptr), (const int32_t*)(foreign ? c->d_fbin_nodes.p : nullptr),
+                       (const int32_t*)c->d_rowptr.p,
                        (const int32_t*)c->d_colind.p, n_rows, (int32_t)c->n_rows_ext, c->ghost_overlap, c->sw_overlap,
                        c->d_sub_n.p, c->d_sub_nown.p,
                        c->d_sub_dofs.p);

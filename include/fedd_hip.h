@@ -83,10 +83,12 @@ int  fedd_nccl_unique_id(void* id128);               /* rank 0 calls this, then 
  * 4-GPU scaling points).  cells[3] = cells per block and direction (the reference's M).
  * with_ghost_elements = 1 appends the neighbour blocks' elements that touch an owned node (and
  * their nodes), so that every owned row can be assembled without a matrix exchange.
- * with_ghost_elements = 2 appends one more layer on every side with a neighbour: the elements around the
- * first layer of ghost nodes, so that those nodes' rows are complete on this rank too (row ghosts, see
- * fedd_mesh_set_rows; what FROSch obtains by importing the overlapping matrix rows from their owners).
- * fedd_mesh_structured_row_ghosts lists them (count with NULL arrays first); needs >= 2 cells per block.
+ * with_ghost_elements = L >= 2 (at most 8) appends L layers of elements around the owned nodes on every
+ * side with a neighbour, so that the rows of the ghost nodes within L - 1 layers are complete on this rank
+ * too (row ghosts, see fedd_mesh_set_rows; what FROSch obtains by importing the overlapping matrix rows
+ * from their owners).  fedd_mesh_structured_row_ghosts lists them (count with NULL arrays first).
+ * L = 2 gives the Schwarz subdomains at a rank boundary true overlap rows; L = 4 (27-node boxes, overlap 1)
+ * lets every rank build whole every box that holds one of its nodes, see fedd_schwarz_setup.
  * ---------------------------------------------------------------------------------------------- */
 int fedd_mesh_structured_sizes(int dim, const int* decomp, const int* cells, int rank,
                                int with_ghost_elements,
@@ -98,7 +100,7 @@ int fedd_mesh_structured_build(int dim, const int* decomp, const int* cells, int
                                double* xyz /*[n_rep*dim]*/, int64_t* gid_rep /*[n_rep]*/,
                                int32_t* flag_rep /*[n_rep]*/,
                                int64_t* gid_uni /*[n_uni]*/, int32_t* flag_uni /*[n_uni]*/);
-int fedd_mesh_structured_row_ghosts(int dim, const int* decomp, const int* cells, int rank,
+int fedd_mesh_structured_row_ghosts(int dim, const int* decomp, const int* cells, int rank, int with_ghost_elements,
                                     const double* origin, const double* size, int flags_option,
                                     int64_t* n_row_ghosts, int64_t* gid /*nullable*/, int32_t* flag /*nullable*/);
 
@@ -238,7 +240,9 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
  * apply, 1 = strided; "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
  * matrix cores, 2 = scalar-pivot without dropping rows;
  * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes;
- * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank. */
+ * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank;
+ * "whole_boxes" 1 (default) = with row ghosts, a box that a rank boundary crosses is built whole (with its full
+ * overlap) on every rank that owns a part of it wherever the stored rows reach, 0 = each rank takes its part. */
 int fedd_set_option(fedd_ctx* ctx, const char* key, double value);
 
 /* device-time accounting (HIP events on the context's stream around each kernel class) */

@@ -71,7 +71,8 @@ def _worker(rank, world, port, dec, M, ghosts, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dec,M,ghosts", [((1, 1, 2), 6, 1), ((1, 2, 2), 5, 1), ((1, 1, 2), 6, 2), ((1, 2, 2), 5, 2)])
+@pytest.mark.parametrize("dec,M,ghosts", [((1, 1, 2), 6, 1), ((1, 2, 2), 5, 1), ((1, 1, 2), 6, 2), ((1, 2, 2), 5, 2),
+                                          ((1, 2, 2), 5, 4)])
 def test_multirank_solve_on_one_gpu(fedd_lib, dec, M, ghosts):
     import scipy.sparse as sp
     import torch.multiprocessing as mp
@@ -132,7 +133,7 @@ def test_multirank_solve_on_one_gpu(fedd_lib, dec, M, ghosts):
         np.testing.assert_allclose(xa, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
 
 
-def _worker_elasticity(rank, world, port, dec, M, q, ghosts=2):
+def _worker_elasticity(rank, world, port, dec, M, q, ghosts=4):
     import sys
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -264,7 +265,7 @@ def test_bench_contract_one_gpu(fedd_lib):
 def _thread_rank(capi, group, rank, dec, M, out, errs):
     try:
         world = group.world
-        m = capi.structured_mesh(3, dec, [M] * 3, rank, ghosts=2)      # row ghosts: the mode bench.py uses
+        m = capi.structured_mesh(3, dec, [M] * 3, rank, ghosts=4)      # four ghost layers: what bench.py uses
         c = capi.Context(device=0, rank=rank, nranks=world, nccl_id=None)
         c.mesh_set_dict(m)
         c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, [M] * 3, m["gid_rep"]))
@@ -389,3 +390,64 @@ def test_row_ghosts_make_the_two_rank_schwarz_apply_equal_to_the_one_rank_apply(
         diff[ghosts] = np.abs(z - z_ref).max() / np.abs(z_ref).max()
     assert diff[2] <= 1e-13
     assert diff[1] > 1e-3
+
+
+@pytest.mark.parametrize("G,dec,target,layers", [(12, (2, 2, 2), 27, 4), (16, (1, 2, 2), 27, 4), (12, (2, 2, 2), 8, 3)])
+def test_whole_boxes_make_the_preconditioner_independent_of_the_number_of_ranks(fedd_lib, G, dec, target, layers):
+    """With enough ghost layers (boxes of 3 node planes + 1 of overlap: 4 element layers; 2-plane boxes: 3) every
+    rank builds every box that holds one of its nodes whole, rank boundaries or not, so the subdomains are those of
+    a one-rank run: M^-1 r equal to rounding and the same GMRES iteration count, on decompositions whose rank
+    boundaries cut through the boxes."""
+    import threading
+    capi = fedd_lib
+
+    def setup(c):
+        c.pattern_build(1, capi.BLOCK_SCALAR)
+        c.assemble(capi.FORM_LAPLACE)
+        c.assemble_rhs([1.0])
+        c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+        c.schwarz_set_target(target, 1.0)
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+
+    ref = capi.structured_mesh(3, 1, G)
+    c0 = capi.Context(device=0)
+    c0.mesh_set_dict(ref)
+    setup(c0)
+    r = np.random.default_rng(3).standard_normal(ref["n_global"])
+    z_ref = c0.schwarz_apply(r)
+    x_ref, its_ref, _ = c0.gmres(None, rtol=1e-10, max_it=500, restart=100, use_prec=True)
+    c0.close()
+    world = int(np.prod(dec))
+    cells = [G // d for d in dec]
+    group = capi.ThreadGroup(world)
+    out, errs = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            m = capi.structured_mesh(3, dec, cells, rank, ghosts=layers)
+            c = capi.Context(device=0, rank=rank, nranks=world, nccl_id=None)
+            c.mesh_set_dict(m)
+            c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, cells, m["gid_rep"]))
+            c.comm_set_thread_group(group)
+            setup(c)
+            z = c.schwarz_apply(r[m["gid_uni"]])
+            x, its, _ = c.gmres(None, rtol=1e-10, max_it=500, restart=100, use_prec=True)
+            out[rank] = (m["gid_uni"], z, x, its)
+            c.close()
+        except Exception as e:      # pragma: no cover
+            errs.append(repr(e))
+            group._barrier.abort()
+
+    th = [threading.Thread(target=rank_main, args=(k,)) for k in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    z, x = np.zeros_like(z_ref), np.zeros_like(x_ref)
+    for gu, zz, xx, its in out:
+        z[gu] = zz
+        x[gu] = xx
+        assert its == its_ref
+    np.testing.assert_allclose(z, z_ref, rtol=0, atol=1e-13 * np.abs(z_ref).max())
+    np.testing.assert_allclose(x, x_ref, rtol=0, atol=1e-9 * np.abs(x_ref).max())

@@ -244,12 +244,15 @@ def test_two_rank_halo_plan_over_gloo(fedd_lib, dim, dec, M):
         np.testing.assert_allclose(dot, yy @ yy, rtol=1e-12)
 
 
-@pytest.mark.parametrize("dim,dec,cells", [(3, (2, 2, 2), [3, 3, 3]), (3, (1, 2, 2), [2, 2, 2]), (2, (3, 2), [2, 3]),
-                                           (3, (2, 2, 2), [4, 2, 3])])
-def test_two_layer_ghost_mesh_completes_the_rows_of_the_first_ghost_layer(dim, dec, cells):
-    """Ghost mode 2 of the structured generator (host code, no GPU): against the one-block mesh of the same
-    grid, every owned node AND every row ghost has exactly its global set of incident elements, the row
-    ghosts contain every ghost node adjacent to an owned one, coordinates / flags / owners agree."""
+@pytest.mark.parametrize("dim,dec,cells,layers", [(3, (2, 2, 2), [3, 3, 3], 2), (3, (1, 2, 2), [2, 2, 2], 2),
+                                                  (2, (3, 2), [2, 3], 2), (3, (2, 2, 2), [4, 2, 3], 2),
+                                                  (3, (2, 2, 2), [5, 5, 5], 4), (3, (3, 3, 3), [2, 2, 2], 4),
+                                                  (2, (3, 2), [2, 3], 3), (3, (2, 1, 3), [3, 4, 2], 5)])
+def test_ghost_layers_complete_the_rows_of_the_row_ghosts(dim, dec, cells, layers):
+    """L >= 2 ghost layers of the structured generator (host code, no GPU): against the one-block mesh of the
+    same grid, every owned node AND every row ghost has exactly its global set of incident elements, the row
+    ghosts contain every ghost node within L - 1 layers of an owned one, coordinates (to rounding: blocks
+    compute them from their own corner, as in the reference) / flags / owners agree."""
     from collections import defaultdict
     from feddlib_amd import capi
     world = int(np.prod(dec))
@@ -262,7 +265,7 @@ def test_two_layer_ghost_mesh_completes_the_rows_of_the_first_ghost_layer(dim, d
     gflag = dict(zip(ref["gid_rep"], ref["flag_rep"]))
     owned_all = []
     for r in range(world):
-        m = capi.structured_mesh(dim, dec, cells, r, ghosts=2)
+        m = capi.structured_mesh(dim, dec, cells, r, ghosts=layers)
         lconn = [tuple(e) for e in np.sort(m["gid_rep"][m["conn"]], axis=1)]
         assert len(set(lconn)) == len(lconn)
         linc = defaultdict(set)
@@ -270,16 +273,17 @@ def test_two_layer_ghost_mesh_completes_the_rows_of_the_first_ghost_layer(dim, d
             for n in e:
                 linc[n].add(e)
         for g, x, f in zip(m["gid_rep"], m["xyz"], m["flag_rep"]):
-            assert gxyz[g] == tuple(x) and gflag[g] == f
+            assert np.allclose(gxyz[g], x, rtol=0, atol=1e-14) and gflag[g] == f
         own, rg = set(m["gid_uni"]), set(m["row_ghost_gid"])
         assert not (own & rg) and len(rg) == len(m["row_ghost_gid"])
         for g in own | rg:
             assert linc[g] == ginc[g]
         for g, f in zip(m["row_ghost_gid"], m["row_ghost_flag"]):
             assert gflag[g] == f
-        for g in own:
-            for e in ginc[g]:
-                assert all(n in own or n in rg for n in e)
+        front = set(own)
+        for _ in range(layers - 1):                  # grow L - 1 layers through the global mesh
+            front = front | {n for g in front for e in ginc[g] for n in e}
+        assert front - own <= rg
         owners = capi.structured_owner(dim, dec, cells, m["gid_rep"])
         assert all((o == r) == (g in own) for g, o in zip(m["gid_rep"], owners))
         owned_all += list(m["gid_uni"])

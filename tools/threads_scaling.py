@@ -1,6 +1,6 @@
 """Iteration counts of the fixed-grid (strong-scaling) split used by bench.py, with the N ranks as threads of
 one process on one GPU (capi.ThreadGroup; development aid -- times are meaningless, counts are not).
-usage: threads_scaling.py [global cells per direction] [ghost mode: 1 = one element layer, 2 = row ghosts] [box_kind]"""
+usage: threads_scaling.py [global cells per direction] [ghost element layers: 1, 2 (overlap rows), 4 (whole boxes)] [box_kind]"""
 import os
 import sys
 import threading
@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from feddlib_amd import capi  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-GHOSTS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+GHOSTS = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 BOX = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 DECOMP = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
 
