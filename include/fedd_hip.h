@@ -133,11 +133,14 @@ int fedd_mesh_set(fedd_ctx* ctx, int dim, int nen, int64_t n_elem, const int32_t
 /* The same with row ghosts: nodes of the repeated map that another rank owns but ALL of whose elements are
  * in this rank's mesh.  Their matrix rows are then built, assembled and given the Dirichlet treatment
  * like owned rows (they follow the owned rows in the CSR arrays), and the overlapping Schwarz
- * subdomains take the true rows of such nodes instead of identity rows -- the one-level preconditioner
- * of a rank-boundary subdomain is then the same as that of an interior one.  Everything else (SpMV,
- * vectors, fedd_csr_get, the coarse level) stays on the owned rows.  With row ghosts declared, only they
- * are imported in the halo exchange (the owned rows and the subdomains reach no further).  Every
- * ghost node adjacent to an owned node must be listed. */
+ * subdomains take the true rows of such nodes instead of identity rows.  The boxes of the subdomains come
+ * from one lattice over all ranks, and a box that holds an owned node is built whole -- with the other
+ * ranks' nodes inside it and the full overlap -- wherever all its dofs have stored rows (with 27-node boxes
+ * and overlap 1: row ghosts 3 node layers deep); each rank keeps the rows of its own nodes.  The
+ * preconditioner is then the one a single rank would build, whatever the number of ranks.  Where the row
+ * ghosts do not reach, a rank takes its own part of the box (true overlap rows still).  Everything else
+ * (SpMV, vectors, fedd_csr_get, the coarse level) stays on the owned rows.  With row ghosts declared, only
+ * they are imported in the halo exchange.  Every ghost node adjacent to an owned node must be listed. */
 int fedd_mesh_set_rows(fedd_ctx* ctx, int dim, int nen, int64_t n_elem, const int32_t* conn,
                        int64_t n_rep, const double* xyz, const int64_t* gid_rep,
                        int64_t n_uni, const int64_t* gid_uni, const int32_t* bcflag_uni,
