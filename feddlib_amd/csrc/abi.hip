@@ -229,6 +229,21 @@ static int mesh_set_impl(fedd_ctx* c, int dim, int nen, int64_t n_elem, const in
         FEDD_CHECK(conn[k] >= 0 && conn[k] < n_rep, "fedd_mesh_set: element node id %d out of range", conn[k]);
         conn2[k] = col_of_rep[conn[k]];
     }
+    if (ng_rows > 0) {
+        // only the row ghosts are imported in the halo exchange: every column of an owned row must be one
+        const int32_t first_plain = (int32_t)(n_uni + ng_rows);
+        for (int64_t e = 0; e < n_elem; ++e) {
+            bool touches_owned = false, has_plain = false;
+            for (int v = 0; v < nen; ++v) {
+                const int32_t id = conn2[e * nen + v];
+                touches_owned = touches_owned || id < n_uni;
+                has_plain = has_plain || id >= first_plain;
+            }
+            FEDD_CHECK(!(touches_owned && has_plain),
+                       "fedd_mesh_set_rows: element %lld joins an owned node and a ghost node that is not listed as a row ghost",
+                       (long long)e);
+        }
+    }
     std::vector<double> xyz2((size_t)(c->n_node * dim));
     for (int64_t i = 0; i < n_rep; ++i)
         for (int d = 0; d < dim; ++d) xyz2[(size_t)col_of_rep[i] * dim + d] = xyz[i * dim + d];

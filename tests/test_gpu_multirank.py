@@ -392,7 +392,8 @@ def test_row_ghosts_make_the_two_rank_schwarz_apply_equal_to_the_one_rank_apply(
     assert diff[1] > 1e-3
 
 
-@pytest.mark.parametrize("G,dec,target,layers", [(12, (2, 2, 2), 27, 4), (16, (1, 2, 2), 27, 4), (12, (2, 2, 2), 8, 3)])
+@pytest.mark.parametrize("G,dec,target,layers", [(12, (2, 2, 2), 27, 4), (16, (1, 2, 2), 27, 4), (12, (2, 2, 2), 8, 3),
+                                                 (30, (3, 2), 16, 5)])
 def test_whole_boxes_make_the_preconditioner_independent_of_the_number_of_ranks(fedd_lib, G, dec, target, layers):
     """With enough ghost layers (boxes of 3 node planes + 1 of overlap: 4 element layers; 2-plane boxes: 3) every
     rank builds every box that holds one of its nodes whole, rank boundaries or not, so the subdomains are those of
@@ -409,7 +410,8 @@ def test_whole_boxes_make_the_preconditioner_independent_of_the_number_of_ranks(
         c.schwarz_set_target(target, 1.0)
         c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
 
-    ref = capi.structured_mesh(3, 1, G)
+    dim = len(dec)
+    ref = capi.structured_mesh(dim, 1, G)
     c0 = capi.Context(device=0)
     c0.mesh_set_dict(ref)
     setup(c0)
@@ -424,10 +426,10 @@ def test_whole_boxes_make_the_preconditioner_independent_of_the_number_of_ranks(
 
     def rank_main(rank):
         try:
-            m = capi.structured_mesh(3, dec, cells, rank, ghosts=layers)
+            m = capi.structured_mesh(dim, dec, cells, rank, ghosts=layers)
             c = capi.Context(device=0, rank=rank, nranks=world, nccl_id=None)
             c.mesh_set_dict(m)
-            c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, cells, m["gid_rep"]))
+            c.halo_set_owners(m["gid_rep"], capi.structured_owner(dim, dec, cells, m["gid_rep"]))
             c.comm_set_thread_group(group)
             setup(c)
             z = c.schwarz_apply(r[m["gid_uni"]])

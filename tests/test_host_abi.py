@@ -288,3 +288,23 @@ def test_ghost_layers_complete_the_rows_of_the_row_ghosts(dim, dec, cells, layer
         assert all((o == r) == (g in own) for g, o in zip(m["gid_rep"], owners))
         owned_all += list(m["gid_uni"])
     assert sorted(owned_all) == list(range(ref["n_global"]))
+
+
+def test_mesh_set_rows_rejects_inconsistent_row_ghost_lists():
+    """fedd_mesh_set_rows on a host-only context (numbering only, no GPU): a row ghost that this rank owns, one
+    that is not in the repeated map, and a list that misses a ghost node adjacent to an owned node."""
+    from feddlib_amd import capi
+    dec, cells = (1, 1, 2), [3, 3, 3]
+    m = capi.structured_mesh(3, dec, cells, 1, ghosts=2)
+    c = capi.Context(device=-1, rank=1, nranks=2, nccl_id=None)
+    c.mesh_set_dict(m)                                    # the generator's own list is accepted
+    rg, rf = m["row_ghost_gid"], m["row_ghost_flag"]
+    with pytest.raises(capi.FeddError, match="owned by this rank"):
+        c.mesh_set(3, m["conn"], m["xyz"], m["gid_rep"], m["gid_uni"], m["flag_uni"],
+                   np.concatenate([rg, m["gid_uni"][:1]]), np.concatenate([rf, [0]]))
+    with pytest.raises(capi.FeddError, match="not in the repeated map"):
+        c.mesh_set(3, m["conn"], m["xyz"], m["gid_rep"], m["gid_uni"], m["flag_uni"],
+                   np.concatenate([rg, [10 ** 9]]), np.concatenate([rf, [0]]))
+    with pytest.raises(capi.FeddError, match="not listed as a row ghost"):
+        c.mesh_set(3, m["conn"], m["xyz"], m["gid_rep"], m["gid_uni"], m["flag_uni"], rg[1:], rf[1:])
+    c.close()
