@@ -392,9 +392,10 @@ def test_row_ghosts_make_the_two_rank_schwarz_apply_equal_to_the_one_rank_apply(
     assert diff[1] > 1e-3
 
 
-@pytest.mark.parametrize("G,dec,target,layers", [(12, (2, 2, 2), 27, 4), (16, (1, 2, 2), 27, 4), (12, (2, 2, 2), 8, 3),
-                                                 (30, (3, 2), 16, 5)])
-def test_whole_boxes_make_the_preconditioner_independent_of_the_number_of_ranks(fedd_lib, G, dec, target, layers):
+@pytest.mark.parametrize("G,dec,target,layers,problem", [(12, (2, 2, 2), 27, 4, "laplace"), (16, (1, 2, 2), 27, 4, "laplace"),
+                                                         (12, (2, 2, 2), 8, 3, "laplace"), (30, (3, 2), 16, 5, "laplace"),
+                                                         (8, (1, 2, 2), 0, 4, "linelas")])
+def test_whole_boxes_make_the_preconditioner_independent_of_the_number_of_ranks(fedd_lib, G, dec, target, layers, problem):
     """With enough ghost layers (boxes of 3 node planes + 1 of overlap: 4 element layers; 2-plane boxes: 3) every
     rank builds every box that holds one of its nodes whole, rank boundaries or not, so the subdomains are those of
     a one-rank run: M^-1 r equal to rounding and the same GMRES iteration count, on decompositions whose rank
@@ -402,7 +403,18 @@ def test_whole_boxes_make_the_preconditioner_independent_of_the_number_of_ranks(
     import threading
     capi = fedd_lib
 
+    dofs = 3 if problem == "linelas" else 1
+
     def setup(c):
+        if problem == "linelas":       # 3 dofs per node, FULL blocks, Dirichlet on the face x = 0 only, two levels
+            c.pattern_build(3, capi.BLOCK_FULL)
+            c.assemble(capi.FORM_LINELAS, [1.0 * 2 * 0.3 / (1 - 2 * 0.3), 1.0])
+            c.assemble_rhs([0.0, 1.0, 0.0])
+            c.dirichlet([2], [0.0, 0.0, 0.0])
+            c.schwarz_set_target(target, 1.0)
+            c.schwarz_set_coarse(8)
+            c.schwarz_setup(1, capi.COMBINE_RESTRICTED, two_level=1, coarse_kind=capi.COARSE_Q1)
+            return
         c.pattern_build(1, capi.BLOCK_SCALAR)
         c.assemble(capi.FORM_LAPLACE)
         c.assemble_rhs([1.0])
@@ -415,7 +427,7 @@ def test_whole_boxes_make_the_preconditioner_independent_of_the_number_of_ranks(
     c0 = capi.Context(device=0)
     c0.mesh_set_dict(ref)
     setup(c0)
-    r = np.random.default_rng(3).standard_normal(ref["n_global"])
+    r = np.random.default_rng(3).standard_normal(ref["n_global"] * dofs)
     z_ref = c0.schwarz_apply(r)
     x_ref, its_ref, _ = c0.gmres(None, rtol=1e-10, max_it=500, restart=100, use_prec=True)
     c0.close()
@@ -432,9 +444,10 @@ def test_whole_boxes_make_the_preconditioner_independent_of_the_number_of_ranks(
             c.halo_set_owners(m["gid_rep"], capi.structured_owner(dim, dec, cells, m["gid_rep"]))
             c.comm_set_thread_group(group)
             setup(c)
-            z = c.schwarz_apply(r[m["gid_uni"]])
+            gd = (m["gid_uni"][:, None] * dofs + np.arange(dofs)[None, :]).ravel()     # global dof ids, node-interleaved
+            z = c.schwarz_apply(r[gd])
             x, its, _ = c.gmres(None, rtol=1e-10, max_it=500, restart=100, use_prec=True)
-            out[rank] = (m["gid_uni"], z, x, its)
+            out[rank] = (gd, z, x, its)
             c.close()
         except Exception as e:      # pragma: no cover
             errs.append(repr(e))
