@@ -323,6 +323,10 @@ def main():
             "spmv_frac_hbm_peak": kern["spmv"]["GBs"] / HBM_PEAK_GBS if "spmv" in kern else None,
             "mesh_generation_s": t_mesh, "mesh_upload_s": t_upload,
         }
+        if N > 1:
+            out["communication_note"] = ("phases 'halo' (pack kernel, grouped RCCL send/receive, unpack kernel; one before every SpMV "
+                                         "and every Schwarz apply) and 'allreduce' are HIP-event times on the library's stream, rank 0, "
+                                         "sampled every 8th call; 'allreduce' is also contained in 'ortho' and 'coarse_*'")
         if spmv_b2b is not None:
             out["spmv_back_to_back"] = spmv_b2b
         if two is not None:

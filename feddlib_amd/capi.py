@@ -15,9 +15,9 @@ FORM_LAPLACE, FORM_LAPLACE_VEC, FORM_MASS, FORM_MASS_VEC, FORM_LINELAS = range(5
 BLOCK_SCALAR, BLOCK_DIAG, BLOCK_FULL = range(3)
 COMBINE_RESTRICTED, COMBINE_AVERAGING, COMBINE_FULL = range(3)
 (T_SYMBOLIC, T_ASSEMBLE, T_RHS, T_DIRICHLET, T_SPMV, T_SCHWARZ_SETUP, T_SCHWARZ_APPLY, T_ORTHO, T_COARSE_SETUP,
- T_COARSE_APPLY) = range(10)
+ T_COARSE_APPLY, T_HALO, T_ALLREDUCE) = range(12)
 TIMER_NAMES = ["symbolic", "assemble", "rhs", "dirichlet", "spmv", "schwarz_setup", "schwarz_apply", "ortho",
-               "coarse_setup", "coarse_apply"]
+               "coarse_setup", "coarse_apply", "halo", "allreduce"]
 COARSE_Q1 = 1
 
 _i32p = C.POINTER(C.c_int32)

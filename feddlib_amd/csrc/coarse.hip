@@ -676,7 +676,7 @@ int coarse_setup(fedd_ctx* c) {
     FEDD_HIP(hipMemsetAsync(d_bad, 0, 3 * sizeof(int32_t), c->stream));
     hipLaunchKernelGGL(k_mask, dim3((unsigned)((c->n_rows + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_isdir.p,
                        c->n_rows, c->d_co_mask.p, d_bad + 2);
-    if (c->n_cols != c->n_rows) FEDD_TRY(halo_import(c, c->d_co_mask.p, dofs));
+    if (c->n_cols != c->n_rows || !c->halo.peers.empty()) FEDD_TRY(halo_import(c, c->d_co_mask.p, dofs));
     // ---- K0 = Phi^T A Phi ----
     const int NC = 1 << dim, NS = dim == 3 ? 64 : 16, NW = dim == 3 ? 125 : 25;
     // chunks per cell: about 256 nodes each (4 batches), so that few, well-filled cells still

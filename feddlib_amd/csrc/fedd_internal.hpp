@@ -228,7 +228,8 @@ struct ScopedTimer {
             // the per-iteration classes are sampled every timing_stride-th launch: an event pair
             // around each of several hundred small launches per solve costs a few percent
             const bool per_iteration = timer == FEDD_T_SPMV || timer == FEDD_T_SCHWARZ_APPLY ||
-                                       timer == FEDD_T_ORTHO || timer == FEDD_T_COARSE_APPLY;
+                                       timer == FEDD_T_ORTHO || timer == FEDD_T_COARSE_APPLY ||
+                                       timer == FEDD_T_HALO || timer == FEDD_T_ALLREDUCE;
             const int64_t k = c->timers[id].seen++;
             if (per_iteration && c->timing_stride > 1 && k % c->timing_stride != 0) return;
             if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)

@@ -518,6 +518,7 @@ __global__ void k_axpby(double a, const double* __restrict__ x, double b, const 
 
 int allreduce_sum(fedd_ctx* c, double* d_buf, int n) {
     if (c->nranks == 1) return 0;
+    ScopedTimer timer(c, FEDD_T_ALLREDUCE);
     if (c->cb_allreduce) {  // host-staged transport (functional tests)
         std::vector<double> tmp((size_t)n);
         FEDD_HIP(hipMemcpyAsync(tmp.data(), d_buf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));

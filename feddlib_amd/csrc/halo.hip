@@ -42,6 +42,7 @@ int halo_import(fedd_ctx* c, double* d_xcol, int dofs) {
     FEDD_CHECK(h.ready && (c->comm || c->cb_exchange),
                "halo import: no exchange plan / transport; call fedd_halo_exchange_setup after fedd_mesh_set");
     const int64_t ns = (int64_t)h.send_lid.size(), nr = (int64_t)h.recv_lid.size();
+    ScopedTimer timer(c, FEDD_T_HALO);
     if (ns > 0)
         hipLaunchKernelGGL(k_pack, dim3((unsigned)((ns * dofs + 255) / 256)), dim3(256), 0, c->stream, (const double*)d_xcol,
                            (const int32_t*)h.d_send_lid.p, ns, dofs, h.d_send_buf.p);

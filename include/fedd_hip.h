@@ -58,7 +58,9 @@ enum fedd_timer {
     FEDD_T_ORTHO    = 7,  /* GMRES multi-dot / multi-axpy kernels              */
     FEDD_T_COARSE_SETUP = 8,  /* second level: Galerkin product + dense inverse */
     FEDD_T_COARSE_APPLY = 9,  /* second level: restrict, K0^-1, prolongate      */
-    FEDD_T_COUNT    = 10
+    FEDD_T_HALO     = 10, /* ghost import: pack, send / receive, unpack (several ranks)  */
+    FEDD_T_ALLREDUCE= 11, /* all-reduce calls (inside the classes that issue them)        */
+    FEDD_T_COUNT    = 12
 };
 
 /* ------------------------------------------------------------------------------------------------
