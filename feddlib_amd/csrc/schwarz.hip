@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
         if (nf == 0) break;
         for (int k = tid; k < s_prev; k += 256)
             if (lst[k] >= n_stored) s_bad = 1;
+        if (tid == 0 && n_own + s_prev > NMAX) s_bad = 1;   // the whole box would not fit the dense solver: cut it
         __syncthreads();
         if (!s_bad) break;
         __syncthreads();
