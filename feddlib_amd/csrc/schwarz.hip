@@ -764,84 +764,109 @@ int schwarz_setup(fedd_ctx* c) {
     // default target: 27 nodes for scalar problems, 27 / dofs for node-interleaved vector problems
     // (the dense local solver takes 256 dofs including the overlap)
     const int target = c->sw_target > 0 ? c->sw_target : (c->merged ? 27 : std::max(1, 27 / std::max(1, dofs)));
-    const double s = c->sw_scale * std::pow(V * (double)target / n_nodes, 1.0 / dim);
-    int64_t nraw = 1;
-    for (int d = 0; d < 3; ++d) {
-        gm.g[d] = 1;
-        gm.w[d] = 1.0;
-        if (d >= dim) continue;
-        const double Lp = L[d] > 0 ? L[d] : 1.0;
-        int g = (int)std::ceil(Lp / s - 1e-9);
-        if (g < 1 || !(L[d] > 0)) g = 1;
-        if (g % 2 == 0) ++g;   // odd: the lattice has a centre box (see k_bin_id)
-        gm.g[d] = g;
-        gm.w[d] = Lp / g;
-        nraw *= g;
+    // If a subdomain comes out larger than the dense local solver takes (NMAX dofs with the overlap), the lattice is
+    // refined (box edge x 0.85) and the lists are built again: every rank takes the same decision (several
+    // ranks: the largest size is all-reduced), so the lattice stays one lattice.
+    int64_t nraw = 1, nsub = 0;
+    int32_t max_n = 0, max_own = 0;
+    bool foreign = false;
+    for (int attempt = 0;; ++attempt) {
+        const double s = c->sw_scale * std::pow(0.85, attempt) * std::pow(V * (double)target / n_nodes, 1.0 / dim);
+        nraw = 1;
+        for (int d = 0; d < 3; ++d) {
+            gm.g[d] = 1;
+            gm.w[d] = 1.0;
+            if (d >= dim) continue;
+            const double Lp = L[d] > 0 ? L[d] : 1.0;
+            int g = (int)std::ceil(Lp / s - 1e-9);
+            if (g < 1 || !(L[d] > 0)) g = 1;
+            if (g % 2 == 0) ++g;   // odd: the lattice has a centre box (see k_bin_id)
+            gm.g[d] = g;
+            gm.w[d] = Lp / g;
+            nraw *= g;
+        }
+        FEDD_CHECK(nraw < ((int64_t)1 << 30), "schwarz setup: %lld boxes", (long long)nraw);
+        // ---- dofs -> boxes (box of the carrying node), drop empty boxes, counting sort ----
+        // with row ghosts (and "whole_boxes") the row-ghost dofs are binned too: a box that holds owned dofs also
+        // lists the other ranks' dofs inside it, and k_sub_dofs builds the whole box when the stored rows reach
+        foreign = c->whole_boxes && c->box_kind == 0 && n_stored > n_rows && !c->merged;
+        const int32_t n_binned = foreign ? n_stored : n_rows;
+        FEDD_TRY(c->d_itmp0.ensure((size_t)n_binned));     // raw box of each dof
+        FEDD_TRY(c->d_itmp1.ensure((size_t)nraw + 1));     // raw counts
+        FEDD_TRY(c->d_itmp2.ensure((size_t)nraw + 1));     // flags -> compact ids
+        FEDD_HIP(hipMemsetAsync(c->d_itmp1.p, 0, ((size_t)nraw + 1) * sizeof(int32_t), c->stream));
+        const dim3 gn((n_rows + 255) / 256), gb((unsigned)((nraw + 255) / 256)), blk(256);
+        hipLaunchKernelGGL(k_bin_id, dim3((unsigned)((n_binned + 255) / 256)), blk, 0, c->stream, (const double*)c->d_xyz.p,
+                           n_binned, n_rows, dofs, (const int32_t*)(c->merged ? c->d_dof_node.p : nullptr), gm, c->d_itmp0.p,
+                           c->d_itmp1.p);
+        hipLaunchKernelGGL(k_flag_nonempty, gb, blk, 0, c->stream, (const int32_t*)c->d_itmp1.p, (int32_t)nraw, c->d_itmp2.p);
+        nsub = 0;
+        FEDD_TRY(exclusive_scan_i32(c, c->d_itmp2.p, c->d_itmp2.p, nraw, &nsub));
+        FEDD_CHECK(nsub > 0, "schwarz setup: no subdomain");
+        c->sw_nsub = nsub;
+        FEDD_TRY(c->d_bin_ptr.ensure((size_t)nsub + 1));
+        FEDD_TRY(c->d_bin_nodes.ensure((size_t)n_rows));   // dofs grouped by box
+        FEDD_TRY(c->d_node_bin.ensure((size_t)n_rows));    // compact box id of each dof
+        FEDD_TRY(c->d_sub_n.ensure((size_t)nsub));
+        FEDD_TRY(c->d_sub_nown.ensure((size_t)nsub));
+        FEDD_TRY(c->d_sub_dofs.ensure((size_t)nsub * NMAX));
+        hipLaunchKernelGGL(k_compact_counts, gb, blk, 0, c->stream, (const int32_t*)c->d_itmp1.p, (const int32_t*)c->d_itmp2.p,
+                           (int32_t)nraw, c->d_bin_ptr.p);
+        FEDD_TRY(exclusive_scan_i32(c, c->d_bin_ptr.p, c->d_bin_ptr.p, nsub, nullptr));
+        // cursor = copy of bin_ptr (reuse the raw-count buffer)
+        FEDD_HIP(hipMemcpyAsync(c->d_itmp1.p, c->d_bin_ptr.p, (size_t)nsub * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_fill_bins, gn, blk, 0, c->stream, (const int32_t*)c->d_itmp0.p, (const int32_t*)c->d_itmp2.p, n_rows,
+                           c->d_itmp1.p, c->d_node_bin.p, c->d_bin_nodes.p);
+        hipLaunchKernelGGL(k_sort_bins, dim3((unsigned)((nsub + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_bin_ptr.p,
+                           (int32_t)nsub, c->d_bin_nodes.p);
+        // ---- foreign members of the boxes (row-ghost dofs), same counting sort ----
+        if (foreign) {
+            const int32_t nfor = n_stored - n_rows;
+            const dim3 gf((unsigned)((nfor + 255) / 256));
+            FEDD_TRY(c->d_fbin_ptr.ensure((size_t)nsub + 1));
+            FEDD_TRY(c->d_fbin_nodes.ensure((size_t)nfor));
+            FEDD_HIP(hipMemsetAsync(c->d_fbin_ptr.p, 0, ((size_t)nsub + 1) * sizeof(int32_t), c->stream));
+            hipLaunchKernelGGL(k_foreign_count, gf, blk, 0, c->stream, (const int32_t*)c->d_itmp0.p, (const int32_t*)c->d_itmp2.p,
+                               n_rows, n_stored, c->d_fbin_ptr.p);
+            FEDD_TRY(exclusive_scan_i32(c, c->d_fbin_ptr.p, c->d_fbin_ptr.p, nsub, nullptr));
+            FEDD_HIP(hipMemcpyAsync(c->d_itmp1.p, c->d_fbin_ptr.p, (size_t)nsub * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_foreign_fill, gf, blk, 0, c->stream, (const int32_t*)c->d_itmp0.p, (const int32_t*)c->d_itmp2.p,
+                               n_rows, n_stored, c->d_itmp1.p, c->d_fbin_nodes.p);
+            hipLaunchKernelGGL(k_sort_bins, dim3((unsigned)((nsub + 255) / 256)), blk, 0, c->stream,
+                               (const int32_t*)c->d_fbin_ptr.p, (int32_t)nsub, c->d_fbin_nodes.p);
+        }
+        // ---- overlapping dof lists ----
+        hipLaunchKernelGGL(k_sub_dofs, dim3((unsigned)nsub), blk, 0, c->stream, (const int32_t*)c->d_bin_ptr.p,
+                           (const int32_t*)c->d_bin_nodes.p, (const int32_t*)c->d_node_bin.p,
+                           (const int32_t*)(foreign ? c->d_fbin_ptr.p : nullptr), (const int32_t*)(foreign ? c->d_fbin_nodes.p : nullptr),
+                           (const int32_t*)c->d_rowptr.p,
+                           (const int32_t*)c->d_colind.p, n_rows, (int32_t)c->n_rows_ext, c->ghost_overlap, c->sw_overlap,
+                           c->d_sub_n.p, c->d_sub_nown.p,
+                           c->d_sub_dofs.p);
+        max_n = 0;
+        FEDD_TRY(reduce_max_i32(c, c->d_sub_n.p, nsub, &max_n));
+        c->sw_max_size = max_n;
+        max_own = 0;
+        FEDD_TRY(reduce_max_i32(c, c->d_sub_nown.p, nsub, &max_own));
+        c->sw_max_own = max_own;
+        if (c->nranks > 1) {   // the largest subdomain of any rank (max through the sum transport: own slot per rank)
+            std::vector<double> h((size_t)c->nranks, 0.0);
+            h[(size_t)c->rank] = (double)max_n;
+            FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>((size_t)c->nranks, c->d_dtmp0.cap)));
+            FEDD_HIP(hipMemcpyAsync(c->d_dtmp0.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            FEDD_TRY(allreduce_sum(c, c->d_dtmp0.p, c->nranks));
+            FEDD_HIP(hipMemcpyAsync(h.data(), c->d_dtmp0.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            FEDD_HIP(hipStreamSynchronize(c->stream));
+            double mx = 0.0;
+            for (double v : h) mx = std::max(mx, v);
+            c->sw_max_size_all = (int32_t)mx;
+        } else {
+            c->sw_max_size_all = max_n;
+        }
+        if (c->sw_max_size_all <= NMAX || attempt >= 8) break;
     }
-    FEDD_CHECK(nraw < ((int64_t)1 << 30), "schwarz setup: %lld boxes", (long long)nraw);
-    // ---- dofs -> boxes (box of the carrying node), drop empty boxes, counting sort ----
-    // with row ghosts (and "whole_boxes") the row-ghost dofs are binned too: a box that holds owned dofs also
-    // lists the other ranks' dofs inside it, and k_sub_dofs builds the whole box when the stored rows reach
-    const bool foreign = c->whole_boxes && c->box_kind == 0 && n_stored > n_rows && !c->merged;
-    const int32_t n_binned = foreign ? n_stored : n_rows;
-    FEDD_TRY(c->d_itmp0.ensure((size_t)n_binned));     // raw box of each dof
-    FEDD_TRY(c->d_itmp1.ensure((size_t)nraw + 1));     // raw counts
-    FEDD_TRY(c->d_itmp2.ensure((size_t)nraw + 1));     // flags -> compact ids
-    FEDD_HIP(hipMemsetAsync(c->d_itmp1.p, 0, ((size_t)nraw + 1) * sizeof(int32_t), c->stream));
-    const dim3 gn((n_rows + 255) / 256), gb((unsigned)((nraw + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(k_bin_id, dim3((unsigned)((n_binned + 255) / 256)), blk, 0, c->stream, (const double*)c->d_xyz.p,
-                       n_binned, n_rows, dofs, (const int32_t*)(c->merged ? c->d_dof_node.p : nullptr), gm, c->d_itmp0.p,
-                       c->d_itmp1.p);
-    hipLaunchKernelGGL(k_flag_nonempty, gb, blk, 0, c->stream, (const int32_t*)c->d_itmp1.p, (int32_t)nraw, c->d_itmp2.p);
-    int64_t nsub = 0;
-    FEDD_TRY(exclusive_scan_i32(c, c->d_itmp2.p, c->d_itmp2.p, nraw, &nsub));
-    FEDD_CHECK(nsub > 0, "schwarz setup: no subdomain");
-    c->sw_nsub = nsub;
-    FEDD_TRY(c->d_bin_ptr.ensure((size_t)nsub + 1));
-    FEDD_TRY(c->d_bin_nodes.ensure((size_t)n_rows));   // dofs grouped by box
-    FEDD_TRY(c->d_node_bin.ensure((size_t)n_rows));    // compact box id of each dof
-    FEDD_TRY(c->d_sub_n.ensure((size_t)nsub));
-    FEDD_TRY(c->d_sub_nown.ensure((size_t)nsub));
-    FEDD_TRY(c->d_sub_dofs.ensure((size_t)nsub * NMAX));
-    hipLaunchKernelGGL(k_compact_counts, gb, blk, 0, c->stream, (const int32_t*)c->d_itmp1.p, (const int32_t*)c->d_itmp2.p,
-                       (int32_t)nraw, c->d_bin_ptr.p);
-    FEDD_TRY(exclusive_scan_i32(c, c->d_bin_ptr.p, c->d_bin_ptr.p, nsub, nullptr));
-    // cursor = copy of bin_ptr (reuse the raw-count buffer)
-    FEDD_HIP(hipMemcpyAsync(c->d_itmp1.p, c->d_bin_ptr.p, (size_t)nsub * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
-    hipLaunchKernelGGL(k_fill_bins, gn, blk, 0, c->stream, (const int32_t*)c->d_itmp0.p, (const int32_t*)c->d_itmp2.p, n_rows,
-                       c->d_itmp1.p, c->d_node_bin.p, c->d_bin_nodes.p);
-    hipLaunchKernelGGL(k_sort_bins, dim3((unsigned)((nsub + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_bin_ptr.p,
-                       (int32_t)nsub, c->d_bin_nodes.p);
-    // ---- foreign members of the boxes (row-ghost dofs), same counting sort ----
-    if (foreign) {
-        const int32_t nfor = n_stored - n_rows;
-        const dim3 gf((unsigned)((nfor + 255) / 256));
-        FEDD_TRY(c->d_fbin_ptr.ensure((size_t)nsub + 1));
-        FEDD_TRY(c->d_fbin_nodes.ensure((size_t)nfor));
-        FEDD_HIP(hipMemsetAsync(c->d_fbin_ptr.p, 0, ((size_t)nsub + 1) * sizeof(int32_t), c->stream));
-        hipLaunchKernelGGL(k_foreign_count, gf, blk, 0, c->stream, (const int32_t*)c->d_itmp0.p, (const int32_t*)c->d_itmp2.p,
-                           n_rows, n_stored, c->d_fbin_ptr.p);
-        FEDD_TRY(exclusive_scan_i32(c, c->d_fbin_ptr.p, c->d_fbin_ptr.p, nsub, nullptr));
-        FEDD_HIP(hipMemcpyAsync(c->d_itmp1.p, c->d_fbin_ptr.p, (size_t)nsub * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
-        hipLaunchKernelGGL(k_foreign_fill, gf, blk, 0, c->stream, (const int32_t*)c->d_itmp0.p, (const int32_t*)c->d_itmp2.p,
-                           n_rows, n_stored, c->d_itmp1.p, c->d_fbin_nodes.p);
-        hipLaunchKernelGGL(k_sort_bins, dim3((unsigned)((nsub + 255) / 256)), blk, 0, c->stream,
-                           (const int32_t*)c->d_fbin_ptr.p, (int32_t)nsub, c->d_fbin_nodes.p);
-    }
-    // ---- overlapping dof lists ----
-    hipLaunchKernelGGL(k_sub_dofs, dim3((unsigned)nsub), blk, 0, c->stream, (const int32_t*)c->d_bin_ptr.p,
-                       (const int32_t*)c->d_bin_nodes.p, (const int32_t*)c->d_node_bin.p,
-                       (const int32_t*)(foreign ? c->d_fbin_ptr.p : nullptr), (const int32_t*)(foreign ? c->d_fbin_nodes.p : nullptr),
-                       (const int32_t*)c->d_rowptr.p,
-                       (const int32_t*)c->d_colind.p, n_rows, (int32_t)c->n_rows_ext, c->ghost_overlap, c->sw_overlap,
-                       c->d_sub_n.p, c->d_sub_nown.p,
-                       c->d_sub_dofs.p);
-    int32_t max_n = 0;
-    FEDD_TRY(reduce_max_i32(c, c->d_sub_n.p, nsub, &max_n));
-    c->sw_max_size = max_n;
-    int32_t max_own = 0;
-    FEDD_TRY(reduce_max_i32(c, c->d_sub_nown.p, nsub, &max_own));
-    c->sw_max_own = max_own;
+    max_n = std::max(max_n, c->sw_max_size_all);
+    const dim3 blk(256);
     FEDD_CHECK(max_n <= NMAX,
                "schwarz setup: an overlapping subdomain has %d dofs, the dense local solver takes at most %d; "
                "lower the target with fedd_schwarz_set_target (now %d nodes)", max_n, NMAX, target);

@@ -193,3 +193,19 @@ def test_spmv_kernels_agree(fedd_lib, ctx, dim, M):
     finally:
         ctx.set_option("spmv_kind", 0)
     assert np.array_equal(ys[0], ys[2])
+
+
+def test_box_lattice_refines_itself_when_a_subdomain_would_exceed_the_dense_solver(fedd_lib, ctx):
+    """125-node boxes plus overlap are far beyond the 256 dofs the dense local solver takes: the setup refines
+    the lattice (box edge x 0.85 per attempt) until every subdomain fits, and the solve is still exact."""
+    m, A_bc, rhs_bc, flags = laplace(fedd_lib, ctx, 3, 14)
+    ctx.schwarz_set_target(125, 1.0)
+    try:
+        ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+        info = ctx.schwarz_info()
+        assert info["max_size"] <= 256 and info["n_subdomains"] > 27       # 3^3 boxes of 125 nodes were asked for
+        x, its, rel = ctx.gmres(None, rtol=1e-12, max_it=300, restart=100, use_prec=True)
+        xd = fo.direct_solve(A_bc, rhs_bc)
+        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+    finally:
+        ctx.schwarz_set_target(0, 1.0)
