@@ -863,7 +863,10 @@ int schwarz_setup(fedd_ctx* c) {
         } else {
             c->sw_max_size_all = max_n;
         }
-        if (c->sw_max_size_all <= NMAX || attempt >= 8) break;
+        // with the default target the lattice is also refined past the register-tiled inversion classes (160 dofs):
+        // the LDS variant beyond them is an order of magnitude slower than what the few extra iterations cost
+        const int32_t limit = c->sw_target > 0 ? NMAX : 160;
+        if (c->sw_max_size_all <= limit || attempt >= 8) break;
     }
     max_n = std::max(max_n, c->sw_max_size_all);
     const dim3 blk(256);
