@@ -252,6 +252,35 @@ def main():
                             ("; the matrix (%.0f MB) fits the 256 MB Infinity Cache, so this is not a pure HBM figure"
                              % (b / 1e6) if b < 256e6 else "")}
     kern = kernel_table(tm, m, nr, nnz, info) if rank == 0 else None
+
+    # ---- N > 1, outside every timed region: the communication checked against communication-free references ----
+    self_check = None
+    if N > 1:
+        import scipy.sparse as sp
+
+        def sum_over_ranks(v):
+            tt = torch.tensor([v], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            return float(tt.item())
+
+        # (1) halo exchange: distributed SpMV of x(gid) against the same product with every column value computed
+        #     locally from its global id (no exchange involved)
+        rowptr, col, val, col_gid = c.csr_get()
+        fgid = lambda g: np.sin(1.0e-3 * g) + 1.0e-7 * g
+        y = c.spmv(fgid(m["gid_uni"].astype(np.float64)))
+        A_loc = sp.csr_matrix((val, col, rowptr), shape=(rowptr.shape[0] - 1, col_gid.shape[0]))
+        y_ref = A_loc @ fgid(col_gid.astype(np.float64))
+        halo_err = max_over_ranks(float(np.abs(y - y_ref).max() / max(np.abs(y_ref).max(), 1e-300)))
+        # (2) all-reduce: the residual GMRES reports (built from the library's all-reduced dot products) against
+        #     ||b - A x|| / ||b|| formed with torch.distributed
+        one_step(c, capi, a, False)
+        c.sync()
+        x, b = c.solution_get(), c.rhs_get()
+        r = b - c.spmv(x)
+        true_rel = (sum_over_ranks(float(r @ r)) / sum_over_ranks(float(b @ b))) ** 0.5
+        self_check = {"halo_spmv_max_rel_err": halo_err, "true_relres": true_rel, "reported_relres": rel}
+        if not (halo_err <= 1e-12 and true_rel <= 10.0 * a.rtol):
+            raise SystemExit("bench.py: communication self-check failed: %r" % (self_check,))
     c.close()
     del m
 
@@ -324,6 +353,7 @@ def main():
             "mesh_generation_s": t_mesh, "mesh_upload_s": t_upload,
         }
         if N > 1:
+            out["self_check"] = self_check
             out["communication_note"] = ("phases 'halo' (pack kernel, grouped RCCL send/receive, unpack kernel; one before every SpMV "
                                          "and every Schwarz apply) and 'allreduce' are HIP-event times on the library's stream, rank 0, "
                                          "sampled every 8th call; 'allreduce' is also contained in 'ortho' and 'coarse_*'")

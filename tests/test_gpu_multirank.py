@@ -234,6 +234,7 @@ def test_bench_contract_n2_fixed_grid_rehearsal(fedd_lib):
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["self_check"]["halo_spmv_max_rel_err"] <= 1e-12 and d["self_check"]["true_relres"] <= 1e-7
     assert d["config"]["dofs"] == 25 ** 3 and d["config"]["relres"] <= 1e-8
     assert "1x1x2 blocks of 24x24x12 cells" in d["config"]["workload"]
 
