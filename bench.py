@@ -30,6 +30,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: without this RCCL's peer-to-peer setup fails (hipIpcGetMemHandle)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 DECOMP = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
