@@ -274,12 +274,14 @@ int matrix_scale(fedd_ctx* c, int slot, double alpha);
 int block_merge(fedd_ctx* c, int slot_a, int slot_bt, int slot_b, int slot_c);
 
 // spmv.hip
-int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned);   // incl. ghost import
+// x_has_tail: the buffer behind d_x_owned has room for all n_cols entries; the ghost values are then imported in
+// place (behind the owned entries) instead of into a copy of x
+int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_has_tail = false);   // incl. ghost import
 int halo_import(fedd_ctx* c, double* d_xcol, int dofs);                    // fill ghost tail
 
 // schwarz.hip
 int schwarz_setup(fedd_ctx* c);
-int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned);
+int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool r_has_tail = false);
 int bounding_box(fedd_ctx* c, int64_t n_nodes, double lo[3], double hi[3]);   // of d_xyz[0, n_nodes)
 int global_box(fedd_ctx* c, int64_t n_own, double lo[3], double hi[3], double* n_global);   // over all ranks
 

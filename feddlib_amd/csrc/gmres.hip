@@ -546,8 +546,11 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
     FEDD_CHECK(m + 2 <= 1024, "gmres: restart length above 1022 is not supported");
     const int nblk = (int)((n + MD_ROWS - 1) / MD_ROWS), nblk2 = (int)((n + AX_ROWS - 1) / AX_ROWS);
     FEDD_TRY(c->d_V.ensure((size_t)(m + 1) * ldv));
-    FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)2 * n, c->d_w.cap)));   // u | w~
-    FEDD_TRY(c->d_Z.ensure((size_t)n * 2));
+    // work vectors carry room for the ghost entries behind the owned ones (several ranks): the halo import of an
+    // operator input then goes straight into the vector, without a copy into a column-length buffer first
+    const int64_t nc = (std::max<int64_t>(n, c->n_cols) + 15) & ~(int64_t)15;
+    FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)2 * nc, c->d_w.cap)));   // u | w~
+    FEDD_TRY(c->d_Z.ensure((size_t)nc * 2));
     FEDD_TRY(c->d_part.ensure(std::max((size_t)(2 * m + 4) * nblk * 2, (size_t)nblk2)));
     Off o;
     Off2 o2;
@@ -569,9 +572,9 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
     double* S = c->d_small.p;
     double* V = c->d_V.p;
     double* u = c->d_w.p;        // first-pass result / next basis vector before its second pass
-    double* wt = c->d_w.p + n;   // B u
+    double* wt = c->d_w.p + nc;  // B u
     double* z = c->d_Z.p;        // M^-1 v
-    double* r = c->d_Z.p + n;    // residual / V y
+    double* r = c->d_Z.p + nc;   // residual / V y
     const dim3 gn((unsigned)((n + 255) / 256)), blk(256);
     hipStream_t st = c->stream;
 
@@ -581,8 +584,9 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
         return allreduce_sum(c, out, 1);
     };
     auto apply_B = [&](const double* in, double* out) -> int {  // out = A M^-1 in
-        if (use_prec) FEDD_TRY(schwarz_apply(c, in, z));
-        return spmv_owned(c, use_prec ? z : in, out);
+        const bool tail = in == u;     // u, z and r have a ghost tail, a basis column does not
+        if (use_prec) FEDD_TRY(schwarz_apply(c, in, z, tail));
+        return spmv_owned(c, use_prec ? z : in, out, use_prec ? true : tail);
     };
 
     FEDD_HIP(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), st));  // "Zero Initial Guess" (LinearSolver_def.hpp:76-78)
@@ -684,7 +688,7 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
         hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(kfin + 1) * sizeof(double), st, S, o, kfin, m);
         hipLaunchKernelGGL(k_combine, gn, blk, 0, st, (const double*)V, ldv, n, kfin, (const double*)(S + o.y), r);
         if (use_prec) {
-            FEDD_TRY(schwarz_apply(c, r, z));
+            FEDD_TRY(schwarz_apply(c, r, z, true));
             hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)z, d_x, n);
         } else {
             hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)r, d_x, n);

@@ -971,12 +971,16 @@ int schwarz_setup(fedd_ctx* c) {
 }
 
 // z_owned = M^-1 r_owned
-int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned) {
+int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool r_has_tail) {
     const double* r = d_r_owned;
     if (c->n_cols != c->n_rows || !c->halo.peers.empty()) {   // also a rank that only sends takes part
-        FEDD_HIP(hipMemcpyAsync(c->d_xcol.p, d_r_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        FEDD_TRY(halo_import(c, c->d_xcol.p, c->dofs));
-        r = c->d_xcol.p;
+        if (r_has_tail) {   // the caller's buffer takes the ghost values behind its owned entries
+            FEDD_TRY(halo_import(c, const_cast<double*>(d_r_owned), c->dofs));
+        } else {
+            FEDD_HIP(hipMemcpyAsync(c->d_xcol.p, d_r_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            FEDD_TRY(halo_import(c, c->d_xcol.p, c->dofs));
+            r = c->d_xcol.p;
+        }
     }
     const dim3 grid((unsigned)c->sw_nsub), blk(256);
     if (c->sw_combine == FEDD_COMBINE_RESTRICTED) {

@@ -153,12 +153,16 @@ __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ ro
 
 }  // namespace
 
-int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned) {
+int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_has_tail) {
     const double* x = d_x_owned;
     if (c->n_cols != c->n_rows || !c->halo.peers.empty()) {   // also a rank that only sends takes part
-        FEDD_HIP(hipMemcpyAsync(c->d_xcol.p, d_x_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        FEDD_TRY(halo_import(c, c->d_xcol.p, c->dofs));
-        x = c->d_xcol.p;
+        if (x_has_tail) {   // the caller's buffer takes the ghost values behind its owned entries
+            FEDD_TRY(halo_import(c, const_cast<double*>(d_x_owned), c->dofs));
+        } else {
+            FEDD_HIP(hipMemcpyAsync(c->d_xcol.p, d_x_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            FEDD_TRY(halo_import(c, c->d_xcol.p, c->dofs));
+            x = c->d_xcol.p;
+        }
     }
     const double avg = c->n_rows ? (double)c->nnz / (double)c->n_rows : 1.0;
     const int32_t n = (int32_t)c->n_rows;
