@@ -467,3 +467,20 @@ def test_whole_boxes_make_the_preconditioner_independent_of_the_number_of_ranks(
         assert its == its_ref
     np.testing.assert_allclose(z, z_ref, rtol=0, atol=1e-13 * np.abs(z_ref).max())
     np.testing.assert_allclose(x, x_ref, rtol=0, atol=1e-9 * np.abs(x_ref).max())
+
+
+def test_bench_contract_n4_fixed_grid_rehearsal(fedd_lib):
+    """bench.py's 1x2x2 split of a fixed grid (four ranks on one GPU over gloo), with the communication self-check."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1",
+           "--warmup", "0", "--global-cells", "32", "--rehearse-one-gpu", "--no-two-level"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["dofs"] == 33 ** 3
+    assert "1x2x2 blocks of 32x16x16 cells" in d["config"]["workload"]
+    assert d["self_check"]["halo_spmv_max_rel_err"] <= 1e-12 and d["self_check"]["true_relres"] <= 1e-7
+    assert "halo" in d["phases_device_ms_per_step"] and "allreduce" in d["phases_device_ms_per_step"]
