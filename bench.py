@@ -212,6 +212,8 @@ def main():
     m = capi.structured_mesh(3, dec, cells, rank, size=dom, ghosts=4 if N > 1 else 0)
     t_mesh = time.perf_counter() - t0
     c = capi.Context(device=dev, rank=rank, nranks=N, nccl_id=nccl_id)
+    for kv in filter(None, os.environ.get("FEDD_OPTIONS", "").split(",")):   # development: key=value,...
+        c.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     t0 = time.perf_counter()
     c.mesh_set_dict(m)
     if N > 1:

@@ -106,9 +106,11 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__
 // and dropped: 16-byte loads (same), windows of 6 / 10 / 12 x 256 entries (same within 2 %), a persistent
 // variant that prefetches the next window behind the gathers (87 VGPRs, 5 workgroups per CU: slower),
 // gathering in the row phase with 1 / 2 / 4 lanes per row (coalesced gathers: same or slower).
-// Non-temporal loads of the matrix stream: 214^3 cells 406 -> 380 us back to back (x is no longer pushed out
-// of L2 between the visits of neighbouring node planes) but 388 us either way inside the solver; 100^3 cells
-// 31 -> 40 us (the 203 MB matrix is partly served by the Infinity Cache from one SpMV to the next): not used.
+// Non-temporal loads of the matrix stream (option "spmv_nt"): 214^3 cells 406 -> 380 us back to back (x is no
+// longer pushed out of L2 between the visits of neighbouring node planes) but within the noise inside the solver
+// (same box: 391 / 376 us and 395 / 394 us, step 636 / 634 and 638 / 638 ms); 100^3 cells 31 -> 40 us (the 203 MB
+// matrix is partly served by the Infinity Cache from one SpMV to the next): off by default.
+template <bool NT>
 __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                   const double* __restrict__ val, const double* __restrict__ x,
                                                   double* __restrict__ y, const int32_t* __restrict__ block_row,
@@ -125,13 +127,13 @@ __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ ro
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int32_t idx = min(base + tid + u * 256, last);
-        v[u] = val[idx];
-        cc[u] = colind[idx];
+        v[u] = NT ? __builtin_nontemporal_load(val + idx) : val[idx];
+        cc[u] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
     }
     {
         const int32_t idx = min(base + CH + min(tid, ovh - 1), last);
-        v[NU] = val[idx];
-        cc[NU] = colind[idx];
+        v[NU] = NT ? __builtin_nontemporal_load(val + idx) : val[idx];
+        cc[NU] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
     }
     const int32_t r_first = max(min(R0 + tid, R1 - 1), 0);
     const int32_t rb0 = rowptr[r_first], re0 = rowptr[r_first + 1];
@@ -181,8 +183,12 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
         const int32_t ovh = (int32_t)std::max<int64_t>(c->max_row_nnz, 1);
         const size_t lds = (size_t)(SP_CHUNK + ovh) * sizeof(double);
         ScopedTimer ts(c, FEDD_T_SPMV);
-        if (windowed)
-            hipLaunchKernelGGL(k_spmv_win, dim3((unsigned)nb), dim3(256), lds, c->stream, (const int32_t*)c->d_rowptr.p,
+        if (windowed && c->spmv_nt)
+            hipLaunchKernelGGL(k_spmv_win<true>, dim3((unsigned)nb), dim3(256), lds, c->stream, (const int32_t*)c->d_rowptr.p,
+                               (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, x, d_y_owned,
+                               (const int32_t*)c->d_spmv_rows.p, nb, (int32_t)c->nnz, ovh);
+        else if (windowed)
+            hipLaunchKernelGGL(k_spmv_win<false>, dim3((unsigned)nb), dim3(256), lds, c->stream, (const int32_t*)c->d_rowptr.p,
                                (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, x, d_y_owned,
                                (const int32_t*)c->d_spmv_rows.p, nb, (int32_t)c->nnz, ovh);
         else
