@@ -582,15 +582,21 @@ __global__ __launch_bounds__(256) void k_apply(const int32_t* __restrict__ sub_n
 // persistent, software-pipelined variant of this kernel was slower (183 us) and is not kept.
 constexpr int AP_BATCH = 6;  // 16-byte loads in flight per lane (6 * 512 elements cover 101 x 27)
 
+// COMPACT (subdomains of at most 128 dofs): the gathered r and, after the products, the partial row sums share
+// 152 doubles of static LDS, so that an interior 101 x 27 subdomain takes 21824 + 1216 = 23040 B and seven
+// workgroups fit the 160 KB of a CU instead of six (the partial sums then use 152 / nrow lane groups instead of
+// 256 / nrow).  Otherwise 256 + 256 doubles.
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ sub_n,
                                                     const int32_t* __restrict__ sub_nown,
                                                     const int32_t* __restrict__ sub_dofs,
                                                     const int64_t* __restrict__ inv_ptr,
                                                     const double* __restrict__ inv, const double* __restrict__ r,
                                                     double* __restrict__ z, int span) {
-    __shared__ double rsub[NMAX];
-    __shared__ double part[256];
-    __shared__ int32_t sdof[NMAX];
+    constexpr int PS = COMPACT ? 152 : 256;          // partial-sum slots
+    __shared__ double shbuf[COMPACT ? 152 : NMAX + 256];
+    double* const rsub = shbuf;
+    double* const part = COMPACT ? shbuf : shbuf + NMAX;
     extern __shared__ double prod[];
     const int tid = threadIdx.x;
     // bijective XCD remap (workgroups i and i + 8 share an XCD and its L2): XCD k takes a contiguous
@@ -616,10 +622,7 @@ __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ 
         a[k].y = t.y;
     }
     const double rv = r[d];
-    if (tid < n) {
-        sdof[tid] = d;
-        rsub[tid] = rv;
-    }
+    if (tid < n) rsub[tid] = rv;
     __syncthreads();
     const int dc = 512 / nrow, dr = 512 - dc * nrow;
     int c0 = (2 * tid) / nrow, r0 = 2 * tid - c0 * nrow;  // column / row of element f
@@ -650,12 +653,12 @@ __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ 
             ++c0;
         }
     }
-    __syncthreads();
-    const int S = 256 / nrow;
+    __syncthreads();   // all products parked; rsub is dead from here on (COMPACT: its space becomes `part`)
+    const int S = PS / nrow;
     const int rr = tid % nrow, s = tid / nrow;
-    double acc = 0.0;
     if (s < S) {
         // four independent LDS reads per step (fixed association, so still reproducible)
+        double acc = 0.0;
         const double* pr = prod + rr;
         int c = s;
         for (; c + 3 * S < n; c += 4 * S) {
@@ -663,13 +666,13 @@ __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ 
             acc += (p0 + p1) + (p2 + p3);
         }
         for (; c < n; c += S) acc += pr[c * nrow];
+        part[tid] = acc;
     }
-    part[tid] = acc;
     __syncthreads();
-    if (tid < nrow) {
+    if (tid < nrow) {   // lane tid < nrow loaded the dof id of owned row tid itself
         double sum = 0.0;
         for (int q = 0; q < S; ++q) sum += part[q * nrow + tid];
-        z[sdof[tid]] = sum;
+        z[d] = sum;
     }
 }
 
@@ -987,11 +990,17 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
         // flat streaming kernel while the product park of the largest slab fits 48 KB of LDS
         const size_t park = (((size_t)c->sw_max_size * (size_t)c->sw_max_own + 1) & ~(size_t)1) * sizeof(double);
         ScopedTimer t(c, FEDD_T_SCHWARZ_APPLY);
-        if (c->apply_kind == 0 && park <= 48 * 1024)
-            hipLaunchKernelGGL(k_apply_flat, grid, blk, park, c->stream, (const int32_t*)c->d_sub_n.p,
-                               (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
-                               (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned,
-                               (c->sw_max_size + 63) & ~63);
+        if ((c->apply_kind == 0 || c->apply_kind == 2) && park <= 48 * 1024)   // 2 = flat without the compact LDS layout (A/B)
+            if (c->sw_max_size <= 128 && c->apply_kind != 2)
+                hipLaunchKernelGGL(k_apply_flat<true>, grid, blk, park, c->stream, (const int32_t*)c->d_sub_n.p,
+                                   (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
+                                   (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned,
+                                   (c->sw_max_size + 63) & ~63);
+            else
+                hipLaunchKernelGGL(k_apply_flat<false>, grid, blk, park, c->stream, (const int32_t*)c->d_sub_n.p,
+                                   (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
+                                   (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned,
+                                   (c->sw_max_size + 63) & ~63);
         else
             hipLaunchKernelGGL(k_apply<true>, grid, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
                                (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
