@@ -293,6 +293,8 @@ def main():
     if N == 1 and not weak and not a.no_cfg2:
         m2 = capi.structured_mesh(3, dec, [100] * 3, 0)
         c2 = capi.Context(device=dev, rank=0, nranks=1, nccl_id=None)
+        for kv in filter(None, os.environ.get("FEDD_OPTIONS", "").split(",")):
+            c2.set_option(kv.split("=")[0], float(kv.split("=")[1]))
         c2.mesh_set_dict(m2)
         c2.sync()
         d1, i1, r1, t1 = measure(c2, m2["n_global"], False)

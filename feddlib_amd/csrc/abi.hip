@@ -607,6 +607,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     const std::string k(key);
     if (k == "spmv_kind") c->spmv_kind = (int)value;
     else if (k == "box_kind") c->box_kind = (int)value;
+    else if (k == "asm_lds_kb") c->asm_lds_kb = std::max(2, (int)value);
     else if (k == "spmv_nt") c->spmv_nt = (int)value;
     else if (k == "whole_boxes") c->whole_boxes = (int)value;
     else if (k == "asm_kind") c->asm_kind = (int)value;

@@ -549,7 +549,9 @@ int launch_pairs(fedd_ctx* c, const AsmArgs& a, int ntab, int64_t n_rows, int ro
     constexpr int CPP = PairCfg<DIM, NEN, FORM>::CPP;
     const int maxdeg = std::max(1, c->max_deg);
     const size_t per_row = (size_t)maxdeg * CPP * 12;  // f64 value + i32 column per contribution
-    int R = (int)std::min<size_t>(63, (40 * 1024) / per_row);  // <= 63: one wave scans the row offsets
+    // rows per workgroup from the LDS budget: 37 KB lets four workgroups share the 160 KB of a CU (40 KB: three;
+    // P1 Laplace 3D: 32 rows, 0.81 -> 0.59 ms at 100^3 cells, 7.9 -> 5.7 ms at 214^3; smaller budgets gain nothing more)
+    int R = (int)std::min<size_t>(63, ((size_t)c->asm_lds_kb * 1024) / per_row);  // <= 63: one wave scans the row offsets
     if (R < 1) R = 1;
     const int cap = R * maxdeg * CPP + R * 2;                   // + the per-row bank-shift padding
     const size_t lds = (size_t)ntab * 8 + (size_t)cap * 12 + (size_t)(R + 1) * 4 + 16;

@@ -246,6 +246,7 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
  * matrix cores, 2 = scalar-pivot without dropping rows;
  * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes;
  * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank;
+ * "asm_lds_kb" (default 37) = LDS budget in KB of the assembly kernel's contribution park, i.e. rows per workgroup;
  * "spmv_nt" 1 = the window SpMV streams the matrix non-temporally (x then survives in L2 between node planes:
  * -6 % back to back on a 1.8 GB matrix, nothing inside the solver, slower on matrices that fit the Infinity Cache);
  * "whole_boxes" 1 (default) = with row ghosts, a box that a rank boundary crosses is built whole (with its full
