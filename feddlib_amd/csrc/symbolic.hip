@@ -170,8 +170,13 @@ int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
     const int32_t n_own = (int32_t)(c->n_own + c->n_rowg);   // every node that gets rows (owned, then row ghosts)
     const int nen = c->nen;
     // upper bound for the distinct columns of one node row
-    int cap = c->max_deg * (nen - 1) + 1;
-    if (cap < 1) cap = 1;
+    int cap_full = c->max_deg * (nen - 1) + 1;
+    if (cap_full < 1) cap_full = 1;
+    // The per-lane lists live in LDS (cap x 64 ints per one-wave workgroup), and LDS decides how many waves a CU
+    // holds: the bound above (73 for P1 tets) gives 8, a list of 32 entries 20.  Vertex-only elements are tried
+    // with 32 first; a row that fills it (then the count may be cut off) sends the pass again with the full bound.
+    int cap = (nen == c->dim + 1) ? std::min(cap_full, 32) : cap_full;
+  retry_with_full_lists:
     const size_t lds = (size_t)cap * 64 * sizeof(int32_t);
     FEDD_CHECK(lds <= 160 * 1024, "pattern build: a node with %d incident elements exceeds the LDS list (cap %d)", c->max_deg, cap);
     const dim3 grid((n_own + 63) / 64), block(64);
@@ -193,6 +198,10 @@ int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
                        c->d_n2e.p, n_own, cap, nptr, (const int32_t*)nullptr, stash);
     int32_t max_nn = 0;
     FEDD_TRY(reduce_max_i32(c, nptr, n_own, &max_nn));
+    if (max_nn >= cap && cap < cap_full) {
+        cap = cap_full;
+        goto retry_with_full_lists;
+    }
     int64_t node_nnz = 0;
     FEDD_TRY(exclusive_scan_i32(c, nptr, nptr, n_own, &node_nnz));
     const int64_t mult = scalar ? 1 : (block_mode == FEDD_BLOCK_FULL ? (int64_t)dofs * dofs : dofs);
