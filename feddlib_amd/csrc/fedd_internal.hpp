@@ -150,7 +150,7 @@ struct fedd_ctx {
     int whole_boxes = 1;                        // row ghosts: build boxes whole across rank boundaries where the stored rows reach
     fedd::DevBuf<int32_t> d_fbin_ptr, d_fbin_nodes;   // [nsub+1], [row-ghost dofs] other ranks' dofs grouped by box
     int32_t sw_max_size_all = 0;                // largest subdomain over all ranks
-    int spmv_nt = 0;                            // 1 = the window SpMV streams the matrix non-temporally
+    int spmv_nt = -1;                           // window SpMV streams the matrix non-temporally: -1 = if larger than the Infinity Cache, 0 / 1
     int asm_lds_kb = 37;                        // LDS budget of the assembly kernel's contribution park (KB): 4 workgroups per CU
     int box_kind = 0;                           // Schwarz boxes: 0 = one lattice over all ranks' nodes, 1 = per-rank lattice
     int spmv_kind = 0;                          // 0 = CSR-window / automatic, 1 = row-per-lane-group, 2 = CSR-stream

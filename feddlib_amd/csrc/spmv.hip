@@ -109,7 +109,10 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__
 // Non-temporal loads of the matrix stream (option "spmv_nt"): 214^3 cells 406 -> 380 us back to back (x is no
 // longer pushed out of L2 between the visits of neighbouring node planes) but within the noise inside the solver
 // (same box: 391 / 376 us and 395 / 394 us, step 636 / 634 and 638 / 638 ms); 100^3 cells 31 -> 40 us (the 203 MB
-// matrix is partly served by the Infinity Cache from one SpMV to the next): off by default.
+// matrix is partly served by the Infinity Cache from one SpMV to the next): by default on for matrices larger than
+// that cache (spmv_nt = -1).  Also tried on the window kernel: gathering in the row phase from LDS-staged (val, col)
+// with 1 / 2 lanes per row (376 -> 386 / 391 us at 214^3): the gathers are not what limits it; in real traffic
+// (2.14 GB per launch, x fetched three times) the kernel runs at 0.91 of the read ceiling.
 template <bool NT>
 __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                   const double* __restrict__ val, const double* __restrict__ x,
@@ -183,7 +186,9 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
         const int32_t ovh = (int32_t)std::max<int64_t>(c->max_row_nnz, 1);
         const size_t lds = (size_t)(SP_CHUNK + ovh) * sizeof(double);
         ScopedTimer ts(c, FEDD_T_SPMV);
-        if (windowed && c->spmv_nt)
+        // non-temporal matrix stream: by default for matrices that do not fit the 256 MB Infinity Cache anyway
+        const bool nt = c->spmv_nt < 0 ? 12.0 * (double)c->nnz > 256.0 * 1024.0 * 1024.0 : c->spmv_nt != 0;
+        if (windowed && nt)
             hipLaunchKernelGGL(k_spmv_win<true>, dim3((unsigned)nb), dim3(256), lds, c->stream, (const int32_t*)c->d_rowptr.p,
                                (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, x, d_y_owned,
                                (const int32_t*)c->d_spmv_rows.p, nb, (int32_t)c->nnz, ovh);

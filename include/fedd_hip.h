@@ -248,7 +248,8 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
  * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank;
  * "asm_lds_kb" (default 37) = LDS budget in KB of the assembly kernel's contribution park, i.e. rows per workgroup;
  * "spmv_nt" 1 = the window SpMV streams the matrix non-temporally (x then survives in L2 between node planes:
- * -6 % back to back on a 1.8 GB matrix, nothing inside the solver, slower on matrices that fit the Infinity Cache);
+ * -6 % back to back on a 1.8 GB matrix, 0 to -4 % inside the solver, slower on matrices that fit the Infinity
+ * Cache), 0 = never, -1 (default) = for matrices larger than the Infinity Cache;
  * "whole_boxes" 1 (default) = with row ghosts, a box that a rank boundary crosses is built whole (with its full
  * overlap) on every rank that owns a part of it wherever the stored rows reach, 0 = each rank takes its part. */
 int fedd_set_option(fedd_ctx* ctx, const char* key, double value);
