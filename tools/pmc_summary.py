@@ -13,7 +13,7 @@ def load(d, name):
     return acc
 
 fe = load(sys.argv[1], "FETCH_SIZE"); wr = load(sys.argv[2], "WRITE_SIZE")
-classes = {"spmv": "k_spmv_win", "schwarz_apply": "k_apply", "assemble": "k_assemble_pairs<", "multidot": "k_multidot(",
+classes = {"spmv": "k_spmv_win<", "schwarz_apply": "k_apply", "assemble": "k_assemble_pairs<", "multidot": "k_multidot(",
            "multiaxpy": "k_multiaxpy(", "multidot2": "k_multidot2", "axpy2": "k_axpy2", "invert": "k_invert_reg<7"}
 out = {}
 for key, pat in classes.items():
