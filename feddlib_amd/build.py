@@ -70,20 +70,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 def build_driver(verbose: bool = True, which: str = "laplace") -> str:
-    """The C++ host-facade drivers (mirror feddlib/problems/tests/laplace/main.cpp and
+    """The example drivers under examples/drivers (test harness, not product: they mirror feddlib/problems/tests/laplace/main.cpp and
     steadyLinElas_Perf/main.cpp), g++ against the C ABI."""
     gxx = shutil.which("g++")
     if gxx is None:
         raise RuntimeError("g++ not found")
     host = os.path.join(HERE, "host")
-    out = os.path.join(host, "bin", which + "_driver")
-    src = os.path.join(host, "drivers", which + "_main.cpp")
+    ex = os.path.join(HERE, "..", "examples")
+    out = os.path.join(ex, "bin", which + "_driver")
+    src = os.path.join(ex, "drivers", which + "_main.cpp")
     deps = [src, os.path.join(host, "feddlib", "fedd_facade.hpp"), os.path.join(host, "Teuchos_shim.hpp"), LIB]
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
     os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = [gxx, "-std=c++17", "-O2", "-I", host, src, "-o", out, "-L", LIBDIR, "-lfedd_hip",
-           "-Wl,-rpath,$ORIGIN/../../lib"]
+           "-Wl,-rpath,$ORIGIN/../../feddlib_amd/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

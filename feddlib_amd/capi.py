@@ -15,9 +15,9 @@ FORM_LAPLACE, FORM_LAPLACE_VEC, FORM_MASS, FORM_MASS_VEC, FORM_LINELAS = range(5
 BLOCK_SCALAR, BLOCK_DIAG, BLOCK_FULL = range(3)
 COMBINE_RESTRICTED, COMBINE_AVERAGING, COMBINE_FULL = range(3)
 (T_SYMBOLIC, T_ASSEMBLE, T_RHS, T_DIRICHLET, T_SPMV, T_SCHWARZ_SETUP, T_SCHWARZ_APPLY, T_ORTHO, T_COARSE_SETUP,
- T_COARSE_APPLY, T_HALO, T_ALLREDUCE) = range(12)
+ T_COARSE_APPLY, T_HALO, T_ALLREDUCE, T_SPMV_SETUP) = range(13)
 TIMER_NAMES = ["symbolic", "assemble", "rhs", "dirichlet", "spmv", "schwarz_setup", "schwarz_apply", "ortho",
-               "coarse_setup", "coarse_apply", "halo", "allreduce"]
+               "coarse_setup", "coarse_apply", "halo", "allreduce", "spmv_setup"]
 COARSE_Q1 = 1
 
 _i32p = C.POINTER(C.c_int32)
@@ -65,6 +65,7 @@ SIGNATURES = {
     "fedd_solution_get": [C.c_void_p, _f64p],
     "fedd_spmv": [C.c_void_p, _f64p, _f64p],
     "fedd_spmv_device": [C.c_void_p, C.c_int],
+    "fedd_spmv_info": [C.c_void_p, _i64p, _i64p],
     "fedd_schwarz_setup": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],
     "fedd_schwarz_set_target": [C.c_void_p, C.c_int, C.c_double],
     "fedd_schwarz_set_coarse": [C.c_void_p, C.c_double],
@@ -78,6 +79,7 @@ SIGNATURES = {
     "fedd_timing_enable": [C.c_void_p, C.c_int],
     "fedd_timing_reset": [C.c_void_p],
     "fedd_timing_get": [C.c_void_p, C.c_int, _f64p, _i64p],
+    "fedd_read_bandwidth": [C.c_void_p, C.c_int64, C.c_int, _f64p],
     "fedd_halo_plan_sizes": [C.c_void_p, _ip, _i64p, _i64p],
     "fedd_halo_plan_get": [C.c_void_p, _i32p, _i64p, _i32p, _i64p, _i32p],
     "fedd_halo_set_owners": [C.c_void_p, C.c_int64, _i64p, _i32p],
@@ -392,6 +394,11 @@ class Context:
         _chk(self._L.fedd_spmv(self._h, _p(x, _f64p), _p(y, _f64p)))
         return y
 
+    def spmv_info(self):
+        a, b = C.c_int64(), C.c_int64()
+        _chk(self._L.fedd_spmv_info(self._h, C.byref(a), C.byref(b)))
+        return dict(nnz_pattern=a.value, nnz_streamed=b.value)
+
     def spmv_device(self, reps):
         _chk(self._L.fedd_spmv_device(self._h, reps))
 
@@ -458,6 +465,12 @@ class Context:
             _chk(self._L.fedd_timing_get(self._h, i, C.byref(ms), C.byref(n)))
             out[name] = (ms.value, n.value)
         return out
+
+    def read_bandwidth(self, nbytes=2 << 30, reps=10):
+        """GB/s of a read-only stream on this GPU (roofline calibration)."""
+        g = C.c_double()
+        _chk(self._L.fedd_read_bandwidth(self._h, int(nbytes), reps, C.byref(g)))
+        return g.value
 
     # ---- halo plan ----
     def halo_set_owners(self, gid_rep, owner_rep):

@@ -26,7 +26,7 @@ int timing_flush(fedd_ctx* c) {
             FEDD_HIP(hipEventSynchronize(pr.second));
             FEDD_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
             s.total_ms += ms;
-            s.launches += 1;
+            if (!pr.cont) s.launches += 1;
             (void)hipEventDestroy(pr.first);
             (void)hipEventDestroy(pr.second);
         }
@@ -83,7 +83,7 @@ extern "C" int fedd_ctx_create(fedd_ctx** out, int device, const void* nccl_uniq
         }
         if (hipHostMalloc((void**)&c->h_pinned, 4096 * sizeof(double)) != hipSuccess) {
             set_error("fedd_ctx_create: pinned allocation failed");
-            delete c;
+            fedd_ctx_destroy(c);   // frees the stream too
             return 1;
         }
         if (nranks > 1 && nccl_unique_id) {  // without an id: host-callback transport (tests only)
@@ -93,7 +93,7 @@ extern "C" int fedd_ctx_create(fedd_ctx** out, int device, const void* nccl_uniq
             ncclResult_t r = ncclCommInitRank(&comm, nranks, id, rank);
             if (r != ncclSuccess) {
                 set_error("ncclCommInitRank: %s", ncclGetErrorString(r));
-                delete c;
+                fedd_ctx_destroy(c);   // frees the stream and the pinned buffer
                 return 1;
             }
             c->comm = comm;
@@ -167,7 +167,7 @@ static int mesh_set_impl(fedd_ctx* c, int dim, int nen, int64_t n_elem, const in
     c->n_own = n_uni;
     c->n_rowg = 0;
     c->have_adj = c->have_pattern = c->have_schwarz = c->have_coarse = false;
-    c->halo = fedd::HaloPlan();
+    c->halo.reset();
 
     // column-local numbering: owned nodes in unique-map order, then ghosts sorted by global id
     std::unordered_map<int64_t, int32_t> own;
@@ -495,6 +495,21 @@ extern "C" int fedd_spmv_device(fedd_ctx* c, int reps) {
     return 0;
 }
 
+extern "C" int fedd_spmv_info(fedd_ctx* c, int64_t* nnz_pattern, int64_t* nnz_streamed) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_spmv_info: no matrix");
+    if (nnz_pattern) *nnz_pattern = c->nnz;
+    if (nnz_streamed) *nnz_streamed = c->cs_valid ? c->cs_nnz : c->nnz;
+    return 0;
+}
+
+extern "C" int fedd_read_bandwidth(fedd_ctx* c, int64_t bytes, int reps, double* gb_per_s) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(bytes >= (1 << 20) && reps > 0 && gb_per_s, "fedd_read_bandwidth: bytes %lld reps %d", (long long)bytes, reps);
+    FEDD_HIP(hipSetDevice(c->device));
+    return read_bandwidth(c, bytes, reps, gb_per_s);
+}
+
 extern "C" int fedd_schwarz_set_target(fedd_ctx* c, int target_nodes, double scale) {
     FEDD_CHECK(c, "null context");
     FEDD_CHECK(target_nodes >= 0 && scale > 0, "fedd_schwarz_set_target: target %d scale %g", target_nodes, scale);
@@ -609,6 +624,10 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "box_kind") c->box_kind = (int)value;
     else if (k == "asm_lds_kb") c->asm_lds_kb = std::max(2, (int)value);
     else if (k == "spmv_nt") c->spmv_nt = (int)value;
+    else if (k == "spmv_compact") {
+        c->spmv_compact = (int)value;
+        c->cs_valid = false;
+    }
     else if (k == "whole_boxes") c->whole_boxes = (int)value;
     else if (k == "asm_kind") c->asm_kind = (int)value;
     else if (k == "apply_kind") c->apply_kind = (int)value;

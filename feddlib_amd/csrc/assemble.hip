@@ -667,6 +667,7 @@ __global__ void k_divt_fill(const int32_t* __restrict__ nptr, const int32_t* __r
 // Uses (and overwrites) the system slot for the scalar node pattern, so blocks that must survive
 // have to be stored first.
 int assemble_div(fedd_ctx* c, int64_t n_p, int slot_b, int slot_bt) {
+    c->cs_valid = false;   // the solver's compacted SpMV stream follows the matrix values
     FEDD_CHECK(c->nranks == 1, "assemblyDivAndDivT: one rank only for now");
     FEDD_CHECK(n_p > 0 && n_p <= c->n_own, "assemblyDivAndDivT: %lld pressure nodes of %lld nodes", (long long)n_p, (long long)c->n_own);
     const int dim = c->dim, nen = c->nen;
@@ -734,6 +735,7 @@ namespace {
 }
 
 int assemble_matrix(fedd_ctx* c, int form, const double* params) {
+    c->cs_valid = false;   // the solver's compacted SpMV stream follows the matrix values
     const int dim = c->dim, nen = c->nen;
     int kform, degree;
     const int dg = fe_degree(nen, dim, true), ds = fe_degree(nen, dim, false);
@@ -809,6 +811,7 @@ int assemble_rhs(fedd_ctx* c, int dofs, const double* f_const, int extra_degree)
 }
 
 int apply_dirichlet_nodes(fedd_ctx* c, int64_t n, const int32_t* nodes, const int32_t* comp_mask, const double* values) {
+    c->cs_valid = false;   // the solver's compacted SpMV stream follows the matrix values
     if (n == 0) return 0;
     const int dofs = c->dofs;
     for (int64_t k = 0; k < n; ++k)
@@ -835,6 +838,7 @@ int apply_dirichlet_nodes(fedd_ctx* c, int64_t n, const int32_t* nodes, const in
 // matrix this equals setLocalRowOne on the diagonal block + setLocalRowZero on the off-diagonal
 // blocks of that block row (BCBuilder_def.hpp:589-707) applied before the merge.
 int apply_dirichlet_rows(fedd_ctx* c, int64_t n, const int32_t* rows, const double* values) {
+    c->cs_valid = false;   // the solver's compacted SpMV stream follows the matrix values
     if (n == 0) return 0;
     for (int64_t k = 0; k < n; ++k)
         FEDD_CHECK(rows[k] >= 0 && rows[k] < c->n_rows, "fedd_dirichlet_rows: row %d out of range", rows[k]);
@@ -855,6 +859,7 @@ int apply_dirichlet_rows(fedd_ctx* c, int64_t n, const int32_t* rows, const doub
 }
 
 int apply_dirichlet(fedd_ctx* c, int n_bc, const int32_t* flags, const int32_t* comp_mask, const double* values) {
+    c->cs_valid = false;   // the solver's compacted SpMV stream follows the matrix values
     BcArgs b;
     b.n = n_bc;
     b.dofs = c->dofs;

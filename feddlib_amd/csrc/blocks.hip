@@ -96,6 +96,7 @@ int matrix_store(fedd_ctx* c, int slot) {
 }
 
 int matrix_scale(fedd_ctx* c, int slot, double alpha) {
+    c->cs_valid = false;   // the solver's compacted SpMV stream follows the matrix values
     double* v = slot < 0 ? c->d_val.p : c->aux[slot].val.p;
     const int64_t n = slot < 0 ? c->nnz : c->aux[slot].nnz;
     if (n > 0) hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, v, n, alpha);
@@ -105,6 +106,7 @@ int matrix_scale(fedd_ctx* c, int slot, double alpha) {
 }
 
 int block_merge(fedd_ctx* c, int slot_a, int slot_bt, int slot_b, int slot_c) {
+    c->cs_valid = false;   // the solver's compacted SpMV stream follows the matrix values
     FEDD_CHECK(c->nranks == 1, "block merge: one rank only for now");
     const DevCsr* A = &c->aux[slot_a];
     const DevCsr* BT = slot_bt >= 0 ? &c->aux[slot_bt] : nullptr;

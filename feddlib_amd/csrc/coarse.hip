@@ -761,8 +761,8 @@ int coarse_apply_add(fedd_ctx* c, const double* d_r_owned, double* d_z_owned) {
     if (c->nranks > 1) {  // the collective is not part of the kernel time
         timer.stop();
         FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, (int)n0));
+        timer.resume();   // dense_mv and prolongation belong to the same apply (one sampling decision)
     }
-    ScopedTimer timer2(c, c->nranks > 1 ? FEDD_T_COARSE_APPLY : -1);
     hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)((n0 + 3) / 4)), blk, 0, c->stream, (const double*)c->d_co_K.p, ld, n0,
                        (const double*)c->d_co_r0.p, c->d_co_z0.p);
 #define K_PROLONG(D, ...) hipLaunchKernelGGL(k_prolong_add<D>, dim3((unsigned)((c->n_rows + 255) / 256)), blk, 0, c->stream, __VA_ARGS__)

@@ -42,6 +42,10 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;  // elements
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;             // owns its allocation: no copies (a copy once leaked the halo buffers)
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
     int ensure(size_t n) {
         if (n <= cap && p) return 0;
         if (p) {
@@ -77,6 +81,17 @@ struct HaloPlan {
     DevBuf<int32_t> d_send_lid, d_recv_lid;
     DevBuf<double> d_send_buf, d_recv_buf;     // sized for MAX_DOFS * nodes
     bool ready = false;
+    // back to the empty plan; the device buffers are kept (DevBuf grows on demand and is freed with the context)
+    void reset() {
+        peers.clear();
+        send_ptr.clear();
+        recv_ptr.clear();
+        send_lid.clear();
+        recv_lid.clear();
+        req_count.clear();
+        req_gid.clear();
+        ready = false;
+    }
 };
 
 // a device CSR matrix held beside the system matrix (blocks of a mixed problem before the merge)
@@ -102,7 +117,11 @@ struct TimerSlot {
     double total_ms = 0.0;
     int64_t launches = 0;   // launches that were timed
     int64_t seen = 0;       // launches that passed through (timed or not)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    struct Pair {
+        hipEvent_t first, second;
+        bool cont;          // second half of a launch that was interrupted (e.g. by a collective): time, not a launch
+    };
+    std::vector<Pair> pending;
 };
 
 }  // namespace fedd
@@ -158,6 +177,14 @@ struct fedd_ctx {
     fedd::DevBuf<int32_t> d_pat_stash;          // pattern build: merged node lists of the count pass, [k][node]
     fedd::DevBuf<int32_t> d_spmv_rows;          // CSR-stream: first row of every nnz window
     bool spmv_rows_ready = false;
+    // solver-private compacted copy of the owned rows: the entries that are exactly 0.0 left out (the structural
+    // zeros the reference's insertGlobalValues keeps in the pattern, and the zeroed entries of Dirichlet rows).
+    // fedd_csr_get keeps returning the reference pattern; SpMV streams this one (same y bit for bit for finite x).
+    int spmv_compact = 1;                       // option "spmv_compact": 1 = on (default), 0 = stream the parity CSR
+    bool cs_valid = false;                      // false after anything that writes d_val / the pattern
+    int64_t cs_nnz = 0;
+    fedd::DevBuf<int32_t> d_cs_rowptr, d_cs_col, d_cs_rows, d_cs_wincnt;
+    fedd::DevBuf<double> d_cs_val;
     fedd::DevCsr aux[fedd::MAX_AUX];            // stored blocks (A, B, B^T, C) of a mixed problem
     bool merged = false;                        // system matrix = merged blocks (dof -> node map below)
     int64_t merged_nA = 0;                      // rows of block row 0
@@ -226,6 +253,7 @@ struct ScopedTimer {
     fedd_ctx* c;
     int id;
     hipEvent_t a = nullptr, b = nullptr;
+    bool sampled = false, cont = false;
     ScopedTimer(fedd_ctx* ctx, int timer) : c(ctx), id(timer) {   // timer < 0: no-op
         if (c->timing && timer >= 0) {
             // the per-iteration classes are sampled every timing_stride-th launch: an event pair
@@ -235,6 +263,7 @@ struct ScopedTimer {
                                        timer == FEDD_T_HALO || timer == FEDD_T_ALLREDUCE;
             const int64_t k = c->timers[id].seen++;
             if (per_iteration && c->timing_stride > 1 && k % c->timing_stride != 0) return;
+            sampled = true;
             if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
                 (void)hipEventRecord(a, c->stream);
         }
@@ -242,8 +271,16 @@ struct ScopedTimer {
     void stop() {
         if (c->timing && a && b) {
             (void)hipEventRecord(b, c->stream);
-            c->timers[id].pending.emplace_back(a, b);
+            c->timers[id].pending.push_back({a, b, cont});
             a = b = nullptr;
+        }
+    }
+    // after stop(): time the rest of the same launch (same sampling decision, not another launch)
+    void resume() {
+        if (c->timing && sampled && !a) {
+            cont = true;
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+                (void)hipEventRecord(a, c->stream);
         }
     }
     ~ScopedTimer() { stop(); }
@@ -280,6 +317,7 @@ int block_merge(fedd_ctx* c, int slot_a, int slot_bt, int slot_b, int slot_c);
 // place (behind the owned entries) instead of into a copy of x
 int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_has_tail = false);   // incl. ghost import
 int halo_import(fedd_ctx* c, double* d_xcol, int dofs);                    // fill ghost tail
+int read_bandwidth(fedd_ctx* c, int64_t bytes, int reps, double* gbs);     // read-only streaming calibration
 
 // schwarz.hip
 int schwarz_setup(fedd_ctx* c);

@@ -642,9 +642,13 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
             ++checked;
             kfin = jj + 1;
             relres = hp[0] / beta0;
+            // beta^2 = u.u - s.s <= 0: a lucky breakdown, or cancellation after the first pass lost
+            // orthogonality.  Only the implicit residual says "converged"; otherwise the cycle ends here and
+            // the true residual decides (below).
             const bool breakdown = !(hp[2] > 0.0);
-            return (relres <= rtol || breakdown) ? 1 : 0;
+            return relres <= rtol ? 1 : (breakdown ? 2 : 0);
         };
+        bool broke = false;
         for (int j = 0; j < m && issued < max_it; ++j) {
             const int k = j + 1;  // basis vectors final before this step; the step finalises column j of H
             FEDD_TRY(apply_B(u, wt));
@@ -674,15 +678,17 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
                 const int rc = check(j - 1);
                 FEDD_CHECK(rc >= 0, "gmres: waiting for iteration %d failed", j - 1);
                 if (rc) {
-                    converged = true;
+                    converged = rc == 1;
+                    broke = rc == 2;
                     break;
                 }
             }
         }
-        if (!converged && checked < queued) {
+        if (!converged && !broke && checked < queued) {
             const int rc = check(queued - 1);
             FEDD_CHECK(rc >= 0, "gmres: waiting for iteration %d failed", queued - 1);
-            converged = rc != 0;
+            converged = rc == 1;
+            broke = rc == 2;
         }
         // x += M^-1 (V y) with the kfin finalised columns
         hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(kfin + 1) * sizeof(double), st, S, o, kfin, m);
@@ -693,10 +699,16 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
         } else {
             hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)r, d_x, n);
         }
-        if (!converged && its < max_it) {
+        if (!converged && (its < max_it || broke)) {
             FEDD_TRY(spmv_owned(c, d_x, r));
             hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, d_b, -1.0, (const double*)r, r, n);
             FEDD_TRY(norm2_into(r, S + o.nrm + 3));
+            if (broke) {   // rare path: the host reads the true residual (every rank takes the same decision)
+                FEDD_HIP(hipMemcpyAsync(c->h_pinned, S + o.nrm + 3, sizeof(double), hipMemcpyDeviceToHost, st));
+                FEDD_HIP(hipStreamSynchronize(st));
+                relres = std::sqrt(std::max(c->h_pinned[0], 0.0)) / beta0;
+                if (relres <= rtol) converged = true;
+            }
         }
     }
     FEDD_HIP(hipGetLastError());
@@ -790,7 +802,7 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
             ++checked;
             k = jj + 1;
             relres = hp[0] / beta0;
-            const bool breakdown = !(hp[2] > 0.0);
+            const bool breakdown = !(hp[2] > 0.0);   // ||w|| after both passes, behind the DGKS gate: a true breakdown
             return (relres <= rtol || breakdown) ? 1 : 0;
         };
         for (int j = 0; j < m && issued < max_it; ++j) {

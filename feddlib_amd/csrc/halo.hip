@@ -63,14 +63,18 @@ int halo_import(fedd_ctx* c, double* d_xcol, int dofs) {
         return 0;
     }
     ncclComm_t comm = (ncclComm_t)c->comm;
-    ncclGroupStart();
-    for (size_t k = 0; k < h.peers.size(); ++k) {
+    // every call of the group is checked; the group is closed in any case (an open group would swallow the
+    // next collective) and the first failure is the one reported
+    ncclResult_t bad = ncclGroupStart();
+    for (size_t k = 0; k < h.peers.size() && bad == ncclSuccess; ++k) {
         const int64_t s0 = h.send_ptr[k] * dofs, s1 = h.send_ptr[k + 1] * dofs;
         const int64_t r0 = h.recv_ptr[k] * dofs, r1 = h.recv_ptr[k + 1] * dofs;
-        if (s1 > s0) ncclSend(h.d_send_buf.p + s0, (size_t)(s1 - s0), ncclDouble, h.peers[k], comm, c->stream);
-        if (r1 > r0) ncclRecv(h.d_recv_buf.p + r0, (size_t)(r1 - r0), ncclDouble, h.peers[k], comm, c->stream);
+        if (s1 > s0) bad = ncclSend(h.d_send_buf.p + s0, (size_t)(s1 - s0), ncclDouble, h.peers[k], comm, c->stream);
+        if (r1 > r0 && bad == ncclSuccess)
+            bad = ncclRecv(h.d_recv_buf.p + r0, (size_t)(r1 - r0), ncclDouble, h.peers[k], comm, c->stream);
     }
-    ncclResult_t r = ncclGroupEnd();
+    const ncclResult_t r = ncclGroupEnd();
+    FEDD_CHECK(bad == ncclSuccess, "halo import: %s", ncclGetErrorString(bad));
     FEDD_CHECK(r == ncclSuccess, "halo import: %s", ncclGetErrorString(r));
     if (nr > 0)
         hipLaunchKernelGGL(k_unpack, dim3((unsigned)((nr * dofs + 255) / 256)), dim3(256), 0, c->stream, d_xcol,
@@ -88,7 +92,7 @@ extern "C" int fedd_halo_set_owners(fedd_ctx* c, int64_t n_rep, const int64_t* g
     FEDD_CHECK(c && c->n_node > 0, "fedd_halo_set_owners: call fedd_mesh_set first");
     FEDD_CHECK(n_rep == 0 || (gid_rep && owner_rep), "fedd_halo_set_owners: null array");
     HaloPlan& h = c->halo;
-    h = HaloPlan();
+    h.reset();
     const int64_t ng = c->n_node - c->n_own;
     std::unordered_map<int64_t, int32_t> ghost;  // gid -> ghost node id
     ghost.reserve((size_t)ng * 2);
@@ -212,15 +216,16 @@ extern "C" int fedd_halo_exchange_setup(fedd_ctx* c) {
     FEDD_TRY(d_in.ensure((size_t)nin));
     if (!h.req_gid.empty())
         FEDD_HIP(hipMemcpy(d_req.p, h.req_gid.data(), h.req_gid.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    ncclGroupStart();
+    ncclResult_t bad = ncclGroupStart();
     int64_t so = 0, ro = 0;
-    for (int p = 0; p < R; ++p) {
-        if (h.req_count[p] > 0) ncclSend(d_req.p + so, (size_t)h.req_count[p], ncclInt64, p, comm, c->stream);
-        if (from[p] > 0) ncclRecv(d_in.p + ro, (size_t)from[p], ncclInt64, p, comm, c->stream);
+    for (int p = 0; p < R && bad == ncclSuccess; ++p) {
+        if (h.req_count[p] > 0) bad = ncclSend(d_req.p + so, (size_t)h.req_count[p], ncclInt64, p, comm, c->stream);
+        if (from[p] > 0 && bad == ncclSuccess) bad = ncclRecv(d_in.p + ro, (size_t)from[p], ncclInt64, p, comm, c->stream);
         so += h.req_count[p];
         ro += from[p];
     }
     r = ncclGroupEnd();
+    FEDD_CHECK(bad == ncclSuccess, "halo setup exchange: %s", ncclGetErrorString(bad));
     FEDD_CHECK(r == ncclSuccess, "halo setup exchange: %s", ncclGetErrorString(r));
     std::vector<int64_t> in((size_t)nin);
     if (nin) FEDD_HIP(hipMemcpyAsync(in.data(), d_in.p, (size_t)nin * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));

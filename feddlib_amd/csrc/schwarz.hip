@@ -194,6 +194,13 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
                     const int32_t col = colind[p];
                     if (col < n_rows && node_bin[col] == b) continue;
                     if (!ghost_overlap && col >= n_rows) continue;  // another rank's dof: its row is not stored here
+                    // With row ghosts only they are imported by the halo exchange: a plain ghost beyond them has
+                    // neither a stored row nor a defined entry in the work vectors, so it never joins a subdomain
+                    // (overlap deeper than the mesh's row-ghost layers).  The whole-box attempt is given up instead.
+                    if (n_stored > n_rows && col >= n_stored) {
+                        if (nf > 0) s_bad = 1;
+                        continue;
+                    }
                     insert(col);
                 }
             }
@@ -732,6 +739,8 @@ int global_box(fedd_ctx* c, int64_t n_own, double lo[3], double hi[3], double* n
     FEDD_HIP(hipStreamSynchronize(c->stream));
     *n_global = 0.0;
     for (int r = 0; r < nr; ++r) {
+        // every rank sees every rank's count: all of them give up together
+        FEDD_CHECK(h[(size_t)r * 7 + 6] > 0.0, "rank %d owns no nodes", r);
         for (int d = 0; d < 3; ++d) {
             lo[d] = std::min(lo[d], h[(size_t)r * 7 + d]);
             hi[d] = std::max(hi[d], h[(size_t)r * 7 + 3 + d]);
@@ -748,7 +757,9 @@ int schwarz_setup(fedd_ctx* c) {
     const int dim = c->dim, dofs = c->dofs;
     const int32_t n_rows = (int32_t)c->n_rows;
     const int32_t n_stored = (int32_t)c->n_rows_ext;   // rows the local matrices can read (owned + row ghosts)
-    FEDD_CHECK(n_own > 0, "schwarz setup: no owned nodes");
+    // (a failed check ahead of a collective would leave the other ranks waiting in it: with several ranks the
+    // rank-local conditions are tested after the first all-reduce, on numbers every rank has)
+    FEDD_CHECK(n_own > 0 || c->nranks > 1, "schwarz setup: no owned nodes");
     // ---- bounding box and number of the owned nodes: of all ranks, so that the lattice of boxes is the
     // one a single rank would lay over the whole mesh and a rank boundary only cuts the boxes it crosses
     // (box_kind 1: each rank's own bounding box; costs iterations) ----
@@ -958,6 +969,15 @@ int schwarz_setup(fedd_ctx* c) {
     int32_t bad = 0;
     FEDD_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     FEDD_HIP(hipStreamSynchronize(c->stream));
+    if (c->nranks > 1) {   // one rank's failure is every rank's: nobody is left waiting in the next collective
+        double flag = bad ? 1.0 : 0.0;
+        FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>(1, c->d_dtmp0.cap)));
+        FEDD_HIP(hipMemcpyAsync(c->d_dtmp0.p, &flag, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        FEDD_TRY(allreduce_sum(c, c->d_dtmp0.p, 1));
+        FEDD_HIP(hipMemcpyAsync(&flag, c->d_dtmp0.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        bad = flag > 0.0;
+    }
     FEDD_CHECK(!bad, "schwarz setup: zero pivot in a local factorisation (matrix singular on a subdomain)");
     if (c->sw_combine == FEDD_COMBINE_AVERAGING) {
         FEDD_TRY(c->d_mult.ensure((size_t)c->n_cols));

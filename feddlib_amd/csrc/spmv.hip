@@ -156,7 +156,167 @@ __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ ro
     }
 }
 
+// ---- compacted stream: the owned rows without their exact zeros ------------------------------------------------
+// Same windows as the SpMV itself: workgroup b owns the rows whose first entry lies in window b of the parity CSR,
+// i.e. the contiguous entry range [rowptr[R0], rowptr[R1]).  Pass 1 counts its nonzero values, a scan over the
+// windows gives each its offset in the compacted stream, pass 2 compacts the range through an LDS prefix sum
+// (coalesced loads and stores) and writes the new row starts.  ~3.8 GB of traffic for the 214^3 grid, once per
+// assembled matrix, against ~0.96 GB saved in every SpMV.
+constexpr int CS_OVH = 256;   // windowed SpMV is only used for rows of at most 256 entries
+
+__global__ __launch_bounds__(256) void k_cs_count(const int32_t* __restrict__ rowptr, const double* __restrict__ val,
+                                                  const int32_t* __restrict__ block_row, int32_t nb,
+                                                  int32_t* __restrict__ wincnt) {
+    __shared__ int32_t red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int32_t R0 = block_row[b], R1 = block_row[b + 1];
+    int32_t cnt = 0;
+    if (R0 < R1) {
+        const int32_t lo = rowptr[R0], hi = rowptr[R1];
+        for (int32_t p = lo + tid; p < hi; p += 256) cnt += __builtin_nontemporal_load(val + p) != 0.0 ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) wincnt[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_cs_fill(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                                 const double* __restrict__ val, const int32_t* __restrict__ block_row,
+                                                 const int32_t* __restrict__ winoff, int32_t* __restrict__ cs_rowptr,
+                                                 int32_t* __restrict__ cs_col, double* __restrict__ cs_val) {
+    __shared__ double sval[SP_CHUNK + CS_OVH];
+    __shared__ int32_t pre[SP_CHUNK + CS_OVH + 1];
+    __shared__ int32_t wsum[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int32_t R0 = block_row[b], R1 = block_row[b + 1];
+    if (R0 >= R1) return;
+    const int32_t lo = rowptr[R0], hi = rowptr[R1], len = hi - lo;   // len <= SP_CHUNK + max_row_nnz - 1
+    const int32_t wbase = winoff[b];
+    for (int32_t j = tid; j < len; j += 256) sval[j] = __builtin_nontemporal_load(val + lo + j);
+    __syncthreads();
+    // exclusive prefix of the nonzero flags: lane t takes the K consecutive positions [t K, t K + K)
+    const int K = (len + 255) / 256;
+    int32_t mine = 0;
+    for (int k = 0; k < K; ++k) {
+        const int32_t j = tid * K + k;
+        mine += (j < len && sval[j] != 0.0) ? 1 : 0;
+    }
+    int32_t inc = mine;   // inclusive scan inside the wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t up = __shfl_up(inc, off, 64);
+        if ((tid & 63) >= off) inc += up;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    int32_t run = inc - mine;
+    for (int w = 0; w < (tid >> 6); ++w) run += wsum[w];
+    for (int k = 0; k < K; ++k) {
+        const int32_t j = tid * K + k;
+        if (j < len) {
+            pre[j] = run;
+            run += sval[j] != 0.0 ? 1 : 0;
+        }
+    }
+    if (tid == 255) pre[len] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    for (int32_t j = tid; j < len; j += 256) {
+        const double v = sval[j];
+        if (v != 0.0) {
+            cs_val[wbase + pre[j]] = v;
+            cs_col[wbase + pre[j]] = __builtin_nontemporal_load(colind + lo + j);
+        }
+    }
+    for (int32_t r = R0 + tid; r < R1; r += 256) cs_rowptr[r] = wbase + pre[rowptr[r] - lo];
+}
+
+// Read-only streaming calibration (fedd_read_bandwidth): sums `n2` double2 with 16-byte loads, four independent
+// loads per lane in flight, grid-stride.  What the box's HBM delivers to a pure read stream; the byte models of
+// SpMV / Schwarz apply are quoted against the 8 TB/s spec AND against this.
+typedef double vd2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_read_stream(const vd2* __restrict__ p, size_t n2, double* out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    double s = 0.0;
+    for (; i + 3 * stride < n2; i += 4 * stride) {
+        const vd2 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride),
+                  c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
+        s += a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y;
+    }
+    for (; i < n2; i += stride) s += p[i].x + p[i].y;
+    if (s == 12345.678) out[0] = s;
+}
+
 }  // namespace
+
+int read_bandwidth(fedd_ctx* c, int64_t bytes, int reps, double* gbs) {
+    DevBuf<double> buf, out;
+    const size_t n = (size_t)bytes / 8;
+    FEDD_TRY(buf.ensure(n));
+    FEDD_TRY(out.ensure(1));
+    FEDD_HIP(hipMemsetAsync(buf.p, 0, n * 8, c->stream));
+    hipEvent_t a, b;
+    FEDD_HIP(hipEventCreate(&a));
+    FEDD_HIP(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int pass = 0; pass < 3; ++pass) {   // best of three batches (the first one also warms up)
+        FEDD_HIP(hipEventRecord(a, c->stream));
+        for (int k = 0; k < reps; ++k)
+            hipLaunchKernelGGL(k_read_stream, dim3(8192), dim3(256), 0, c->stream, (const vd2*)buf.p, n / 2, out.p);
+        FEDD_HIP(hipEventRecord(b, c->stream));
+        FEDD_HIP(hipEventSynchronize(b));
+        float ms = 0.f;
+        FEDD_HIP(hipEventElapsedTime(&ms, a, b));
+        best = std::min(best, ms);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *gbs = (double)(n * 8) * reps / ((double)best * 1e6);
+    return 0;
+}
+
+// window -> first row table of the parity CSR (one-off per pattern)
+static int spmv_window_rows(fedd_ctx* c) {
+    const int32_t nb = (int32_t)(c->nnz / SP_CHUNK + 1);
+    if (!c->spmv_rows_ready) {
+        FEDD_TRY(c->d_spmv_rows.ensure((size_t)nb + 1));
+        hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, c->stream,
+                           (const int32_t*)c->d_rowptr.p, (int32_t)c->n_rows, nb, c->d_spmv_rows.p);
+        c->spmv_rows_ready = true;
+    }
+    return 0;
+}
+
+// (re)build the compacted stream after the matrix changed; part of the solver's first SpMV
+static int spmv_compact_build(fedd_ctx* c) {
+    const int32_t n = (int32_t)c->n_rows;
+    const int32_t nb = (int32_t)(c->nnz / SP_CHUNK + 1);
+    FEDD_TRY(spmv_window_rows(c));
+    ScopedTimer ts(c, FEDD_T_SPMV_SETUP);
+    FEDD_TRY(c->d_cs_wincnt.ensure((size_t)nb + 1));
+    hipLaunchKernelGGL(k_cs_count, dim3((unsigned)nb), dim3(256), 0, c->stream, (const int32_t*)c->d_rowptr.p,
+                       (const double*)c->d_val.p, (const int32_t*)c->d_spmv_rows.p, nb, c->d_cs_wincnt.p);
+    int64_t total = 0;
+    FEDD_TRY(exclusive_scan_i32(c, c->d_cs_wincnt.p, c->d_cs_wincnt.p, nb, &total));
+    c->cs_nnz = total;
+    FEDD_TRY(c->d_cs_rowptr.ensure((size_t)n + 1));
+    FEDD_TRY(c->d_cs_col.ensure((size_t)total + 1));
+    FEDD_TRY(c->d_cs_val.ensure((size_t)total + 1));
+    hipLaunchKernelGGL(k_cs_fill, dim3((unsigned)nb), dim3(256), 0, c->stream, (const int32_t*)c->d_rowptr.p,
+                       (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, (const int32_t*)c->d_spmv_rows.p,
+                       (const int32_t*)c->d_cs_wincnt.p, c->d_cs_rowptr.p, c->d_cs_col.p, c->d_cs_val.p);
+    const int32_t tot32 = (int32_t)total;
+    FEDD_HIP(hipMemcpyAsync(c->d_cs_rowptr.p + n, &tot32, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    const int32_t nbc = (int32_t)(total / SP_CHUNK + 1);
+    FEDD_TRY(c->d_cs_rows.ensure((size_t)nbc + 1));
+    hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nbc + 1 + 255) / 256)), dim3(256), 0, c->stream,
+                       (const int32_t*)c->d_cs_rowptr.p, n, nbc, c->d_cs_rows.p);
+    FEDD_HIP(hipStreamSynchronize(c->stream));   // tot32 lives on this stack frame
+    ts.stop();
+    FEDD_HIP(hipGetLastError());
+    c->cs_valid = true;
+    return 0;
+}
 
 int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_has_tail) {
     const double* x = d_x_owned;
@@ -175,14 +335,31 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
     // very long rows), 1 = row-per-lane-group, 2 = CSR-stream
     const bool windowed = c->spmv_kind == 0 && c->max_row_nnz <= 256 && c->nnz > 0;
     const bool streamed = !windowed && (c->spmv_kind == 0 || c->spmv_kind == 2) && avg <= 64.0 && c->max_row_nnz <= 2048;
+    if (windowed && c->spmv_compact) {
+        // the compacted stream (exact zeros left out): same kernel, fewer bytes, same y for finite x
+        if (!c->cs_valid) FEDD_TRY(spmv_compact_build(c));
+        const int32_t nbc = (int32_t)(c->cs_nnz / SP_CHUNK + 1);
+        const int32_t ovh = (int32_t)std::max<int64_t>(c->max_row_nnz, 1);
+        const size_t lds = (size_t)(SP_CHUNK + ovh) * sizeof(double);
+        const bool nt = c->spmv_nt < 0 ? 12.0 * (double)c->cs_nnz > 256.0 * 1024.0 * 1024.0 : c->spmv_nt != 0;
+        ScopedTimer ts(c, FEDD_T_SPMV);
+        if (c->cs_nnz == 0)
+            FEDD_HIP(hipMemsetAsync(d_y_owned, 0, (size_t)n * sizeof(double), c->stream));
+        else if (nt)
+            hipLaunchKernelGGL(k_spmv_win<true>, dim3((unsigned)nbc), dim3(256), lds, c->stream, (const int32_t*)c->d_cs_rowptr.p,
+                               (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, x, d_y_owned,
+                               (const int32_t*)c->d_cs_rows.p, nbc, (int32_t)c->cs_nnz, ovh);
+        else
+            hipLaunchKernelGGL(k_spmv_win<false>, dim3((unsigned)nbc), dim3(256), lds, c->stream, (const int32_t*)c->d_cs_rowptr.p,
+                               (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, x, d_y_owned,
+                               (const int32_t*)c->d_cs_rows.p, nbc, (int32_t)c->cs_nnz, ovh);
+        ts.stop();
+        FEDD_HIP(hipGetLastError());
+        return 0;
+    }
     if (windowed || streamed) {
         const int32_t nb = (int32_t)(c->nnz / SP_CHUNK + 1);
-        if (!c->spmv_rows_ready) {  // one-off per pattern: window -> first row table
-            FEDD_TRY(c->d_spmv_rows.ensure((size_t)nb + 1));
-            hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, c->stream,
-                               (const int32_t*)c->d_rowptr.p, n, nb, c->d_spmv_rows.p);
-            c->spmv_rows_ready = true;
-        }
+        FEDD_TRY(spmv_window_rows(c));
         const int32_t ovh = (int32_t)std::max<int64_t>(c->max_row_nnz, 1);
         const size_t lds = (size_t)(SP_CHUNK + ovh) * sizeof(double);
         ScopedTimer ts(c, FEDD_T_SPMV);

@@ -167,6 +167,7 @@ int build_adjacency(fedd_ctx* c) {
 }
 
 int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
+    c->cs_valid = false;   // the solver's compacted SpMV stream follows the matrix values
     const int32_t n_own = (int32_t)(c->n_own + c->n_rowg);   // every node that gets rows (owned, then row ghosts)
     const int nen = c->nen;
     // upper bound for the distinct columns of one node row

@@ -60,7 +60,8 @@ enum fedd_timer {
     FEDD_T_COARSE_APPLY = 9,  /* second level: restrict, K0^-1, prolongate      */
     FEDD_T_HALO     = 10, /* ghost import: pack, send / receive, unpack (several ranks)  */
     FEDD_T_ALLREDUCE= 11, /* all-reduce calls (inside the classes that issue them)        */
-    FEDD_T_COUNT    = 12
+    FEDD_T_SPMV_SETUP = 12, /* compaction of the solver's SpMV stream (once per assembled matrix) */
+    FEDD_T_COUNT    = 13
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -207,6 +208,9 @@ int fedd_solution_get(fedd_ctx* ctx, double* x_owned);
  * host pointers; fedd_spmv_device runs `reps` launches on the resident vectors (bench). */
 int fedd_spmv(fedd_ctx* ctx, const double* x_owned, double* y_owned);
 int fedd_spmv_device(fedd_ctx* ctx, int reps);
+/* what the SpMV streams: nnz of the parity CSR (owned rows), nnz of the compacted stream actually read
+ * (= nnz_pattern with "spmv_compact" 0 or when the windowed kernel is not in use) */
+int fedd_spmv_info(fedd_ctx* ctx, int64_t* nnz_pattern, int64_t* nnz_streamed);
 
 /* one-level overlapping additive Schwarz (replaces Thyra::initializePrec on the FROSch factory,
  * feddlib/problems/Solver/Preconditioner_def.hpp:243-463; options from
@@ -250,6 +254,9 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
  * "spmv_nt" 1 = the window SpMV streams the matrix non-temporally (x then survives in L2 between node planes:
  * -6 % back to back on a 1.8 GB matrix, 0 to -4 % inside the solver, slower on matrices that fit the Infinity
  * Cache), 0 = never, -1 (default) = for matrices larger than the Infinity Cache;
+ * "spmv_compact" 1 (default) = SpMV streams a solver-private copy of the owned rows without the entries that are exactly
+ * 0.0 (the structural zeros kept for pattern parity, the zeroed entries of Dirichlet rows): fewer bytes, y identical bit
+ * for bit for finite x; fedd_csr_get always returns the reference pattern; 0 = stream the parity CSR itself;
  * "whole_boxes" 1 (default) = with row ghosts, a box that a rank boundary crosses is built whole (with its full
  * overlap) on every rank that owns a part of it wherever the stored rows reach, 0 = each rank takes its part. */
 int fedd_set_option(fedd_ctx* ctx, const char* key, double value);
@@ -261,6 +268,11 @@ int fedd_set_option(fedd_ctx* ctx, const char* key, double value);
 int fedd_timing_enable(fedd_ctx* ctx, int on);
 int fedd_timing_reset(fedd_ctx* ctx);
 int fedd_timing_get(fedd_ctx* ctx, int timer, double* total_ms, int64_t* launches);
+/* calibration for the roofline figures: GB/s of a read-only stream over a scratch buffer of `bytes` (16-byte
+ * non-temporal loads, `reps` launches back to back, best of three batches) on this GPU, i.e. the ceiling that
+ * the measured fractions of the 8 TB/s spec can be compared with ("of spec" and "of
+ * measured") */
+int fedd_read_bandwidth(fedd_ctx* ctx, int64_t bytes, int reps, double* gb_per_s);
 
 /* multi-GPU: exchange plan for the owned/ghost split (import of ghost x / r entries before SpMV
  * and Schwarz -- the Tpetra Import behind Matrix::apply, Matrix_def.hpp:245-254; GMRES dots are

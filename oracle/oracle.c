@@ -316,7 +316,9 @@ static void multidot(const double* V, const double* w, int64_t n, int ncols, dou
 }
 
 /* right-preconditioned GMRES(m), CGS + DGKS second pass, Givens; returns iterations */
+static double g_t_op = 0.0, g_t_ortho = 0.0;   /* seconds inside the operator (RAS + SpMV) / inside Gram-Schmidt of the last gmres() */
 static int gmres(const Problem* P, const Ras* R, const double* b, double* x, double rtol, int max_it, int restart, double* relres_out) {
+    g_t_op = g_t_ortho = 0.0;
     const int64_t n = P->n; const int m = restart < max_it ? restart : max_it;
     double* V = (double*)malloc((size_t)(m + 1) * n * sizeof(double));
     double* w = (double*)malloc((size_t)n * sizeof(double)), *z = (double*)malloc((size_t)n * sizeof(double)), *r = (double*)malloc((size_t)n * sizeof(double));
@@ -331,7 +333,9 @@ static int gmres(const Problem* P, const Ras* R, const double* b, double* x, dou
         memset(g, 0, (size_t)(m + 1) * sizeof(double)); g[0] = beta; int k = 0;
         for (int j = 0; j < m && its < max_it; ++j) {
             const double* vj = V + (size_t)j * n;
+            double tt = now();
             if (R) { ras_apply(R, vj, z); spmv(P, z, w); } else spmv(P, vj, w);
+            g_t_op += now() - tt; tt = now();
             const double n0 = dot(w, w, n);
             multidot(V, w, n, j + 1, h);
             #pragma omp parallel for schedule(static)
@@ -344,6 +348,7 @@ static int gmres(const Problem* P, const Ras* R, const double* b, double* x, dou
                 for (int c = 0; c <= j; ++c) h[c] += h2[c];
                 n1 = dot(w, w, n);
             }
+            g_t_ortho += now() - tt;
             const double hn = sqrt(n1); double* Hj = H + (size_t)j * (m + 1);
             for (int c = 0; c <= j; ++c) Hj[c] = h[c];
             Hj[j + 1] = hn;
@@ -372,7 +377,7 @@ static int gmres(const Problem* P, const Ras* R, const double* b, double* x, dou
 }
 
 /* whole driver: feddlib/problems/tests/laplace/main.cpp:199-208 with 3D / P1 / structured / H/h = M.
- * times[0..4] = mesh, assemble, bc, prec setup, gmres (seconds).  x (nullable) [(M+1)^3].
+ * times[0..6] = mesh, assemble, bc, prec setup, gmres, of which operator, of which Gram-Schmidt (seconds).  x (nullable) [(M+1)^3].
  * csr outputs (nullable): rowptr[n+1], col[nnz], val[nnz] of the Dirichlet-modified matrix; rhs[n]. */
 int oracle_laplace3d(int M, int target, double rtol, int restart, int max_it, int use_prec, double* times, int* its,
                      double* relres, int* threads, int64_t* nnz_out, int64_t* nsub_out, int* max_n_out, double* x,
@@ -389,6 +394,7 @@ int oracle_laplace3d(int M, int target, double rtol, int restart, int max_it, in
     t0 = now();
     *its = gmres(&P, use_prec ? &R : NULL, P.rhs, xs, rtol, max_it, restart, relres);
     times[4] = now() - t0;
+    times[5] = g_t_op; times[6] = g_t_ortho;   /* split of times[4]: operator applications / Gram-Schmidt (the rest: basis scaling, update of x) */
 #ifdef _OPENMP
     *threads = omp_get_max_threads();
 #else

@@ -78,7 +78,7 @@ def run_laplace3d(M, target=27, rtol=1e-8, restart=100, max_it=2000, use_prec=Tr
                        p(col, C.POINTER(C.c_int32)), p(val, dp), p(rhs, dp))
     out = dict(dofs=n, its=its.value, relres=rel.value, threads=thr.value, nnz=nnz.value, n_subdomains=nsub.value,
                max_size=maxn.value, t_mesh=times[0], t_assemble=times[1], t_bc=times[2], t_prec=times[3],
-               t_gmres=times[4], seconds=float(times[1] + times[2] + times[3] + times[4]))
+               t_gmres=times[4], t_gmres_operator=times[5], t_gmres_ortho=times[6], seconds=float(times[1] + times[2] + times[3] + times[4]))
     if want_system:
         out.update(x=x, rowptr=rowptr, col=col[:nnz.value], val=val[:nnz.value], rhs=rhs)
     return out

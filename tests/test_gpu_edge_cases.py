@@ -193,6 +193,24 @@ def test_spmv_kernels_agree(fedd_lib, ctx, dim, M):
     finally:
         ctx.set_option("spmv_kind", 0)
     assert np.array_equal(ys[0], ys[2])
+    # the solver-private compacted stream (exact zeros dropped: structural zeros of the Kuhn pattern, the zeroed
+    # entries of Dirichlet rows) gives the same y bit for bit as the parity CSR, and fedd_csr_get still returns
+    # the reference pattern
+    info = ctx.spmv_info()
+    rowptr, col, val, _ = ctx.csr_get()
+    assert info["nnz_pattern"] == val.shape[0] == A_bc.nnz
+    assert info["nnz_streamed"] == np.count_nonzero(val) < info["nnz_pattern"]
+    try:
+        ctx.set_option("spmv_compact", 0)
+        y_parity = ctx.spmv(x)
+        assert ctx.spmv_info()["nnz_streamed"] == info["nnz_pattern"]
+    finally:
+        ctx.set_option("spmv_compact", 1)
+    assert np.array_equal(ys[0], y_parity)
+    # ... and follows the matrix when it changes (scale, then a new Dirichlet row)
+    ctx.matrix_scale(-1, -2.5)
+    np.testing.assert_allclose(ctx.spmv(x), -2.5 * yo, rtol=0, atol=1e-12 * np.abs(yo).max())
+    ctx.matrix_scale(-1, -0.4)
 
 
 def test_box_lattice_refines_itself_when_a_subdomain_would_exceed_the_dense_solver(fedd_lib, ctx):

@@ -253,6 +253,108 @@ def test_full_size_properties(fedd_lib, ctx):
     assert abs(x[c] - 0.05621) < 2e-4
 
 
+def test_full_size_properties_cfg3(fedd_lib):
+    """The headline grid itself (BASELINE cfg 3: 214^3 cells, 9 938 375 dofs, whole on one GPU): no oracle run at
+    this size, so size-independent properties -- the reference's nnz, zero row sums and symmetry before the
+    boundary conditions, the 7-point stencil with its 8 structural zeros, rhs = volume, and after the one-level
+    solve the TRUE residual ||b - A x|| / ||b|| formed on the host from the returned CSR."""
+    M = 214
+    c = fedd_lib.Context(device=0)
+    try:
+        m = fedd_lib.structured_mesh(3, 1, M)
+        assert m["n_global"] == 9938375 and m["conn"].shape[0] == 58802064      # SURVEY 8d
+        c.mesh_set_dict(m)
+        del m
+        assert c.pattern_build(1, fedd_lib.BLOCK_SCALAR) == 147968803
+        c.assemble(fedd_lib.FORM_LAPLACE)
+        c.assemble_rhs([1.0])
+        rowptr, col, val, gid = c.csr_get()
+        n = rowptr.shape[0] - 1
+        A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+        h = 1.0 / M
+        assert np.abs(A @ np.ones(n)).max() < 1e-12 * 6 * h
+        x = np.sin(1e-3 * np.arange(n)) + 0.25
+        assert np.abs(A @ x - A.T @ x).max() < 1e-13 * 12 * h * np.abs(x).max()      # symmetry, applied
+        P = M + 1
+        ctr = 107 + 107 * P + 107 * P * P
+        row = A[ctr].toarray().ravel()
+        assert A[ctr].nnz == 15 and np.count_nonzero(row) == 7
+        np.testing.assert_allclose(row[ctr], 6 * h, rtol=1e-12)
+        for off in (1, P, P * P):
+            np.testing.assert_allclose([row[ctr - off], row[ctr + off]], [-h, -h], rtol=1e-12)
+        rhs = c.rhs_get()
+        np.testing.assert_allclose(rhs.sum(), 1.0, rtol=1e-12)
+        del A, row
+        c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+        c.schwarz_set_target(27, 1.0)
+        c.schwarz_setup(overlap=1, combine=fedd_lib.COMBINE_RESTRICTED)
+        xs, its, rel = c.gmres(None, rtol=1e-8, max_it=2000, restart=100, use_prec=True)
+        assert rel <= 1e-8
+        rowptr, col, val, gid = c.csr_get()
+        Abc = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+        b = c.rhs_get()
+        true_rel = np.linalg.norm(b - Abc @ xs) / np.linalg.norm(b)
+        assert true_rel <= 1e-7, true_rel
+        # device SpMV (compacted stream) against the host product of the returned parity CSR, full size
+        y = c.spmv(x)
+        yh = Abc @ x
+        assert np.abs(y - yh).max() <= 1e-13 * np.abs(yh).max()
+        info = c.spmv_info()
+        assert info["nnz_pattern"] == 147968803 and info["nnz_streamed"] == np.count_nonzero(val)
+        assert abs(xs[ctr] - 0.05621) < 1e-4          # centre value of -lap u = 1 on the unit cube
+    finally:
+        c.close()
+
+
+def test_full_size_properties_cfg5_share(fedd_lib):
+    """cfg 5's per-GPU share (3D P1 linear elasticity, 94^3 cells, 2 572 125 dofs, steadyLinElas_Perf parameters:
+    mu = 2e6, nu = 0.4, f = (0, 1, 0), Dirichlet on flag 2; FULL 3 x 3 node blocks): before the boundary
+    conditions K annihilates the six rigid-body modes and is symmetric; the two-level solve reaches the
+    XML's tolerance in the TRUE residual."""
+    M = 94
+    c = fedd_lib.Context(device=0)
+    try:
+        m = fedd_lib.structured_mesh(3, 1, M)
+        xyz = m["xyz"].copy()
+        c.mesh_set_dict(m)
+        del m
+        nnz = c.pattern_build(3, fedd_lib.BLOCK_FULL)
+        mu, nu = 2.0e6, 0.4
+        lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
+        c.assemble(fedd_lib.FORM_LINELAS, [lam, mu])
+        c.assemble_rhs([0.0, 1.0, 0.0])
+        rowptr, col, val, gid = c.csr_get()
+        n = rowptr.shape[0] - 1
+        assert n == 3 * 95 ** 3 and nnz == val.shape[0]
+        K = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+        scale = abs(K).max()
+        modes = []
+        for d in range(3):
+            t = np.zeros((n // 3, 3)); t[:, d] = 1.0
+            modes.append(t.ravel())
+        for a, b in ((0, 1), (1, 2), (0, 2)):
+            r = np.zeros((n // 3, 3)); r[:, a] = -xyz[:, b]; r[:, b] = xyz[:, a]
+            modes.append(r.ravel())
+        for v in modes:
+            assert np.abs(K @ v).max() <= 1e-11 * scale
+        x = np.cos(1e-3 * np.arange(n))
+        assert np.abs(K @ x - K.T @ x).max() <= 1e-12 * scale * 81
+        rhs = c.rhs_get().reshape(-1, 3)
+        np.testing.assert_allclose(rhs.sum(axis=0), [0.0, 1.0, 0.0], atol=1e-12)
+        del K
+        c.dirichlet([2], [0.0, 0.0, 0.0])
+        c.schwarz_setup(overlap=1, combine=fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
+        xs, its, rel = c.gmres(None, rtol=1e-6, max_it=1000, restart=100, use_prec=True)
+        assert rel <= 1e-6 and its < 200
+        rowptr, col, val, gid = c.csr_get()
+        Kbc = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+        b = c.rhs_get()
+        true_rel = np.linalg.norm(b - Kbc @ xs) / np.linalg.norm(b)
+        assert true_rel <= 1e-5, true_rel
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("dim,M,target", [(3, 6, 8), (2, 12, 9)])
 def test_linear_elasticity_solve(fedd_lib, ctx, dim, M, target):
     """steadyLinElas_Perf sequence (LinElas_def.hpp:64-99; parameters steadyLinElas_Perf/parametersProblem.xml:5-11):
