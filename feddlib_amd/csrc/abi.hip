@@ -624,7 +624,11 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "box_kind") c->box_kind = (int)value;
     else if (k == "asm_lds_kb") c->asm_lds_kb = std::max(2, (int)value);
     else if (k == "spmv_nt") c->spmv_nt = (int)value;
-    else if (k == "spmv_compact") {
+    else if (k == "spmv_drop_tol") {
+        FEDD_CHECK(value >= 0.0 && value < 1.0, "fedd_set_option: spmv_drop_tol %g", value);
+        c->spmv_drop_tol = value;
+        c->cs_valid = false;
+    } else if (k == "spmv_compact") {
         c->spmv_compact = (int)value;
         c->cs_valid = false;
     }

@@ -181,8 +181,10 @@ struct fedd_ctx {
     // zeros the reference's insertGlobalValues keeps in the pattern, and the zeroed entries of Dirichlet rows).
     // fedd_csr_get keeps returning the reference pattern; SpMV streams this one (same y bit for bit for finite x).
     int spmv_compact = 1;                       // option "spmv_compact": 1 = on (default), 0 = stream the parity CSR
+    double spmv_drop_tol = 2.220446049250313e-16;   // option "spmv_drop_tol": drop |a_ij| <= tol * max_k |a_ik|; 0 = exact zeros only
     bool cs_valid = false;                      // false after anything that writes d_val / the pattern
     int64_t cs_nnz = 0;
+    int32_t cs_tot32 = 0;
     fedd::DevBuf<int32_t> d_cs_rowptr, d_cs_col, d_cs_rows, d_cs_wincnt;
     fedd::DevBuf<double> d_cs_val;
     fedd::DevCsr aux[fedd::MAX_AUX];            // stored blocks (A, B, B^T, C) of a mixed problem

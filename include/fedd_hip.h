@@ -254,9 +254,13 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
  * "spmv_nt" 1 = the window SpMV streams the matrix non-temporally (x then survives in L2 between node planes:
  * -6 % back to back on a 1.8 GB matrix, 0 to -4 % inside the solver, slower on matrices that fit the Infinity
  * Cache), 0 = never, -1 (default) = for matrices larger than the Infinity Cache;
- * "spmv_compact" 1 (default) = SpMV streams a solver-private copy of the owned rows without the entries that are exactly
- * 0.0 (the structural zeros kept for pattern parity, the zeroed entries of Dirichlet rows): fewer bytes, y identical bit
- * for bit for finite x; fedd_csr_get always returns the reference pattern; 0 = stream the parity CSR itself;
+ * "spmv_compact" 1 (default) = SpMV streams a solver-private copy of the owned rows without their numerically zero
+ * entries (the structural zeros kept for pattern parity, the zeroed entries of Dirichlet rows); fedd_csr_get always
+ * returns the reference pattern and values; 0 = stream the parity CSR itself;
+ * "spmv_drop_tol" (default 2^-52) = an entry is left out of that copy when |a_ij| <= tol * max_k |a_ik|: 0 drops the
+ * entries that are exactly 0.0 only (y then identical bit for bit, for finite x, to the product with the parity CSR), the
+ * default also drops cancellation noise below one ulp of the row's largest entry (cf. the reference's optional setZeros_
+ * threshold, FE_def.hpp:719-721), which changes y by less than the rounding error of the row sum;
  * "whole_boxes" 1 (default) = with row ghosts, a box that a rank boundary crosses is built whole (with its full
  * overlap) on every rank that owns a part of it wherever the stored rows reach, 0 = each rank takes its part. */
 int fedd_set_option(fedd_ctx* ctx, const char* key, double value);

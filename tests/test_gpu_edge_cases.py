@@ -192,22 +192,33 @@ def test_spmv_kernels_agree(fedd_lib, ctx, dim, M):
             np.testing.assert_allclose(ys[kind], yo, rtol=0, atol=1e-13 * np.abs(yo).max())
     finally:
         ctx.set_option("spmv_kind", 0)
-    assert np.array_equal(ys[0], ys[2])
-    # the solver-private compacted stream (exact zeros dropped: structural zeros of the Kuhn pattern, the zeroed
-    # entries of Dirichlet rows) gives the same y bit for bit as the parity CSR, and fedd_csr_get still returns
-    # the reference pattern
-    info = ctx.spmv_info()
+    # The default kernel streams a solver-private compacted copy of the rows; fedd_csr_get still returns the
+    # reference pattern and values.
     rowptr, col, val, _ = ctx.csr_get()
+    n = rowptr.shape[0] - 1
+    row_of = np.repeat(np.arange(n), np.diff(rowptr))
+    rowmax = np.zeros(n)
+    np.maximum.at(rowmax, row_of, np.abs(val))
+    info = ctx.spmv_info()
     assert info["nnz_pattern"] == val.shape[0] == A_bc.nnz
-    assert info["nnz_streamed"] == np.count_nonzero(val) < info["nnz_pattern"]
+    # default: entries below one ulp of their row's largest entry are left out (exact zeros and cancellation noise)
+    assert info["nnz_streamed"] == np.count_nonzero(np.abs(val) > 2.0 ** -52 * rowmax[row_of]) < info["nnz_pattern"]
     try:
+        # tolerance 0: exactly the entries that are 0.0 are left out, and y is bit for bit the y of the parity CSR
+        # (same products, same summation order: CSR-stream, kind 2, reads the parity CSR)
+        ctx.set_option("spmv_drop_tol", 0.0)
+        y_exact = ctx.spmv(x)
+        assert ctx.spmv_info()["nnz_streamed"] == np.count_nonzero(val)
+        assert np.array_equal(y_exact, ys[2])
         ctx.set_option("spmv_compact", 0)
-        y_parity = ctx.spmv(x)
+        assert np.array_equal(ctx.spmv(x), ys[2])
         assert ctx.spmv_info()["nnz_streamed"] == info["nnz_pattern"]
     finally:
         ctx.set_option("spmv_compact", 1)
-    assert np.array_equal(ys[0], y_parity)
-    # ... and follows the matrix when it changes (scale, then a new Dirichlet row)
+        ctx.set_option("spmv_drop_tol", 2.0 ** -52)
+    # what the default tolerance changes is below the rounding error of the row sums
+    assert np.abs(ys[0] - ys[2]).max() <= 2.0 ** -50 * np.abs(A_bc).max() * np.abs(x).max()
+    # the compacted copy follows the matrix when it changes
     ctx.matrix_scale(-1, -2.5)
     np.testing.assert_allclose(ctx.spmv(x), -2.5 * yo, rtol=0, atol=1e-12 * np.abs(yo).max())
     ctx.matrix_scale(-1, -0.4)

@@ -278,7 +278,8 @@ def test_full_size_properties_cfg3(fedd_lib):
         P = M + 1
         ctr = 107 + 107 * P + 107 * P * P
         row = A[ctr].toarray().ravel()
-        assert A[ctr].nnz == 15 and np.count_nonzero(row) == 7
+        # 15 pattern entries: the 7-point stencil plus 8 structural zeros (exact 0.0 or cancellation noise)
+        assert A[ctr].nnz == 15 and np.count_nonzero(np.abs(row) > 1e-12 * h) == 7
         np.testing.assert_allclose(row[ctr], 6 * h, rtol=1e-12)
         for off in (1, P, P * P):
             np.testing.assert_allclose([row[ctr - off], row[ctr + off]], [-h, -h], rtol=1e-12)
@@ -300,7 +301,10 @@ def test_full_size_properties_cfg3(fedd_lib):
         yh = Abc @ x
         assert np.abs(y - yh).max() <= 1e-13 * np.abs(yh).max()
         info = c.spmv_info()
-        assert info["nnz_pattern"] == 147968803 and info["nnz_streamed"] == np.count_nonzero(val)
+        assert info["nnz_pattern"] == 147968803
+        # streamed: 7 per free row (neighbours on the boundary included: BCBuilder leaves columns alone), 1 per Dirichlet row
+        n_dir = P ** 3 - (P - 2) ** 3
+        assert info["nnz_streamed"] == 7 * (P - 2) ** 3 + n_dir
         assert abs(xs[ctr] - 0.05621) < 1e-4          # centre value of -lap u = 1 on the unit cube
     finally:
         c.close()

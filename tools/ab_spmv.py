@@ -1,5 +1,5 @@
-"""A/B of the SpMV kernels (`spmv_kind`) on the structured 3D P1 Laplace matrix (development aid).
-usage: ab_spmv.py [cells per direction] [kinds ...]"""
+"""A/B of SpMV kernel variants on the structured 3D P1 Laplace matrix (development aid).
+usage: ab_spmv.py [cells per direction] [key=value,key=value ...]   (each argument = one configuration of options)"""
 import os
 import sys
 
@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from feddlib_amd import capi  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-kinds = [int(v) for v in sys.argv[2:]] or [0, 1, 2]
+configs = sys.argv[2:] or ["spmv_var=0"]
 m = capi.structured_mesh(3, 1, M)
 c = capi.Context(device=0)
 c.mesh_set_dict(m)
@@ -18,20 +18,26 @@ c.assemble(capi.FORM_LAPLACE)
 c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
 nr, _, nnz = c.csr_sizes()
 x = np.random.default_rng(0).standard_normal(nr)
-ys = {}
+ceiling = c.read_bandwidth(2 << 30, 10)
+print("read ceiling %.0f GB/s" % ceiling, flush=True)
+y0 = None
 c.timing_enable(True)
 for rep in range(2):
-    for kind in kinds:
-        c.set_option("spmv_kind", kind)
-        ys[kind] = c.spmv(x)
+    for cfg in configs:
+        for kv in cfg.split(","):
+            k, v = kv.split("=")
+            c.set_option(k, float(v))
+        y = c.spmv(x)
+        if y0 is None:
+            y0 = y
         c.spmv_device(5)
         c.timing_reset()
         c.spmv_device(50)
         c.sync()
         t = c.timing_get()["spmv"]
         ms = t[0] / t[1]
-        err = np.abs(ys[kind] - ys[kinds[0]]).max() / np.abs(ys[kinds[0]]).max()
-        print("M %d spmv_kind %d  %.2f us  %.0f GB/s  (%.3f of 8 TB/s)  diff vs kind %d: %.1e"
-              % (M, kind, ms * 1e3, (12.0 * nnz + 20.0 * nr) / ms / 1e6, (12.0 * nnz + 20.0 * nr) / ms / 8e9, kinds[0], err),
-              flush=True)
+        b = 12.0 * c.spmv_info()["nnz_streamed"] + 20.0 * nr
+        err = np.abs(y - y0).max() / np.abs(y0).max()
+        print("M %d %-40s %.2f us  %.0f GB/s streamed (%.3f of 8 TB/s, %.3f of ceiling)  diff vs first: %.1e"
+              % (M, cfg, ms * 1e3, b / ms / 1e6, b / ms / 8e9, b / ms / 1e6 / ceiling, err), flush=True)
 c.close()
