@@ -634,6 +634,8 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     }
     else if (k == "whole_boxes") c->whole_boxes = (int)value;
     else if (k == "asm_kind") c->asm_kind = (int)value;
+    else if (k == "asm_u") c->asm_u = (int)value;
+    else if (k == "asm_dbg") c->asm_dbg = (int)value;
     else if (k == "apply_kind") c->apply_kind = (int)value;
     else if (k == "inv_kind") c->inv_kind = (int)value;
     else if (k == "gmres_kind") c->gmres_kind = (int)value;

@@ -233,6 +233,158 @@ struct PairCfg {
     static constexpr int CPP = (FORM == F_LINELAS || FORM == F_DIV) ? NEN * DIM : (FORM == F_DIVT ? DIM + 1 : NEN);
 };
 
+// row `li` (component `comp`) of the element matrix of an element with nodes nd and vertex coordinates X:
+// CPP (column id, value) contributions
+template <int DIM, int NEN, int FORM>
+__device__ __forceinline__ void compute_pair(const AsmArgs& a, const double* __restrict__ s_w,
+                                             const double* __restrict__ s_phi, const double* __restrict__ s_dphi, int nq,
+                                             const int32_t (&nd)[NEN], const double (&X)[DIM + 1][DIM], int li, int comp,
+                                             int dofs, int32_t (&cols)[PairCfg<DIM, NEN, FORM>::CPP],
+                                             double (&vals)[PairCfg<DIM, NEN, FORM>::CPP]) {
+    if constexpr (FORM == F_MASS) {
+        const double absdet = fabs(affine_det<DIM>(X));
+#pragma unroll
+        for (int j = 0; j < NEN; ++j) {
+            double v = 0.0;
+            for (int q = 0; q < nq; ++q) v += s_w[q] * s_phi[q * NEN + li] * s_phi[q * NEN + j];
+            cols[j] = nd[j] * dofs + comp;
+            vals[j] = v * absdet;
+        }
+    } else {
+        // Quadrature loop outermost, the transformed gradient of the row's basis function once per point and that
+        // of each column function once per (point, column).  On P1 elements the gradients do not depend on the
+        // point: all of them are formed once.  (The kernel is bound by f64 issue: the earlier form re-derived both
+        // gradients inside the column loop, 345 f64 instructions per pair for P1 Laplace against ~130 now; the
+        // expressions and their order are unchanged, so are the bits.)
+        constexpr bool P1 = NEN == DIM + 1;
+        double Binv[DIM][DIM];
+        const double absdet = fabs(affine<DIM>(X, Binv));
+        double gi[DIM], G[P1 ? NEN : 1][DIM];
+        if constexpr (P1) {
+            grad_t<DIM, NEN>(s_dphi, 0, li, Binv, gi);
+#pragma unroll
+            for (int j = 0; j < NEN; ++j) grad_t<DIM, NEN>(s_dphi, 0, j, Binv, G[j]);
+        }
+        if constexpr (FORM == F_LAPLACE) {
+            double v[NEN];
+#pragma unroll
+            for (int j = 0; j < NEN; ++j) v[j] = 0.0;
+            for (int q = 0; q < nq; ++q) {
+                if constexpr (!P1) grad_t<DIM, NEN>(s_dphi, q, li, Binv, gi);
+                double wg[DIM];
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) wg[d] = s_w[q] * gi[d];
+#pragma unroll
+                for (int j = 0; j < NEN; ++j) {
+                    double gj[DIM];
+                    if constexpr (P1) {
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) gj[d] = G[j][d];
+                    } else {
+                        grad_t<DIM, NEN>(s_dphi, q, j, Binv, gj);
+                    }
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) v[j] += wg[d] * gj[d];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NEN; ++j) {
+                cols[j] = nd[j] * dofs + comp;
+                vals[j] = v[j] * absdet;
+            }
+        } else if constexpr (FORM == F_DIV) {
+            // row = pressure node (vertex li): B_{i,(j,d)} = |detB| sum_q w_q psi_qi dphi_qjd  (FE_def.hpp:1992-2004)
+            const double* __restrict__ s_psi = s_dphi + nq * NEN * DIM;
+            double vd[NEN][DIM];
+#pragma unroll
+            for (int j = 0; j < NEN; ++j)
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) vd[j][d] = 0.0;
+            for (int q = 0; q < nq; ++q) {
+                const double wp = s_w[q] * s_psi[q * (DIM + 1) + li];
+#pragma unroll
+                for (int j = 0; j < NEN; ++j) {
+                    double gj[DIM];
+                    if constexpr (P1) {
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) gj[d] = G[j][d];
+                    } else {
+                        grad_t<DIM, NEN>(s_dphi, q, j, Binv, gj);
+                    }
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) vd[j][d] += wp * gj[d];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NEN; ++j)
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) {
+                    cols[j * DIM + d] = nd[j] * DIM + d;
+                    vals[j * DIM + d] = absdet * vd[j][d];
+                }
+        } else if constexpr (FORM == F_DIVT) {
+            // row = velocity dof (node li, component comp): B^T_{(i,d),j} = |detB| sum_q w_q psi_qj dphi_qid  (:2022-2046)
+            const double* __restrict__ s_psi = s_dphi + nq * NEN * DIM;
+            double vj[DIM + 1];
+#pragma unroll
+            for (int j = 0; j <= DIM; ++j) vj[j] = 0.0;
+            for (int q = 0; q < nq; ++q) {
+                if constexpr (!P1) grad_t<DIM, NEN>(s_dphi, q, li, Binv, gi);
+                double gc = 0.0;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) gc = d == comp ? gi[d] : gc;
+#pragma unroll
+                for (int j = 0; j <= DIM; ++j) vj[j] += s_w[q] * s_psi[q * (DIM + 1) + j] * gc;
+            }
+#pragma unroll
+            for (int j = 0; j <= DIM; ++j) {
+                cols[j] = nd[j];
+                vals[j] = absdet * vj[j];
+            }
+        } else {
+            const double lam = a.p0, mu = a.p1;
+            double vb[NEN][DIM];
+#pragma unroll
+            for (int j = 0; j < NEN; ++j)
+#pragma unroll
+                for (int b = 0; b < DIM; ++b) vb[j][b] = 0.0;
+            for (int q = 0; q < nq; ++q) {
+                if constexpr (!P1) grad_t<DIM, NEN>(s_dphi, q, li, Binv, gi);
+                double gia = 0.0;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) gia = d == comp ? gi[d] : gia;
+#pragma unroll
+                for (int j = 0; j < NEN; ++j) {
+                    double gj[DIM];
+                    if constexpr (P1) {
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) gj[d] = G[j][d];
+                    } else {
+                        grad_t<DIM, NEN>(s_dphi, q, j, Binv, gj);
+                    }
+                    double dot = 0.0, gja = 0.0;
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) {
+                        dot += gi[d] * gj[d];
+                        gja = d == comp ? gj[d] : gja;
+                    }
+                    // 2 mu eps_i:eps_j + lam tr(eps_i) tr(eps_j) with eps from epsilonTensor (FE_def.hpp:4931-4944)
+#pragma unroll
+                    for (int b = 0; b < DIM; ++b)
+                        vb[j][b] += s_w[q] * (mu * ((b == comp ? dot : 0.0) + gi[b] * gja) + lam * gia * gj[b]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NEN; ++j)
+#pragma unroll
+                for (int b = 0; b < DIM; ++b) {
+                    cols[j * DIM + b] = nd[j] * dofs + b;
+                    vals[j * DIM + b] = absdet * vb[j][b];
+                }
+        }
+    }
+}
+
 template <int DIM, int NEN, int FORM>
 __device__ __forceinline__ void eval_pair(const AsmArgs& a, const double* __restrict__ s_w,
                                           const double* __restrict__ s_phi, const double* __restrict__ s_dphi, int nq,
@@ -247,103 +399,7 @@ __device__ __forceinline__ void eval_pair(const AsmArgs& a, const double* __rest
     for (int v = 0; v <= DIM; ++v)
 #pragma unroll
         for (int d = 0; d < DIM; ++d) X[v][d] = a.xyz[(int64_t)nd[v] * DIM + d];
-    if constexpr (FORM == F_MASS) {
-        const double absdet = fabs(affine_det<DIM>(X));
-#pragma unroll
-        for (int j = 0; j < NEN; ++j) {
-            double v = 0.0;
-            for (int q = 0; q < nq; ++q) v += s_w[q] * s_phi[q * NEN + li] * s_phi[q * NEN + j];
-            cols[j] = nd[j] * dofs + comp;
-            vals[j] = v * absdet;
-        }
-    } else {
-        double Binv[DIM][DIM];
-        const double absdet = fabs(affine<DIM>(X, Binv));
-        if constexpr (FORM == F_LAPLACE) {
-#pragma unroll
-            for (int j = 0; j < NEN; ++j) {
-                double v = 0.0;
-                for (int q = 0; q < nq; ++q) {
-                    double gi[DIM], gj[DIM];
-                    grad_t<DIM, NEN>(s_dphi, q, li, Binv, gi);
-                    grad_t<DIM, NEN>(s_dphi, q, j, Binv, gj);
-#pragma unroll
-                    for (int d = 0; d < DIM; ++d) v += s_w[q] * gi[d] * gj[d];
-                }
-                cols[j] = nd[j] * dofs + comp;
-                vals[j] = v * absdet;
-            }
-        } else if constexpr (FORM == F_DIV) {
-            // row = pressure node (vertex li): B_{i,(j,d)} = |detB| sum_q w_q psi_qi dphi_qjd  (FE_def.hpp:1992-2004)
-            const double* __restrict__ s_psi = s_dphi + nq * NEN * DIM;
-#pragma unroll
-            for (int j = 0; j < NEN; ++j) {
-                double vd[DIM];
-#pragma unroll
-                for (int d = 0; d < DIM; ++d) vd[d] = 0.0;
-                for (int q = 0; q < nq; ++q) {
-                    double gj[DIM];
-                    grad_t<DIM, NEN>(s_dphi, q, j, Binv, gj);
-                    const double wp = s_w[q] * s_psi[q * (DIM + 1) + li];
-#pragma unroll
-                    for (int d = 0; d < DIM; ++d) vd[d] += wp * gj[d];
-                }
-#pragma unroll
-                for (int d = 0; d < DIM; ++d) {
-                    cols[j * DIM + d] = nd[j] * DIM + d;
-                    vals[j * DIM + d] = absdet * vd[d];
-                }
-            }
-        } else if constexpr (FORM == F_DIVT) {
-            // row = velocity dof (node li, component comp): B^T_{(i,d),j} = |detB| sum_q w_q psi_qj dphi_qid  (:2022-2046)
-            const double* __restrict__ s_psi = s_dphi + nq * NEN * DIM;
-            double vj[DIM + 1];
-#pragma unroll
-            for (int j = 0; j <= DIM; ++j) vj[j] = 0.0;
-            for (int q = 0; q < nq; ++q) {
-                double gi[DIM];
-                grad_t<DIM, NEN>(s_dphi, q, li, Binv, gi);
-                double gc = 0.0;
-#pragma unroll
-                for (int d = 0; d < DIM; ++d) gc = d == comp ? gi[d] : gc;
-#pragma unroll
-                for (int j = 0; j <= DIM; ++j) vj[j] += s_w[q] * s_psi[q * (DIM + 1) + j] * gc;
-            }
-#pragma unroll
-            for (int j = 0; j <= DIM; ++j) {
-                cols[j] = nd[j];
-                vals[j] = absdet * vj[j];
-            }
-        } else {
-            const double lam = a.p0, mu = a.p1;
-#pragma unroll
-            for (int j = 0; j < NEN; ++j) {
-                double vb[DIM];
-#pragma unroll
-                for (int b = 0; b < DIM; ++b) vb[b] = 0.0;
-                for (int q = 0; q < nq; ++q) {
-                    double gi[DIM], gj[DIM];
-                    grad_t<DIM, NEN>(s_dphi, q, li, Binv, gi);
-                    grad_t<DIM, NEN>(s_dphi, q, j, Binv, gj);
-                    double dot = 0.0, gia = 0.0, gja = 0.0;
-#pragma unroll
-                    for (int d = 0; d < DIM; ++d) {
-                        dot += gi[d] * gj[d];
-                        gia = d == comp ? gi[d] : gia;
-                        gja = d == comp ? gj[d] : gja;
-                    }
-#pragma unroll
-                    for (int b = 0; b < DIM; ++b)
-                        vb[b] += s_w[q] * (mu * ((b == comp ? dot : 0.0) + gi[b] * gja) + lam * gia * gj[b]);
-                }
-#pragma unroll
-                for (int b = 0; b < DIM; ++b) {
-                    cols[j * DIM + b] = nd[j] * dofs + b;
-                    vals[j * DIM + b] = absdet * vb[b];
-                }
-            }
-        }
-    }
+    compute_pair<DIM, NEN, FORM>(a, s_w, s_phi, s_dphi, nq, nd, X, li, comp, dofs, cols, vals);
 }
 
 template <int DIM, int NEN, int FORM>
@@ -361,7 +417,11 @@ __global__ __launch_bounds__(256) void k_assemble_pairs(AsmArgs a, int R, int tp
     const int tid = threadIdx.x;
     for (int i = tid; i < ntab; i += 256) sm[i] = a.tab[i];
     const int dofs = a.dofs;
-    const int32_t r0 = blockIdx.x * R;
+    // each XCD takes a contiguous eighth of the rows: rows of neighbouring node lines share elements, whose
+    // connectivity and coordinates then meet in one L2 (PMC traffic 2.7x -> 1.75x the algorithmic bytes at 100^3 cells)
+    const int32_t nwg = gridDim.x, q8 = nwg >> 3, rem8 = nwg & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int32_t wg = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + within;
+    const int32_t r0 = wg * R;
     const int nrows = min(R, a.n_rows - r0);
     // exclusive prefix of the rows' pair counts: first wave, one lane per row (R <= 64), DPP scan
     if (tid < 64) {
@@ -438,6 +498,149 @@ __global__ __launch_bounds__(256) void k_assemble_pairs(AsmArgs a, int R, int tp
             a.val[rs + s] = acc;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Slot-addressed variant (default, asm_kind 0).  A workgroup owns R consecutive dof rows, i.e. one
+// contiguous range of the CSR arrays, and keeps an image of that range in LDS:
+//   phase 0: the range's column ids -> LDS (coalesced), accumulators zeroed;
+//   phase 1: one lane per (row, incident element) pair, as in the pair-parallel kernel; the global
+//            loads of U pairs per lane (adjacency entry -> element nodes -> vertex coordinates) are
+//            issued as three batches of independent requests; each contribution's CSR slot is found
+//            by a binary search of its column id in the row's LDS-resident column list, and
+//            (slot, value) is parked in LDS;
+//   phase 2: one lane per row adds its parked contributions into the LDS image in their fixed order
+//            (adjacency order, then local column order): no atomics, no sweep over the row's other
+//            contributions -- 96 read-modify-writes per P1 row instead of 15 slots x 96 compares;
+//   phase 3: the image is written to HBM as one contiguous coalesced stream.
+// Summation order is fixed by the sorted adjacency list => bitwise reproducible.  Workgroups are
+// remapped so that each XCD takes a contiguous eighth of the rows (rows of neighbouring node lines
+// share elements: their connectivity and coordinates then meet in one L2).
+// ---------------------------------------------------------------------------------------------
+template <int DIM, int NEN, int FORM, int U /* pairs per lane whose loads are in flight together */>
+__global__ __launch_bounds__(256) void k_assemble_slots(AsmArgs a, int R, int cap_contrib, int cap_cols, int nwg, int dbg) {
+    constexpr int CPP = PairCfg<DIM, NEN, FORM>::CPP;
+    constexpr int PADV = 1, PADS = 2;        // per-row shifts of the parks: the lanes of phase 2 (one per row) hit different banks
+    extern __shared__ double sm[];
+    const int nq = a.nq;
+    const int ntab = nq * (1 + NEN + NEN * DIM + DIM + 1);
+    double* s_w = sm;
+    double* s_phi = s_w + nq;
+    double* s_dphi = s_phi + nq * NEN;
+    double* cval = sm + ntab;                                   // [cap_contrib]
+    double* acc = cval + cap_contrib;                           // [cap_cols]   image of val[rs0, rs0 + ncols)
+    int32_t* scol = reinterpret_cast<int32_t*>(acc + cap_cols); // [cap_cols]   image of colind[...]
+    int32_t* off = scol + cap_cols;                             // [R + 1]      pair offsets of the rows
+    int32_t* rbase = off + R + 1;                               // [R + 1]      row starts relative to rs0
+    uint16_t* cslot = reinterpret_cast<uint16_t*>(rbase + R + 1);   // [cap_contrib] position in the image
+    const int tid = threadIdx.x;
+    const int32_t q8 = nwg >> 3, rem8 = nwg & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int32_t wg = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + within;
+    for (int i = tid; i < ntab; i += 256) sm[i] = a.tab[i];
+    const int dofs = a.dofs;
+    const int32_t r0 = wg * R;
+    const int nrows = min(R, a.n_rows - r0);
+    const int32_t rs0 = a.rowptr[r0];
+    if (tid < 64) {   // exclusive prefix of the rows' pair counts; row starts
+        int deg = 0;
+        if (tid < nrows) {
+            const int32_t node = (r0 + tid) / dofs;
+            deg = a.n2e_ptr[node + 1] - a.n2e_ptr[node];
+        }
+        int incl = deg;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (tid >= d) incl += t;
+        }
+        if (tid <= nrows) {
+            off[tid] = incl - deg;
+            rbase[tid] = a.rowptr[r0 + tid] - rs0;
+        }
+    }
+    __syncthreads();
+    const int npairs = off[nrows];
+    const int ncols = rbase[nrows];
+    for (int i = tid; i < ncols; i += 256) {
+        scol[i] = a.colind[rs0 + i];
+        acc[i] = 0.0;
+    }
+    __syncthreads();
+    for (int i0 = tid; i0 < npairs && !(dbg & 2); i0 += 256 * U) {
+        int lo_[U], li_[U];
+        int32_t e_[U], nd[U][NEN];
+        double X[U][DIM + 1][DIM];
+        // batch 1: adjacency entries (row of the pair by binary search over the offsets)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(i0 + u * 256, npairs - 1);
+            int lo = 0, hi = nrows - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (off[mid] <= i) lo = mid;
+                else hi = mid - 1;
+            }
+            lo_[u] = lo;
+            const int32_t node = (r0 + lo) / dofs;
+            e_[u] = a.n2e[a.n2e_ptr[node] + (i - off[lo])];
+        }
+        // batch 2: element nodes
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int32_t e = e_[u] / NEN;
+            li_[u] = e_[u] - e * NEN;
+            e_[u] = e;
+#pragma unroll
+            for (int j = 0; j < NEN; ++j) nd[u][j] = a.conn[(int64_t)e * NEN + j];
+        }
+        // batch 3: vertex coordinates
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v <= DIM; ++v)
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) X[u][v][d] = a.xyz[(int64_t)nd[u][v] * DIM + d];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+            if (i >= npairs) break;
+            const int lo = lo_[u];
+            const int comp = (r0 + lo) % dofs;
+            int32_t cols[CPP];
+            double vals[CPP];
+            compute_pair<DIM, NEN, FORM>(a, s_w, s_phi, s_dphi, nq, nd[u], X[u], li_[u], comp, dofs, cols, vals);
+            const int lb = rbase[lo], ln = rbase[lo + 1] - lb;
+            const int bv = i * CPP + lo * PADV, bs = i * CPP + lo * PADS;
+#pragma unroll
+            for (int c = 0; c < CPP; ++c) {
+                cval[bv + c] = vals[c];
+                cslot[bs + c] = (uint16_t)(lb + find_slot(scol + lb, ln, cols[c]));
+            }
+        }
+    }
+    __syncthreads();
+    // L lanes per row: lane t adds the contributions c = j L + t, j = 0..NEN-1 (for the block forms: column
+    // component t of every element node).  Two contributions of one pair never share a slot, and lanes t != t' never
+    // touch the same slot at all, so every slot still receives its terms in adjacency order.
+    constexpr int L = CPP % NEN == 0 ? CPP / NEN : 1, CPL = CPP / L;
+    if (tid < nrows * L && !(dbg & 1)) {
+        const int row = tid / L, t = tid - row * L;
+        const int pb = off[row], pe = off[row + 1];
+        for (int i = pb; i < pe; ++i) {
+            const int bv = i * CPP + row * PADV, bs = i * CPP + row * PADS;
+            double vv[CPL];
+            int ss[CPL];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                vv[j] = cval[bv + j * L + t];
+                ss[j] = cslot[bs + j * L + t];
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) acc[ss[j]] += vv[j];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < ncols; i += 256) a.val[rs0 + i] = acc[i];
 }
 
 struct RhsArgs {
@@ -569,9 +772,64 @@ int launch_pairs(fedd_ctx* c, const AsmArgs& a, int ntab, int64_t n_rows, int ro
     return 0;
 }
 
+// slot-addressed kernel; returns -1 (without error) when a row or the LDS budget does not suit it
+template <int DIM, int NEN, int FORM>
+int launch_slots(fedd_ctx* c, const AsmArgs& a, int ntab, int64_t n_rows, int rowcap) {
+    constexpr int CPP = PairCfg<DIM, NEN, FORM>::CPP;
+    const int maxdeg = std::max(1, c->max_deg);
+    rowcap = std::max(1, rowcap);
+    // per row: parked contributions (f64 value + u16 slot, + the bank shifts), image of the CSR row (f64 + i32)
+    const size_t per_row = (size_t)maxdeg * CPP * 10 + 12 + (size_t)rowcap * 12 + 8;
+    const size_t budget = (size_t)c->asm_lds_kb * 1024;
+    // (R <= 63: one wave scans the row offsets, lane nrows writes the total)
+    int R = (int)std::min<size_t>(63, budget > (size_t)ntab * 8 ? (budget - (size_t)ntab * 8) / per_row : 0);
+    if (R < 1) R = (int)std::min<size_t>(63, (150 * 1024 - (size_t)ntab * 8) / per_row);   // large P2 rows: one workgroup per CU
+    if (R < 1) return -1;
+    const int cap_cols = R * rowcap;
+    if (cap_cols > 65535) return -1;    // u16 positions
+    int cap_contrib = R * maxdeg * CPP + R * 2 + 2;
+    cap_contrib += cap_contrib & 1;     // keeps the arrays behind it 8-byte aligned
+    const size_t lds = (size_t)ntab * 8 + (size_t)cap_contrib * 8 + (size_t)cap_cols * 12 + (size_t)(2 * R + 2) * 4 +
+                       (size_t)cap_contrib * 2 + 16;
+    if (lds > 160 * 1024) return -1;
+    const int nwg = (int)((n_rows + R - 1) / R);
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024)
+            FEDD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ScopedTimer t(c, FEDD_T_ASSEMBLE);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, c->stream, a, R, cap_contrib, cap_cols, nwg, c->asm_dbg);
+        t.stop();
+        return 0;
+    };
+    if (NEN <= 4 && c->asm_u >= 3) FEDD_TRY(go(k_assemble_slots<DIM, NEN, FORM, (NEN <= 4 ? 3 : 1)>));
+    else if (NEN <= 4 && c->asm_u == 2) FEDD_TRY(go(k_assemble_slots<DIM, NEN, FORM, (NEN <= 4 ? 2 : 1)>));
+    else FEDD_TRY(go(k_assemble_slots<DIM, NEN, FORM, 1>));
+    FEDD_HIP(hipGetLastError());
+    return 0;
+}
+
+// asm_kind 0: slot-addressed kernel, falling back to the pair-parallel sweep where it does not fit; 2: the sweep
+template <int DIM, int NEN, int FORM>
+int launch_matrix(fedd_ctx* c, const AsmArgs& a, int ntab, int64_t n_rows, int rowcap) {
+    // Measured (one MI355X): elasticity, 94^3 cells, FULL blocks: sweep 7.9 ms, slots 5.5 ms; B / B^T likewise;
+    // Laplace, 214^3 cells: sweep 5.15 ms, slots 5.5-5.7 ms (the one-wave accumulation of phase 2 costs what the sweep
+    // over 96 contributions costs).  asm_kind 0 picks by the contributions per pair, 3 forces the slot kernel.
+    constexpr bool many = PairCfg<DIM, NEN, FORM>::CPP > NEN;
+    if (((c->asm_kind == 0 && many) || c->asm_kind == 3) && n_rows > 0) {
+        const int rc = launch_slots<DIM, NEN, FORM>(c, a, ntab, n_rows, rowcap);
+        if (rc >= 0) return rc;
+    }
+    return launch_pairs<DIM, NEN, FORM>(c, a, ntab, n_rows, rowcap);
+}
+
 template <int DIM, int NEN>
 int launch_assemble(fedd_ctx* c, int kform, const AsmArgs& a, int ntab) {
-    if (c->asm_kind == 0) {
+    if (c->asm_kind != 1) {
+        if (kform == F_LAPLACE) return launch_matrix<DIM, NEN, F_LAPLACE>(c, a, ntab, c->n_rows_ext, c->max_row_nnz);
+        if (kform == F_MASS) return launch_matrix<DIM, NEN, F_MASS>(c, a, ntab, c->n_rows_ext, c->max_row_nnz);
+        return launch_matrix<DIM, NEN, F_LINELAS>(c, a, ntab, c->n_rows_ext, c->max_row_nnz);
+    }
+    if (false) {
         if (kform == F_LAPLACE) return launch_pairs<DIM, NEN, F_LAPLACE>(c, a, ntab, c->n_rows_ext, c->max_row_nnz);
         if (kform == F_MASS) return launch_pairs<DIM, NEN, F_MASS>(c, a, ntab, c->n_rows_ext, c->max_row_nnz);
         return launch_pairs<DIM, NEN, F_LINELAS>(c, a, ntab, c->n_rows_ext, c->max_row_nnz);
@@ -717,8 +975,8 @@ int assemble_div(fedd_ctx* c, int64_t n_p, int slot_b, int slot_bt) {
     at.rowptr = BT.rowptr.p; at.colind = BT.colind.p; at.val = BT.val.p; at.n_rows = (int32_t)BT.n_rows; at.dofs = dim;
 #define DIV_LAUNCH(D, N)                                                                               \
     do {                                                                                               \
-        FEDD_TRY((launch_pairs<D, N, F_DIV>(c, ab, ntab, n_p, B.max_row_nnz)));                        \
-        FEDD_TRY((launch_pairs<D, N, F_DIVT>(c, at, ntab, BT.n_rows, BT.max_row_nnz)));                \
+        FEDD_TRY((launch_matrix<D, N, F_DIV>(c, ab, ntab, n_p, B.max_row_nnz)));                       \
+        FEDD_TRY((launch_matrix<D, N, F_DIVT>(c, at, ntab, BT.n_rows, BT.max_row_nnz)));               \
     } while (0)
     if (dim == 2 && nen == 3) DIV_LAUNCH(2, 3);
     else if (dim == 2 && nen == 6) DIV_LAUNCH(2, 6);

@@ -173,7 +173,9 @@ struct fedd_ctx {
     int asm_lds_kb = 37;                        // LDS budget of the assembly kernel's contribution park (KB): 4 workgroups per CU
     int box_kind = 0;                           // Schwarz boxes: 0 = one lattice over all ranks' nodes, 1 = per-rank lattice
     int spmv_kind = 0;                          // 0 = CSR-window / automatic, 1 = row-per-lane-group, 2 = CSR-stream
-    int asm_kind = 0;                           // 0 = pair-parallel assembly, 1 = lane-per-row gather
+    int asm_dbg = 0;                            // ablation switches of the assembly kernel (development)
+    int asm_u = 1;                              // slot-addressed assembly: pairs per lane with their loads in flight together (P1)
+    int asm_kind = 0;                           // 0 = slot-addressed pair-parallel assembly, 2 = pair-parallel with slot sweep, 1 = lane-per-row gather
     fedd::DevBuf<int32_t> d_pat_stash;          // pattern build: merged node lists of the count pass, [k][node]
     fedd::DevBuf<int32_t> d_spmv_rows;          // CSR-stream: first row of every nnz window
     bool spmv_rows_ready = false;

@@ -245,7 +245,9 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
                int restart, int use_prec, int* its_out, double* relres_out);
 
 /* tuning knobs (A/B tests), 0 is the default of each: "spmv_kind" 0 = CSR-window (CSR-stream when a row has more than 256 entries), 1 = row-per-lane-group, 2 = CSR-stream;
- * "asm_kind" 0 = pair-parallel assembly, 1 = lane-per-row gather; "apply_kind" 0 = flat streaming Schwarz
+ * "asm_kind" 0 = pair-parallel assembly (slot-addressed accumulation for the block forms -- elasticity, B / B^T --, slot sweep for
+ * the scalar forms), 1 = lane-per-row gather, 2 = slot sweep always, 3 = slot-addressed always; "asm_u" pairs per lane whose
+ * loads are in flight together in the slot-addressed kernel (P1; default 1); "asm_dbg" ablation switches (development); "apply_kind" 0 = flat streaming Schwarz
  * apply, 1 = strided, 2 = flat without the compact LDS layout; "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
  * matrix cores, 2 = scalar-pivot without dropping rows;
  * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes;
