@@ -42,6 +42,8 @@ SIGNATURES = {
     "fedd_mesh_p2_sizes": [C.c_int, C.c_int64, _i32p, _i64p],
     "fedd_mesh_p2_build": [C.c_int, C.c_int64, C.c_int64, _i32p, _f64p, _i32p, C.c_int64, _i32p, _i32p, C.c_int,
                            _i32p, _f64p, _i32p],
+    "fedd_fe_quadrature": [C.c_int, C.c_int, _ip, _f64p, _f64p],
+    "fedd_fe_basis": [C.c_int, C.c_int, C.c_int, _f64p, _f64p],
     "fedd_mesh_set": [C.c_void_p, C.c_int, C.c_int, C.c_int64, _i32p, C.c_int64, _f64p, _i64p, C.c_int64,
                       _i64p, _i32p],
     "fedd_mesh_set_rows": [C.c_void_p, C.c_int, C.c_int, C.c_int64, _i32p, C.c_int64, _f64p, _i64p, C.c_int64,
@@ -239,6 +241,23 @@ def p2_of_p1(m, volume_id=10):
     gid = np.arange(nv + ned.value, dtype=np.int64)
     return dict(dim=dim, nen=nen2, conn=conn2, xyz=xyz2, gid_rep=gid, flag_rep=flag2, gid_uni=gid.copy(),
                 flag_uni=flag2.copy(), n_global=nv + ned.value, n_p1=nv, elem_flag=m.get("elem_flag"))
+
+
+def fe_quadrature(dim, degree):
+    """(points [nq, dim], weights [nq]) of the product's quadrature rule"""
+    nq = C.c_int()
+    _chk(lib().fedd_fe_quadrature(dim, degree, C.byref(nq), None, None))
+    pts = np.zeros((nq.value, dim)); w = np.zeros(nq.value)
+    _chk(lib().fedd_fe_quadrature(dim, degree, C.byref(nq), _p(pts, _f64p), _p(w, _f64p)))
+    return pts, w
+
+
+def fe_basis(dim, nen, degree):
+    """(phi [nq, nen], dphi [nq, nen, dim]) at the points of fe_quadrature(dim, degree)"""
+    nq = fe_quadrature(dim, degree)[1].shape[0]
+    phi = np.zeros((nq, nen)); dphi = np.zeros((nq, nen, dim))
+    _chk(lib().fedd_fe_basis(dim, nen, degree, _p(phi, _f64p), _p(dphi, _f64p)))
+    return phi, dphi
 
 
 def structured_owner(dim, N, M, gids):

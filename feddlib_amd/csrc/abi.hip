@@ -495,6 +495,25 @@ extern "C" int fedd_spmv_device(fedd_ctx* c, int reps) {
     return 0;
 }
 
+// host-only: the product's reference-element tables, for parity checks against the reference's literals
+extern "C" int fedd_fe_quadrature(int dim, int degree, int* nq, double* pts, double* w) {
+    FEDD_CHECK(nq, "fedd_fe_quadrature: null output");
+    std::vector<double> p, ww;
+    FEDD_TRY(fe_quadrature(dim, degree, p, ww));
+    *nq = (int)ww.size();
+    if (pts) std::copy(p.begin(), p.end(), pts);
+    if (w) std::copy(ww.begin(), ww.end(), w);
+    return 0;
+}
+
+extern "C" int fedd_fe_basis(int dim, int nen, int degree, double* phi, double* dphi) {
+    FeTables t;
+    FEDD_TRY(fe_tables(dim, nen, degree, t));
+    if (phi) std::copy(t.phi.begin(), t.phi.end(), phi);
+    if (dphi) std::copy(t.dphi.begin(), t.dphi.end(), dphi);
+    return 0;
+}
+
 extern "C" int fedd_spmv_info(fedd_ctx* c, int64_t* nnz_pattern, int64_t* nnz_streamed) {
     NEED_DEVICE(c);
     FEDD_CHECK(c->have_pattern, "fedd_spmv_info: no matrix");

@@ -124,6 +124,16 @@ int fedd_mesh_p2_build(int dim, int64_t n_vert, int64_t n_elem, const int32_t* c
                        int volume_id, int32_t* conn_p2, double* xyz_p2, int32_t* flag_p2);
 
 /* ------------------------------------------------------------------------------------------------
+ * reference-element tables the assembly kernels stage in LDS (host side, no GPU needed): quadrature points and
+ * weights of FE::getQuadratureValues (feddlib/core/FE/FE_def.hpp:6023-6727, degree remapping included) and the
+ * values / gradients of FE::phi / FE::gradPhi (:4947-5087, :5565-5713) at those points.  Read-back for parity
+ * tests against the reference's literals (tests/golden/ref_tables.json).
+ * fedd_fe_quadrature: pts[nq*dim], w[nq] (call with NULL arrays for nq).  fedd_fe_basis: phi[nq*nen], dphi[nq*nen*dim].
+ * ---------------------------------------------------------------------------------------------- */
+int fedd_fe_quadrature(int dim, int degree, int* nq, double* pts, double* w);
+int fedd_fe_basis(int dim, int nen, int degree, double* phi, double* dphi);
+
+/* ------------------------------------------------------------------------------------------------
  * mesh upload: what FE::assemblyXxx reads through domainVec_[FEloc]->getElementsC(),
  * getPointsRepeated(), getMapRepeated() (feddlib/core/FE/FE_def.hpp:617-621) and what BCBuilder
  * reads through getBCFlagUnique()/getMapUnique() (feddlib/core/General/BCBuilder_def.hpp:625-626).
