@@ -128,7 +128,7 @@ extern "C" void fedd_ctx_destroy(fedd_ctx* c) {
         fedd::DevBuf<int32_t>* cib[] = {&c->d_co_key[0], &c->d_co_key[1], &c->d_co_val[0], &c->d_co_val[1],
                                         &c->d_co_cell_ptr};
         for (auto* b : cib) b->release();
-        fedd::DevBuf<double>* cdb[] = {&c->d_co_mask, &c->d_co_cellK, &c->d_co_K, &c->d_co_panel,
+        fedd::DevBuf<double>* cdb[] = {&c->d_co_mask, &c->d_co_cellK, &c->d_co_K, &c->d_dense_ws,
                                        &c->d_co_part, &c->d_co_r0, &c->d_co_z0};
         for (auto* b : cdb) b->release();
         for (auto& m : c->aux) {
@@ -652,6 +652,8 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
         c->cs_valid = false;
     }
     else if (k == "whole_boxes") c->whole_boxes = (int)value;
+    else if (k == "schwarz_big") c->sw_big = (int)value;
+    else if (k == "schwarz_big_target") c->sw_big_target = (int)value;
     else if (k == "asm_kind") c->asm_kind = (int)value;
     else if (k == "asm_u") c->asm_u = (int)value;
     else if (k == "asm_dbg") c->asm_dbg = (int)value;

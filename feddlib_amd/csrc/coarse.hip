@@ -302,161 +302,7 @@ __global__ __launch_bounds__(256) void k_fix_diag(double* __restrict__ K, int64_
     if (lane == 0) K[row * ld + row] = row_any ? K[row * ld + row] * (1.0 + 1e-12) : 1.0;
 }
 
-// ---- blocked Gauss-Jordan inversion (no pivoting: K0 is symmetric positive definite) ----
-// step kb with pivot block D = K[kb,kb]:  K[kb,kb] <- D^-1, K[kb,j] <- D^-1 K[kb,j],
-// K[i,kb] <- -K[i,kb] D^-1, K[i,j] <- K[i,j] - K[i,kb] D^-1 K[kb,j]  (i, j != kb).
-
-// D^-1 of the 64 x 64 pivot block, register tiled (the scheme of schwarz.hip k_invert_reg, T = 4)
-__global__ __launch_bounds__(256) void k_diag_inv(const double* __restrict__ K, int64_t ld, int kb,
-                                                  double* __restrict__ Dinv, int32_t* __restrict__ bad) {
-    constexpr int T = 4;
-    __shared__ double colbuf[2][NB], rowbuf[2][NB];
-    const int tid = threadIdx.x, ty = tid & 15, tx = tid >> 4;
-    const double* __restrict__ D = K + ((int64_t)kb * NB) * ld + (int64_t)kb * NB;
-    double A[T][T];
-#pragma unroll
-    for (int a = 0; a < T; ++a)
-#pragma unroll
-        for (int b = 0; b < T; ++b) A[a][b] = D[(int64_t)(ty + 16 * a) * ld + tx + 16 * b];
-    bool singular = false;
-#pragma unroll
-    for (int kq = 0; kq < T; ++kq) {
-#pragma unroll 1
-        for (int kc = 0; kc < 16; ++kc) {
-            const int k = 16 * kq + kc;
-            const int buf = k & 1;
-            if (tx == kc) {
-#pragma unroll
-                for (int a = 0; a < T; ++a) colbuf[buf][ty + 16 * a] = A[a][kq];
-            }
-            if (ty == kc) {
-#pragma unroll
-                for (int b = 0; b < T; ++b) rowbuf[buf][tx + 16 * b] = A[kq][b];
-            }
-            __syncthreads();
-            const double piv = rowbuf[buf][k];
-            singular = singular || !(piv > 1e-300);
-            const double pinv = 1.0 / piv;
-            double cc[T], rr[T];
-#pragma unroll
-            for (int a = 0; a < T; ++a) cc[a] = colbuf[buf][ty + 16 * a];
-#pragma unroll
-            for (int b = 0; b < T; ++b) rr[b] = rowbuf[buf][tx + 16 * b] * pinv;
-            if (ty == kc) {
-                cc[kq] = -1.0;
-#pragma unroll
-                for (int b = 0; b < T; ++b) A[kq][b] = 0.0;
-            }
-            if (tx == kc) {
-                rr[kq] = pinv;
-#pragma unroll
-                for (int a = 0; a < T; ++a) A[a][kq] = 0.0;
-            }
-#pragma unroll
-            for (int a = 0; a < T; ++a)
-#pragma unroll
-                for (int b = 0; b < T; ++b) A[a][b] = fma(-cc[a], rr[b], A[a][b]);
-        }
-    }
-    if (singular && tid == 0) bad[0] = 1;
-#pragma unroll
-    for (int a = 0; a < T; ++a)
-#pragma unroll
-        for (int b = 0; b < T; ++b) Dinv[(ty + 16 * a) * NB + tx + 16 * b] = A[a][b];
-}
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-// 64 x 64 x 64 product on the f64 matrix cores: the four waves of the workgroup each own a 32 x 32
-// quadrant (2 x 2 tiles of v_mfma_f64_16x16x4_f64).  A-fragment lane l = A[l & 15][k = l >> 4],
-// B-fragment B[k = l >> 4][l & 15], result register q of lane l = C[(l >> 4) + 4 q][l & 15].
-constexpr int LDA_S = 68, LDB_S = 80;  // LDS leading dimensions: the fragment reads are 2-way at worst
-
-__device__ __forceinline__ void mm64(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
-                                     int64_t ldb, double* As, double* Bs, double4_t acc[2][2]) {
-    const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e >> 6, cidx = e & 63;
-        As[r * LDA_S + cidx] = A[(int64_t)r * lda + cidx];
-        Bs[r * LDB_S + cidx] = B[(int64_t)r * ldb + cidx];
-    }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    const int r0 = 32 * (wave >> 1), c0 = 32 * (wave & 1);
-    const int li = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int s = 0; s < NB / 4; ++s) {
-        const double a0 = As[(r0 + li) * LDA_S + 4 * s + lk];
-        const double a1 = As[(r0 + 16 + li) * LDA_S + 4 * s + lk];
-        const double b0 = Bs[(4 * s + lk) * LDB_S + c0 + li];
-        const double b1 = Bs[(4 * s + lk) * LDB_S + c0 + 16 + li];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-    }
-}
-
-// element (row, col) of the workgroup's 64 x 64 tile held in acc[ti][tj] register q
-#define MM64_FOR_EACH(BODY)                                                     \
-    {                                                                           \
-        const int wave_ = threadIdx.x >> 6, lane_ = threadIdx.x & 63;           \
-        _Pragma("unroll") for (int ti = 0; ti < 2; ++ti)                        \
-        _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)                        \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                         \
-            const int row = 32 * (wave_ >> 1) + 16 * ti + (lane_ >> 4) + 4 * q; \
-            const int col = 32 * (wave_ & 1) + 16 * tj + (lane_ & 15);          \
-            const double v = acc[ti][tj][q];                                    \
-            BODY                                                                \
-        }                                                                       \
-    }
-
-// column block bj: save the column panel tile C[bj] = K[bj, kb] and form R[bj] = Dinv K[kb, bj]
-__global__ __launch_bounds__(256) void k_panels(const double* __restrict__ K, int64_t ld, int kb,
-                                                const double* __restrict__ Dinv, double* __restrict__ R,
-                                                double* __restrict__ Cp) {
-    __shared__ double As[NB * LDA_S];
-    __shared__ double Bs[NB * LDB_S];
-    const int bj = blockIdx.x;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {
-        const int r = e >> 6, cidx = e & 63;
-        Cp[((int64_t)bj * NB + r) * NB + cidx] = K[((int64_t)bj * NB + r) * ld + (int64_t)kb * NB + cidx];
-    }
-    if (bj == kb) return;
-    double4_t acc[2][2];
-    mm64(Dinv, NB, K + ((int64_t)kb * NB) * ld + (int64_t)bj * NB, ld, As, Bs, acc);
-    MM64_FOR_EACH(R[(int64_t)row * ld + (int64_t)bj * NB + col] = v;)
-}
-
-__global__ __launch_bounds__(256) void k_update(double* __restrict__ K, int64_t ld, int kb,
-                                                const double* __restrict__ Dinv, const double* __restrict__ R,
-                                                const double* __restrict__ Cp) {
-    __shared__ double As[NB * LDA_S];
-    __shared__ double Bs[NB * LDB_S];
-    const int bi = blockIdx.y, bj = blockIdx.x;
-    double* __restrict__ tile = K + ((int64_t)bi * NB) * ld + (int64_t)bj * NB;
-    if (bi == kb) {
-        const double* __restrict__ src = bj == kb ? Dinv : R + (int64_t)bj * NB;
-        const int64_t lds = bj == kb ? NB : ld;
-        for (int e = threadIdx.x; e < NB * NB; e += 256) {
-            const int r = e >> 6, cidx = e & 63;
-            tile[(int64_t)r * ld + cidx] = src[(int64_t)r * lds + cidx];
-        }
-        return;
-    }
-    double4_t acc[2][2];
-    if (bj == kb) {
-        mm64(Cp + (int64_t)bi * NB * NB, NB, Dinv, NB, As, Bs, acc);
-        MM64_FOR_EACH(tile[(int64_t)row * ld + col] = -v;)
-    } else {
-        mm64(Cp + (int64_t)bi * NB * NB, NB, R + (int64_t)bj * NB, ld, As, Bs, acc);
-        MM64_FOR_EACH(tile[(int64_t)row * ld + col] -= v;)
-    }
-}
+// (the blocked Gauss-Jordan inversion of K0 on the f64 matrix cores lives in dense.hip: dense_invert_batched)
 
 // ---- apply ----
 template <int DIM, int DOFS>
@@ -573,22 +419,6 @@ __global__ void k_prolong_add(CoarseGeom cg, int dofs, int64_t n_rows, const dou
     z[row] += sum * m;
 }
 
-int dense_invert(fedd_ctx* c, double* K, int64_t ld, int32_t* d_bad) {
-    const int nblk = (int)(ld / NB);
-    FEDD_TRY(c->d_co_panel.ensure((size_t)NB * NB + 2 * (size_t)NB * ld));
-    double* Dinv = c->d_co_panel.p;
-    double* R = Dinv + NB * NB;
-    double* Cp = R + (size_t)NB * ld;
-    for (int kb = 0; kb < nblk; ++kb) {
-        hipLaunchKernelGGL(k_diag_inv, dim3(1), dim3(256), 0, c->stream, (const double*)K, ld, kb, Dinv, d_bad);
-        hipLaunchKernelGGL(k_panels, dim3(nblk), dim3(256), 0, c->stream, (const double*)K, ld, kb, (const double*)Dinv, R, Cp);
-        hipLaunchKernelGGL(k_update, dim3(nblk, nblk), dim3(256), 0, c->stream, K, ld, kb, (const double*)Dinv,
-                           (const double*)R, (const double*)Cp);
-    }
-    FEDD_HIP(hipGetLastError());
-    return 0;
-}
-
 }  // namespace
 
 #define COARSE_DIM(KERNEL, ...)                      \
@@ -700,7 +530,7 @@ int coarse_setup(fedd_ctx* c) {
     }
     hipLaunchKernelGGL(k_fix_diag, dim3((unsigned)((ld + 3) / 4)), blk, 0, c->stream, c->d_co_K.p, ld, n0);
     // ---- K0 <- K0^-1 ----
-    FEDD_TRY(dense_invert(c, c->d_co_K.p, ld, d_bad + 1));
+    FEDD_TRY(dense_invert_batched(c, c->d_co_K.p, ld, 1, ld * ld, nullptr, (int)(ld / NB), 1, d_bad + 1));
     int32_t bad[3] = {0, 0, 0};
     FEDD_HIP(hipMemcpyAsync(bad, d_bad, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     FEDD_HIP(hipStreamSynchronize(c->stream));

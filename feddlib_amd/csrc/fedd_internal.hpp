@@ -71,7 +71,8 @@ struct DevBuf {
 
 constexpr int MAX_BC = 16;
 constexpr int MAX_DOFS = 3;
-constexpr int SCHWARZ_NMAX = 256;  // largest overlapping subdomain (dofs) the dense kernels take
+constexpr int SCHWARZ_NMAX = 256;  // largest overlapping subdomain (dofs) the register / LDS dense kernels take
+constexpr int SCHWARZ_NMAX_BIG = 1024;  // ... and the batched matrix-core inversion of the large-subdomain path
 
 struct HaloPlan {
     std::vector<int32_t> peers;
@@ -212,6 +213,11 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_inv;                 // per subdomain [n_i][rp_i] column-major slab
     fedd::DevBuf<double> d_mult;                // [n_cols] multiplicity (averaging)
     bool have_schwarz = false;
+    int sw_big = -1;                            // large-subdomain path: -1 = for merged block systems, 0 = never, 1 = always
+    bool sw_big_active = false;                 // the current preconditioner was built by schwarz_setup_big
+    int sw_big_target = 0;                      // owned dofs per box of the bisection (0 = default 120)
+    fedd::DevBuf<double> d_big_ws;              // dense matrices of one chunk of subdomains
+    fedd::DevBuf<int32_t> d_big_nblk;           // 64-blocks per subdomain
 
     // ---- coarse level (two-level Schwarz) ----
     int sw_two_level = 0;
@@ -224,7 +230,7 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_co_mask;             // [n_cols] 1 = free dof, 0 = Dirichlet
     fedd::DevBuf<double> d_co_cellK;            // per-cell Galerkin blocks
     fedd::DevBuf<double> d_co_K;                // [ld*ld] K0, then K0^-1
-    fedd::DevBuf<double> d_co_panel;            // Dinv [64*64] | R [64*ld] | C [ld*64]
+    fedd::DevBuf<double> d_dense_ws;            // dense_invert_batched: per matrix Dinv [64*64] | R [64*ld] | C [ld*64]
     fedd::DevBuf<double> d_co_part, d_co_r0, d_co_z0;
     bool have_coarse = false;
 
@@ -329,8 +335,20 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
 int bounding_box(fedd_ctx* c, int64_t n_nodes, double lo[3], double hi[3]);   // of d_xyz[0, n_nodes)
 int global_box(fedd_ctx* c, int64_t n_own, double lo[3], double hi[3], double* n_global);   // over all ranks
 
+// schwarz_big.hip: subdomains of up to 1024 dofs (balanced coordinate-bisection boxes, batched dense inverses on the
+// f64 matrix cores); the default for merged block systems (option "schwarz_big": -1 auto, 0 never, 1 always)
+bool schwarz_use_big(const fedd_ctx* c);
+int schwarz_setup_big(fedd_ctx* c);
+int schwarz_apply_big(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool r_has_tail);
+int schwarz_overlap_lists_big(fedd_ctx* c, int64_t nsub, int32_t* max_n, int32_t* max_own);
+int schwarz_slab_offsets(fedd_ctx* c, int64_t nsub, int restricted);
+
 // invert_mfma.hip: local inverses of plain systems, n <= 128, on the f64 matrix cores
 int schwarz_invert_mfma(fedd_ctx* c, int restricted, int32_t* d_bad, int max_n);
+
+// dense.hip: in-place inverses of a batch of dense matrices on the f64 matrix cores (blocked Gauss-Jordan, no pivoting)
+int dense_invert_batched(fedd_ctx* c, double* K, int64_t ld, int batch, int64_t stride, const int32_t* d_nblk,
+                         int max_nblk, int spd, int32_t* d_bad);
 
 // coarse.hip
 int coarse_setup(fedd_ctx* c);

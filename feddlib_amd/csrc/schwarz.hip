@@ -141,6 +141,7 @@ __global__ void k_sort_bins(const int32_t* __restrict__ ptr, int32_t nb, int32_t
 // One workgroup per bin: owned dofs first (sorted), then the dofs reached by `overlap` graph
 // layers (sorted).  Layers grow through stored rows: the owned ones and those of the row ghosts
 // (n_stored >= n_rows; without row ghosts a ghost row is not stored on this rank).
+template <int NM, int HSZ>
 __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bin_ptr,
                                                   const int32_t* __restrict__ bin_nodes,
                                                   const int32_t* __restrict__ node_bin,
@@ -151,22 +152,22 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
                                                   int ghost_overlap,
                                                   int overlap, int32_t* __restrict__ sub_n,
                                                   int32_t* __restrict__ sub_nown, int32_t* __restrict__ sub_dofs) {
-    __shared__ int32_t tab[HS];
-    __shared__ int32_t lst[HS];
+    __shared__ int32_t tab[HSZ];
+    __shared__ int32_t lst[HSZ];
     __shared__ int32_t s_cnt, s_prev, s_bad;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int32_t nb = bin_ptr[b];
     const int n_own = bin_ptr[b + 1] - nb;   // the box lists dofs
     const int32_t fb = fbin_ptr ? fbin_ptr[b] : 0;
     const int n_for = fbin_ptr ? fbin_ptr[b + 1] - fb : 0;   // dofs of other ranks' nodes in this box (rows stored here)
-    int32_t* out = sub_dofs + (int64_t)b * NMAX;
-    for (int k = tid; k < n_own && k < NMAX; k += 256) out[k] = bin_nodes[nb + k];
+    int32_t* out = sub_dofs + (int64_t)b * NM;
+    for (int k = tid; k < n_own && k < NM; k += 256) out[k] = bin_nodes[nb + k];
     auto insert = [&](int32_t col) {
-        uint32_t h = ((uint32_t)col * 2654435761u) % HS;
-        for (int probe = 0; probe < HS; ++probe) {
+        uint32_t h = ((uint32_t)col * 2654435761u) % HSZ;
+        for (int probe = 0; probe < HSZ; ++probe) {
             const int32_t old = atomicCAS(&tab[h], -1, col);
             if (old == -1 || old == col) break;
-            h = (h + 1) % HS;
+            h = (h + 1) % HSZ;
         }
     };
     // First with the foreign members: the subdomain is then the WHOLE box plus its overlap, the same on every
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
     // the owned part of the box alone (the rank boundary cuts the box).
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int nf = attempt == 0 ? n_for : 0;
-        for (int k = tid; k < HS; k += 256) tab[k] = -1;
+        for (int k = tid; k < HSZ; k += 256) tab[k] = -1;
         if (tid == 0) {
             s_cnt = 0;
             s_prev = 0;
@@ -207,14 +208,14 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
             __syncthreads();
             if (tid == 0) s_cnt = 0;
             __syncthreads();
-            for (int k = tid; k < HS; k += 256)
+            for (int k = tid; k < HSZ; k += 256)
                 if (tab[k] >= 0) lst[atomicAdd(&s_cnt, 1)] = tab[k];
             __syncthreads();
             if (tid == 0) s_prev = s_cnt;
             __syncthreads();
         }
         if (overlap == 0 && nf > 0) {   // no layer loop ran: list the foreign members
-            for (int k = tid; k < HS; k += 256)
+            for (int k = tid; k < HSZ; k += 256)
                 if (tab[k] >= 0) lst[atomicAdd(&s_cnt, 1)] = tab[k];
             __syncthreads();
             if (tid == 0) s_prev = s_cnt;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
         if (nf == 0) break;
         for (int k = tid; k < s_prev; k += 256)
             if (lst[k] >= n_stored) s_bad = 1;
-        if (tid == 0 && n_own + s_prev > NMAX) s_bad = 1;   // the whole box would not fit the dense solver: cut it
+        if (tid == 0 && n_own + s_prev > NM) s_bad = 1;   // the whole box would not fit the dense solver: cut it
         __syncthreads();
         if (!s_bad) break;
         __syncthreads();
@@ -234,10 +235,10 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
         const int32_t v = lst[k];
         int rank = 0;
         for (int m = 0; m < n_ext; ++m) rank += lst[m] < v ? 1 : 0;
-        if (n_own + rank < NMAX) out[n_own + rank] = v;
+        if (n_own + rank < NM) out[n_own + rank] = v;
     }
-    // the tail of the list is a valid dof id too: the apply kernel reads all NMAX entries
-    for (int k = n_own + n_ext + tid; k < NMAX; k += 256) out[k] = 0;
+    // the tail of the list is a valid dof id too: the apply kernel reads all NM entries
+    for (int k = n_own + n_ext + tid; k < NM; k += 256) out[k] = 0;
     if (tid == 0) {
         sub_n[b] = n_own + n_ext;
         sub_nown[b] = n_own;
@@ -750,7 +751,38 @@ int global_box(fedd_ctx* c, int64_t n_own, double lo[3], double hi[3], double* n
     return 0;
 }
 
+// overlapping dof lists with the 1024-entry stride of the large-subdomain path (schwarz_big.hip): bins in
+// d_bin_ptr / d_bin_nodes / d_node_bin -> d_sub_n / d_sub_nown / d_sub_dofs [nsub * 1024]
+int schwarz_overlap_lists_big(fedd_ctx* c, int64_t nsub, int32_t* max_n, int32_t* max_own) {
+    FEDD_TRY(c->d_sub_n.ensure((size_t)nsub));
+    FEDD_TRY(c->d_sub_nown.ensure((size_t)nsub));
+    FEDD_TRY(c->d_sub_dofs.ensure((size_t)nsub * SCHWARZ_NMAX_BIG));
+    hipLaunchKernelGGL((k_sub_dofs<SCHWARZ_NMAX_BIG, 4096>), dim3((unsigned)nsub), dim3(256), 0, c->stream,
+                       (const int32_t*)c->d_bin_ptr.p, (const int32_t*)c->d_bin_nodes.p, (const int32_t*)c->d_node_bin.p,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)c->d_rowptr.p,
+                       (const int32_t*)c->d_colind.p, (int32_t)c->n_rows, (int32_t)c->n_rows_ext, c->ghost_overlap,
+                       c->sw_overlap, c->d_sub_n.p, c->d_sub_nown.p, c->d_sub_dofs.p);
+    FEDD_TRY(reduce_max_i32(c, c->d_sub_n.p, nsub, max_n));
+    FEDD_TRY(reduce_max_i32(c, c->d_sub_nown.p, nsub, max_own));
+    FEDD_HIP(hipGetLastError());
+    return 0;
+}
+
+// slab offsets (elements) of every subdomain -> d_inv_ptr, total -> sw_inv_elems, d_inv sized
+int schwarz_slab_offsets(fedd_ctx* c, int64_t nsub, int restricted) {
+    FEDD_TRY(c->d_inv_ptr.ensure((size_t)nsub + 1));
+    hipLaunchKernelGGL(k_slab_sizes, dim3((unsigned)((nsub + 255) / 256)), dim3(256), 0, c->stream,
+                       (const int32_t*)c->d_sub_n.p, (const int32_t*)c->d_sub_nown.p, (int32_t)nsub, restricted, c->d_inv_ptr.p);
+    int64_t total = 0;
+    FEDD_TRY(exclusive_scan_i64(c, c->d_inv_ptr.p, c->d_inv_ptr.p, nsub, &total));
+    c->sw_inv_elems = total;
+    FEDD_TRY(c->d_inv.ensure((size_t)total));
+    return 0;
+}
+
 int schwarz_setup(fedd_ctx* c) {
+    if (schwarz_use_big(c)) return schwarz_setup_big(c);
+    c->sw_big_active = false;
     c->have_coarse = false;
     ScopedTimer timer(c, FEDD_T_SCHWARZ_SETUP);
     const int32_t n_own = (int32_t)c->n_own;
@@ -850,7 +882,7 @@ int schwarz_setup(fedd_ctx* c) {
                                (const int32_t*)c->d_fbin_ptr.p, (int32_t)nsub, c->d_fbin_nodes.p);
         }
         // ---- overlapping dof lists ----
-        hipLaunchKernelGGL(k_sub_dofs, dim3((unsigned)nsub), blk, 0, c->stream, (const int32_t*)c->d_bin_ptr.p,
+        hipLaunchKernelGGL((k_sub_dofs<NMAX, HS>), dim3((unsigned)nsub), blk, 0, c->stream, (const int32_t*)c->d_bin_ptr.p,
                            (const int32_t*)c->d_bin_nodes.p, (const int32_t*)c->d_node_bin.p,
                            (const int32_t*)(foreign ? c->d_fbin_ptr.p : nullptr), (const int32_t*)(foreign ? c->d_fbin_nodes.p : nullptr),
                            (const int32_t*)c->d_rowptr.p,
@@ -995,6 +1027,7 @@ int schwarz_setup(fedd_ctx* c) {
 
 // z_owned = M^-1 r_owned
 int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool r_has_tail) {
+    if (c->sw_big_active) return schwarz_apply_big(c, d_r_owned, d_z_owned, r_has_tail);
     const double* r = d_r_owned;
     if (c->n_cols != c->n_rows || !c->halo.peers.empty()) {   // also a rank that only sends takes part
         if (r_has_tail) {   // the caller's buffer takes the ghost values behind its owned entries

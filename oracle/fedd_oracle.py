@@ -873,6 +873,36 @@ def schwarz_bins(xyz: np.ndarray, target: int, scale: float = 1.0):
     return inv.astype(np.int64), uniq.shape[0], g
 
 
+def rcb_bins(xyz_dof: np.ndarray, target: int):
+    """Normative boxes of the product's large-subdomain Schwarz path (feddlib_amd/csrc/schwarz_big.hip): balanced
+    recursive coordinate bisection of the points that carry the dofs -- a part with more than `target` points is
+    split at its median (the first floor(count / 2) points in the order (coordinate, index) go left) along the
+    longest edge of its bounding box (lowest axis on ties); parts are numbered left to right.  Returns
+    (bin of every dof, number of bins)."""
+    n, dim = xyz_dof.shape
+    bins = np.zeros(n, dtype=np.int64)
+    out = []
+
+    def rec(idx):
+        if idx.shape[0] <= target:
+            out.append(idx)
+            return
+        ext = xyz_dof[idx].max(axis=0) - xyz_dof[idx].min(axis=0)
+        ax = 0
+        for d in range(1, dim):
+            if ext[d] > ext[ax]:
+                ax = d
+        order = idx[np.lexsort((idx, xyz_dof[idx, ax]))]
+        h = order.shape[0] // 2
+        rec(order[:h])
+        rec(order[h:])
+
+    rec(np.arange(n))
+    for k, idx in enumerate(out):
+        bins[idx] = k
+    return bins, len(out)
+
+
 class RAS:
     """One-level overlapping additive Schwarz, many subdomains per rank (normative definition,
     DESIGN.md 'Schwarz'): subdomain i = bin_i plus `overlap` graph layers of the (Dirichlet-

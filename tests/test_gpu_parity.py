@@ -169,6 +169,36 @@ def test_schwarz_apply_matches_oracle(fedd_lib, ctx, dim, M, target, combine):
     np.testing.assert_allclose(z, zo, rtol=0, atol=1e-9 * np.abs(zo).max())
 
 
+@pytest.mark.parametrize("dim,M,target,combine", [(3, 10, 150, "restricted"), (3, 9, 90, "averaging"),
+                                                  (2, 40, 600, "full"), (3, 12, 400, "restricted")])
+def test_large_subdomain_path_matches_oracle(fedd_lib, dim, M, target, combine):
+    """The large-subdomain path (schwarz_big.hip: coordinate-bisection boxes, overlapping subdomains of up to 1024
+    dofs, batched blocked Gauss-Jordan inverses on the f64 matrix cores) against the oracle's RAS on the oracle's
+    normative bisection: same boxes, same operator application to 1e-9, and a preconditioned solve."""
+    c = fedd_lib.Context(device=0)
+    try:
+        m, om, A_bc, rhs_bc = _setup_laplace(fedd_lib, c, dim, M)
+        c.set_option("schwarz_big", 1)
+        c.set_option("schwarz_big_target", target)
+        cmb = {"restricted": fedd_lib.COMBINE_RESTRICTED, "averaging": fedd_lib.COMBINE_AVERAGING,
+               "full": fedd_lib.COMBINE_FULL}[combine]
+        c.schwarz_setup(overlap=1, combine=cmb)
+        info = c.schwarz_info()
+        bins, nb = fo.rcb_bins(m["xyz"][:m["gid_uni"].shape[0]], target)
+        ras = fo.RAS(A_bc, bins, nb, overlap=1, combine=combine)
+        assert info["n_subdomains"] == nb and info["max_size"] == ras.max_size
+        assert ras.max_size > 160           # beyond the register-tiled classes of the small path
+        r = np.random.default_rng(5).standard_normal(om.n_global)
+        z, zo = c.schwarz_apply(r), ras.apply(r)
+        np.testing.assert_allclose(z, zo, rtol=0, atol=1e-9 * np.abs(zo).max())
+        x, its, rel = c.gmres(None, rtol=1e-13, max_it=300, restart=100, use_prec=True)
+        xd = fo.direct_solve(A_bc, rhs_bc)
+        assert rel <= 1e-13
+        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
+    finally:
+        c.close()
+
+
 def test_schwarz_one_subdomain_is_direct_solve(fedd_lib, ctx):
     """1 subdomain + exact local solve => M^-1 = A^-1, GMRES converges in one iteration."""
     m, om, A_bc, rhs_bc = _setup_laplace(fedd_lib, ctx, 3, 4)   # 125 dofs < NMAX

@@ -170,3 +170,104 @@ def test_cfg4_block_assembly_on_the_6k_cylinder(fedd_lib, ctx):
     x = np.random.default_rng(4).standard_normal(n)
     np.testing.assert_allclose(ctx.spmv(x), Mo @ x, rtol=0, atol=1e-10 * np.abs(Mo @ x).max())
     print("cfg4 device ms: symbolic %.3f assemble %.3f" % (tm["symbolic"][0], tm["assemble"][0]))
+
+
+def _stokes_system_on_cylinder(fedd_lib, ctx, which, nu):
+    """Stokes::assemble on the DFG cylinder (P2 / P1), merged, with the driver's boundary conditions: no-slip on
+    flags 1 and 4, `parabolic_benchmark` inflow on flag 2 (height 0.41, max velocity 1), flag 3 natural
+    (feddlib/problems/tests/stokes/main.cpp:80-88, 267-296)."""
+    m1 = fedd_lib.read_mesh(os.path.join(GOLD, "DFG3DCylinder_%s.mesh" % which), 3)
+    mv = fedd_lib.p2_of_p1(m1, volume_id=0)
+    n_p, nv = m1["xyz"].shape[0], mv["xyz"].shape[0]
+    ctx.mesh_set_dict(mv)
+    ctx.pattern_build(3, fedd_lib.BLOCK_DIAG)
+    ctx.assemble(fedd_lib.FORM_LAPLACE_VEC)
+    ctx.matrix_scale(-1, nu)
+    ctx.matrix_store(0)
+    ctx.assemble_div(n_p, 1, 2)
+    ctx.matrix_scale(1, -1.0)
+    ctx.matrix_scale(2, -1.0)
+    ctx.block_merge(0, 2, 1, -1)
+    X, flag, H = mv["xyz"], mv["flag_uni"], 0.41
+    nodes = np.nonzero(np.isin(flag, (1, 2, 4)))[0]
+    rows = (3 * nodes[:, None] + np.arange(3)[None, :]).ravel()
+    vals = np.zeros((nodes.shape[0], 3))
+    inflow = flag[nodes] == 2
+    y, z = X[nodes, 1], X[nodes, 2]
+    vals[inflow, 0] = (16.0 * y * (H - y) * z * (H - z) / H ** 4)[inflow]
+    n = 3 * nv + n_p
+    ctx.rhs_set(np.zeros(n))
+    ctx.dirichlet_rows(rows, vals.ravel())
+    return n, nv, n_p
+
+
+@pytest.mark.parametrize("which,combine", [("1k", "restricted"), ("1k", "averaging")])
+def test_stokes_monolithic_schwarz_matches_oracle_on_the_1k_cylinder(fedd_lib, which, combine):
+    """monolithic one-level Schwarz on the merged Stokes system: boxes, operator application and solve against the
+    oracle (scipy) on the reference's 1k cylinder mesh"""
+    c = fedd_lib.Context(device=0)
+    try:
+        n, nv, n_p = _stokes_system_on_cylinder(fedd_lib, c, which, 1.0)
+        rowptr, col, val, gid = c.csr_get()
+        M = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+        b = c.rhs_get()
+        cmb = {"restricted": fedd_lib.COMBINE_RESTRICTED, "averaging": fedd_lib.COMBINE_AVERAGING}[combine]
+        c.schwarz_setup(overlap=1, combine=cmb)        # merged system: the large-subdomain path is the default
+        info = c.schwarz_info()
+        m1 = fedd_lib.read_mesh(os.path.join(GOLD, "DFG3DCylinder_%s.mesh" % which), 3)
+        mv = fedd_lib.p2_of_p1(m1, volume_id=0)
+        xyz_dof = np.concatenate([np.repeat(mv["xyz"], 3, axis=0), m1["xyz"]], axis=0)
+        target = 120
+        G = M.copy()
+        G.data[:] = 1.0
+        while True:       # the library lowers the target (x 0.7) until every overlapping subdomain fits 1024 dofs
+            bins, nb = fo.rcb_bins(xyz_dof, target)
+            P0 = sp.csr_matrix((np.ones(n), (np.arange(n), bins)), shape=(n, nb))
+            sizes = np.asarray(((G @ P0 + P0) > 0).sum(axis=0)).ravel()      # box + one graph layer
+            if sizes.max() <= 1024:
+                break
+            target = max(1, int(target * 0.7))
+        ras = fo.RAS(M, bins, nb, overlap=1, combine=combine)
+        assert info["n_subdomains"] == nb and info["max_size"] == ras.max_size and 256 < ras.max_size <= 1024
+        r = np.random.default_rng(9).standard_normal(n)
+        z, zo = c.schwarz_apply(r), ras.apply(r)
+        np.testing.assert_allclose(z, zo, rtol=0, atol=1e-8 * np.abs(zo).max())
+        x, its, rel = c.gmres(None, rtol=1e-12, max_it=1500, restart=300, use_prec=True)
+        assert rel <= 1e-12
+        xd = fo.direct_solve(M, b)
+        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+    finally:
+        c.close()
+
+
+def test_cfg4_stokes_solve_on_the_6k_cylinder(fedd_lib):
+    """cfg 4 of BASELINE.json end to end: P2/P1 Stokes on DFG3DCylinder_6k.mesh (141 742 dofs), merged saddle-point
+    system, GMRES + monolithic one-level Schwarz (overlapping subdomains of several hundred dofs, exact local solves)
+    against a sparse direct solve of the same system."""
+    c = fedd_lib.Context(device=0)
+    try:
+        n, nv, n_p = _stokes_system_on_cylinder(fedd_lib, c, "6k", 1.0)
+        assert n == 141742
+        c.timing_enable(True)
+        c.timing_reset()
+        c.schwarz_setup(overlap=1, combine=fedd_lib.COMBINE_RESTRICTED)
+        info = c.schwarz_info()
+        assert 256 < info["max_size"] <= 1024
+        x, its, rel = c.gmres(None, rtol=1e-12, max_it=3000, restart=300, use_prec=True)
+        tm = c.timing_get()
+        print("cfg4: %d subdomains, largest %d dofs, %d GMRES iterations, relres %.2e; device ms: Schwarz setup %.1f, "
+              "apply %.1f, SpMV %.1f, orthogonalisation %.1f"
+              % (info["n_subdomains"], info["max_size"], its, rel, tm["schwarz_setup"][0], tm["schwarz_apply"][0],
+                 tm["spmv"][0], tm["ortho"][0]))
+        assert rel <= 1e-12
+        rowptr, col, val, gid = c.csr_get()
+        M = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+        b = c.rhs_get()
+        assert np.linalg.norm(b - M @ x) / np.linalg.norm(b) <= 1e-11
+        xd = fo.direct_solve(M, b)
+        err = np.abs(x - xd).max() / np.abs(xd).max()
+        assert err <= 1e-9, err
+        # velocity and pressure separately (the pressure is the badly scaled part of the vector)
+        assert np.abs(x[3 * nv:] - xd[3 * nv:]).max() <= 1e-8 * np.abs(xd[3 * nv:]).max()
+    finally:
+        c.close()
