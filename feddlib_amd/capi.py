@@ -19,6 +19,7 @@ COMBINE_RESTRICTED, COMBINE_AVERAGING, COMBINE_FULL = range(3)
 TIMER_NAMES = ["symbolic", "assemble", "rhs", "dirichlet", "spmv", "schwarz_setup", "schwarz_apply", "ortho",
                "coarse_setup", "coarse_apply", "halo", "allreduce", "spmv_setup"]
 COARSE_Q1 = 1
+COARSE_GDSW = 2
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)

@@ -542,14 +542,16 @@ extern "C" int fedd_schwarz_setup(fedd_ctx* c, int overlap, int combine, int two
     FEDD_CHECK(c->have_pattern, "fedd_schwarz_setup: assemble the matrix first");
     FEDD_CHECK(overlap >= 0 && overlap <= 4, "fedd_schwarz_setup: overlap %d", overlap);
     FEDD_CHECK(combine >= 0 && combine <= 2, "fedd_schwarz_setup: combine mode %d", combine);
-    FEDD_CHECK(two_level == 0 || coarse_kind == FEDD_COARSE_Q1,
-               "fedd_schwarz_setup: coarse_kind %d is not built (FEDD_COARSE_Q1 = %d is)", coarse_kind, FEDD_COARSE_Q1);
+    FEDD_CHECK(two_level == 0 || coarse_kind == FEDD_COARSE_Q1 || coarse_kind == FEDD_COARSE_GDSW,
+               "fedd_schwarz_setup: coarse_kind %d is not built (FEDD_COARSE_Q1 = %d and FEDD_COARSE_GDSW = %d are)", coarse_kind,
+               FEDD_COARSE_Q1, FEDD_COARSE_GDSW);
     FEDD_CHECK(two_level == 0 || !c->merged,
                "fedd_schwarz_setup: the coarse level takes node-interleaved systems, not a merged block system");
     FEDD_HIP(hipSetDevice(c->device));
     c->sw_overlap = overlap;
     c->sw_combine = combine;
     c->sw_two_level = two_level ? 1 : 0;
+    if (two_level) c->co_kind = coarse_kind;
     return schwarz_setup(c);
 }
 
@@ -652,7 +654,10 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
         c->cs_valid = false;
     }
     else if (k == "whole_boxes") c->whole_boxes = (int)value;
-    else if (k == "schwarz_big") c->sw_big = (int)value;
+    else if (k == "gdsw_tol") {
+        FEDD_CHECK(value > 0.0 && value < 1.0, "fedd_set_option: gdsw_tol %g", value);
+        c->gdsw_tol = value;
+    } else if (k == "schwarz_big") c->sw_big = (int)value;
     else if (k == "schwarz_big_target") c->sw_big_target = (int)value;
     else if (k == "asm_kind") c->asm_kind = (int)value;
     else if (k == "asm_u") c->asm_u = (int)value;

@@ -19,6 +19,7 @@
 // Apply: cell-wise restriction (fixed summation order), dense K0^-1 r0, prolongation.
 #include "fedd_internal.hpp"
 #include <algorithm>
+#include <climits>
 #include <cmath>
 
 namespace fedd {
@@ -304,6 +305,297 @@ __global__ __launch_bounds__(256) void k_fix_diag(double* __restrict__ K, int64_
 
 // (the blocked Gauss-Jordan inversion of K0 on the f64 matrix cores lives in dense.hip: dense_invert_batched)
 
+
+// =====================================================================================================
+// GDSW coarse space (coarse_kind FEDD_COARSE_GDSW): FROSch's GDSWCoarseOperator
+// (feddlib/problems/tests/laplace/parametersPrec.xml:13-23, 62-122; handed over by Preconditioner_def.hpp:379-423),
+// on a second, coarse decomposition: the cells of the lattice that also carries the Q1 space.
+//   * every element belongs to the lattice cell of its centroid; the cells a node's elements lie in span the index
+//     box [imin, imax]; the node's interface ENTITY has the coordinates e_d = imin_d + imax_d in the doubled lattice
+//     (0 .. 2 g_d - 2): e_d odd = "between cells i and i + 1 in direction d".  All e_d even: interior of cell e / 2.
+//     One odd e_d: face, two: edge, three: vertex (3D) -- the interface components GDSW classifies;
+//   * Phi_Gamma: one function per (entity, null-space vector): the null-space vector restricted to the entity.  The null
+//     space is what FROSch uses without node coordinates ("Use node lists" = false, laplace/parametersPrec.xml:5):
+//     the constant per dof component (translations);
+//   * Phi_I = -K_II^-1 K_IGamma Phi_Gamma, the discrete harmonic (energy-minimising) extension into the cell
+//     interiors: the interiors of different cells are not coupled, and a cell sees exactly one entity of each of the
+//     3^dim - 1 CLASSES (per direction: e_d even / e_d = 1 mod 4 / e_d = 3 mod 4), so one constrained solve per
+//     (class, component) extends all entities of the class at once.  The solves run on the device with the
+//     library's own GMRES + one-level Schwarz on the constrained operator (gmres.hip, gm_mask) to `gdsw_tol`
+//     (default 1e-10): an iterative interior solver in place of FROSch's direct ExtensionSolver;
+//   * K0 = Phi^T K Phi, column by colour: entities whose coordinates agree modulo 5 in every direction have supports
+//     that no row couples, so one prolongation - SpMV - restriction gives one column of K0 for all of them;
+//     K0 is inverted by the matrix-core sweep of dense.hip and replicated, exactly like the Q1 level.
+// Storage: Phi[row][slot], slot = class * dofs + k, 3^dim - 1 classes: for the rows of cell h the entry belongs to the
+// entity of that class that h sees; an interface row keeps its single 1 in the class of its own entity (home cell
+// h = floor(e / 2) sees it).
+// =====================================================================================================
+template <int DIM> struct GdswCfg { static constexpr int NCLS = DIM == 3 ? 26 : 8; };
+
+// class code of an entity coordinate: 0 even, 1 = 1 mod 4, 2 = 3 mod 4
+__device__ __forceinline__ int gd_code(int e) { return (e & 1) ? ((e & 3) == 1 ? 1 : 2) : 0; }
+
+// class index 0 .. 3^DIM - 2 of entity e (-1: cell interior)
+template <int DIM>
+__device__ __forceinline__ int gd_class(const int e[3]) {
+    int s = 0, mul = 1;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        s += mul * gd_code(e[d]);
+        mul *= 3;
+    }
+    return s - 1;
+}
+
+// entity of class `cls` seen from cell h; false if it lies outside the lattice
+template <int DIM>
+__device__ __forceinline__ bool gd_entity_of(const CoarseGeom& cg, const int h[3], int cls, int e[3]) {
+    int s = cls + 1;
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        const int code = s % 3;
+        s /= 3;
+        if (code == 0) e[d] = 2 * h[d];
+        else e[d] = ((h[d] & 1) == 0) == (code == 1) ? 2 * h[d] + 1 : 2 * h[d] - 1;
+        ok = ok && e[d] >= 0 && e[d] <= 2 * cg.g[d] - 2;
+    }
+    return ok;
+}
+
+template <int DIM>
+__device__ __forceinline__ int32_t gd_entity_id(const CoarseGeom& cg, const int e[3]) {
+    int32_t id = 0, mul = 1;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        id += mul * e[d];
+        mul *= 2 * cg.g[d] - 1;
+    }
+    return id;
+}
+
+template <int DIM>
+__device__ __forceinline__ void gd_entity_coords(const CoarseGeom& cg, int32_t id, int e[3]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) e[d] = 0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        const int m = 2 * cg.g[d] - 1;
+        e[d] = id % m;
+        id /= m;
+    }
+}
+
+// entity and home cell of every owned node from the cells of its incident elements
+template <int DIM>
+__global__ void k_gd_node_entity(CoarseGeom cg, const int32_t* __restrict__ conn, int nen, const double* __restrict__ xyz,
+                                 const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e, int32_t n_own,
+                                 int32_t* __restrict__ ent, int32_t* __restrict__ key, int32_t* __restrict__ val) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_own) return;
+    int imin[3] = {INT_MAX, INT_MAX, INT_MAX}, imax[3] = {-1, -1, -1};
+    for (int32_t p = n2e_ptr[i]; p < n2e_ptr[i + 1]; ++p) {
+        const int32_t e = n2e[p] / nen;
+        double cen[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) cen[d] = 0.0;
+        for (int v = 0; v <= DIM; ++v) {
+            const int32_t nd = conn[(int64_t)e * nen + v];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) cen[d] += xyz[(int64_t)nd * DIM + d];
+        }
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            const double t = (cen[d] / (DIM + 1) - cg.lo[d]) / cg.L[d] * (double)cg.g[d];
+            int ic = (int)floor(t);
+            ic = min(cg.g[d] - 1, max(0, ic));
+            imin[d] = min(imin[d], ic);
+            imax[d] = max(imax[d], ic);
+        }
+    }
+    int e3[3] = {0, 0, 0}, h[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        if (imax[d] < 0) imin[d] = imax[d] = 0;   // a node without elements: interior of cell 0
+        e3[d] = imin[d] + imax[d];
+        h[d] = e3[d] >> 1;
+    }
+    ent[i] = gd_entity_id<DIM>(cg, e3);
+    key[i] = cell_of<DIM>(cg, h);
+    val[i] = i;
+}
+
+// Phi <- Phi_Gamma (interface rows: 1 in the class of their own entity, component a; Dirichlet rows 0), interior
+// rows 0; imask = 1 on free interior dofs (the unknowns of the extension solves), 0 elsewhere
+template <int DIM>
+__global__ void k_gd_phi_init(CoarseGeom cg, const int32_t* __restrict__ ent, int dofs, int64_t n_rows,
+                              const double* __restrict__ mask, double* __restrict__ phi, double* __restrict__ imask) {
+    constexpr int NCLS = GdswCfg<DIM>::NCLS;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int32_t node = (int32_t)(r / dofs);
+    const int a = (int)(r - (int64_t)node * dofs);
+    int e[3];
+    gd_entity_coords<DIM>(cg, ent[node], e);
+    const int cls = gd_class<DIM>(e);
+    const int nsd = NCLS * dofs;
+    for (int s = 0; s < nsd; ++s) phi[r * nsd + s] = 0.0;
+    if (cls >= 0) phi[r * nsd + cls * dofs + a] = mask[r];
+    imask[r] = cls < 0 ? mask[r] : 0.0;
+}
+
+// v = column (cls, k) of Phi on the interface rows, 0 on the interior rows
+__global__ void k_gd_gamma_col(const double* __restrict__ phi, const double* __restrict__ imask, int64_t n_rows, int nsd,
+                               int slot, const double* __restrict__ mask, double* __restrict__ v) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    v[r] = (imask[r] == 0.0 && mask[r] != 0.0) ? phi[r * nsd + slot] : 0.0;
+}
+
+// b = -imask o w
+__global__ void k_gd_rhs(const double* __restrict__ imask, const double* __restrict__ w, int64_t n_rows, double* __restrict__ b) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows) b[r] = imask[r] != 0.0 ? -w[r] : 0.0;
+}
+
+// interior rows: Phi[r][slot] = x[r]
+__global__ void k_gd_store(const double* __restrict__ imask, const double* __restrict__ x, int64_t n_rows, int nsd, int slot,
+                           double* __restrict__ phi) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows && imask[r] != 0.0) phi[r * nsd + slot] = x[r];
+}
+
+// restriction, step 1: per home cell the sums over its rows of Phi[r][slot] * rv[r], slot chunk `blockIdx.y` of 16,
+// fixed-order workgroup reduction (same pattern as k_restrict_cells)
+__global__ __launch_bounds__(256) void k_gd_restrict_cells(const int32_t* __restrict__ cell_ptr,
+                                                           const int32_t* __restrict__ cell_nodes, int dofs, int nsd,
+                                                           const double* __restrict__ phi, const double* __restrict__ rv,
+                                                           double* __restrict__ part) {
+    constexpr int CH = 16;
+    __shared__ double red[4][CH];
+    const int cell = blockIdx.x, s0 = blockIdx.y * CH, tid = threadIdx.x;
+    double acc[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) acc[q] = 0.0;
+    const int32_t b = cell_ptr[cell], e = cell_ptr[cell + 1];
+    for (int64_t item = (int64_t)b * dofs + tid; item < (int64_t)e * dofs; item += 256) {
+        const int32_t node = cell_nodes[item / dofs];
+        const int64_t r = (int64_t)node * dofs + item % dofs;
+        const double x = rv[r];
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+            if (s0 + q < nsd) acc[q] = fma(phi[r * nsd + s0 + q], x, acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+        double v = acc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6][q] = v;
+    }
+    __syncthreads();
+    if (tid < CH && s0 + tid < nsd) part[(int64_t)cell * nsd + s0 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+// restriction, step 2: r0[(E, k)] = sum over the cells that see E (fixed order) of their class(E) partial sum
+template <int DIM>
+__global__ void k_gd_restrict_ent(CoarseGeom cg, int dofs, int64_t n_ent, const double* __restrict__ part,
+                                  double* __restrict__ r0) {
+    constexpr int NCLS = GdswCfg<DIM>::NCLS;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_ent * dofs) return;
+    const int32_t E = (int32_t)(t / dofs);
+    const int k = (int)(t - (int64_t)E * dofs);
+    int e[3];
+    gd_entity_coords<DIM>(cg, E, e);
+    const int cls = gd_class<DIM>(e);
+    double sum = 0.0;
+    if (cls >= 0) {
+        // cells h with |2 h_d - e_d| <= 1: e_d even -> h_d = e_d / 2; odd -> (e_d - 1) / 2 and (e_d + 1) / 2
+        for (int a = 0; a < (1 << DIM); ++a) {
+            int h[3] = {0, 0, 0};
+            bool ok = true;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) {
+                const int bit = (a >> d) & 1;
+                if (e[d] & 1) h[d] = (e[d] - 1) / 2 + bit;
+                else {
+                    h[d] = e[d] / 2;
+                    ok = ok && bit == 0;
+                }
+                ok = ok && h[d] >= 0 && h[d] < cg.g[d];
+            }
+            if (ok) sum += part[(int64_t)cell_of<DIM>(cg, h) * (NCLS * dofs) + cls * dofs + k];
+        }
+    }
+    r0[t] = sum;
+}
+
+// prolongation: z[r] (+)= mask[r] * sum_slots Phi[r][slot] * z0[entity(home(r), class)][k]
+template <int DIM, bool ADD>
+__global__ void k_gd_prolong(CoarseGeom cg, const int32_t* __restrict__ ent, int dofs, int64_t n_rows,
+                             const double* __restrict__ phi, const double* __restrict__ mask,
+                             const double* __restrict__ z0, double* __restrict__ z) {
+    constexpr int NCLS = GdswCfg<DIM>::NCLS;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int32_t node = (int32_t)(r / dofs);
+    int e[3], h[3] = {0, 0, 0};
+    gd_entity_coords<DIM>(cg, ent[node], e);
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) h[d] = e[d] >> 1;
+    const int nsd = NCLS * dofs;
+    double sum = 0.0;
+    for (int cls = 0; cls < NCLS; ++cls) {
+        int ee[3] = {0, 0, 0};
+        if (!gd_entity_of<DIM>(cg, h, cls, ee)) continue;
+        const int64_t E = gd_entity_id<DIM>(cg, ee);
+        for (int k = 0; k < dofs; ++k) sum = fma(phi[r * nsd + cls * dofs + k], z0[E * dofs + k], sum);
+    }
+    if (ADD) z[r] += sum * mask[r];
+    else z[r] = sum * mask[r];
+}
+
+// z0 = sum of the unit vectors (E, k) over the interface entities E of one colour (e_d = col_d mod 5)
+struct GdCol { int c[3]; };
+
+template <int DIM>
+__global__ void k_gd_colour(CoarseGeom cg, int dofs, int64_t n_ent, int k, GdCol col, double* __restrict__ z0) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_ent * dofs) return;
+    const int32_t E = (int32_t)(t / dofs);
+    const int kk = (int)(t - (int64_t)E * dofs);
+    int e[3];
+    gd_entity_coords<DIM>(cg, E, e);
+    bool on = kk == k && gd_class<DIM>(e) >= 0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) on = on && (e[d] % 5) == col.c[d];
+    z0[t] = on ? 1.0 : 0.0;
+}
+
+// K0[(E, a)][(E', k)] = r0[(E, a)] with E' the entity of the colour within two lattice steps of E
+template <int DIM>
+__global__ void k_gd_scatter_col(CoarseGeom cg, int dofs, int64_t n_ent, int k, GdCol col, const double* __restrict__ r0,
+                                 double* __restrict__ K, int64_t ld) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_ent * dofs) return;
+    const int32_t E = (int32_t)(t / dofs);
+    int e[3], ep[3] = {0, 0, 0};
+    gd_entity_coords<DIM>(cg, E, e);
+    if (gd_class<DIM>(e) < 0) return;
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        int dlt = (col.c[d] - e[d] % 5 + 5) % 5;   // 0 .. 4
+        if (dlt > 2) dlt -= 5;                     // -2 .. 2
+        ep[d] = e[d] + dlt;
+        ok = ok && ep[d] >= 0 && ep[d] <= 2 * cg.g[d] - 2;
+    }
+    if (!ok || gd_class<DIM>(ep) < 0) return;
+    const int64_t Ep = gd_entity_id<DIM>(cg, ep);
+    K[t * ld + Ep * dofs + k] = r0[t];
+}
+
 // ---- apply ----
 template <int DIM, int DOFS>
 __global__ __launch_bounds__(256) void k_restrict_cells(CoarseGeom cg, const int32_t* __restrict__ cell_ptr,
@@ -427,7 +719,211 @@ __global__ void k_prolong_add(CoarseGeom cg, int dofs, int64_t n_rows, const dou
         else { KERNEL(2, __VA_ARGS__); }             \
     } while (0)
 
+
+// ---- GDSW: setup and application (kernels and definitions: "GDSW coarse space" above) ----
+static int gdsw_restrict(fedd_ctx* c, const double* d_rv, double* d_r0) {
+    const int dim = c->dim, dofs = c->dofs;
+    const CoarseGeom cg = c->co_geom;
+    const int ncls = dim == 3 ? 26 : 8, nsd = ncls * dofs;
+    const int64_t ncell = c->co_ncell, n_ent = c->co_nlat;
+    hipLaunchKernelGGL(k_gd_restrict_cells, dim3((unsigned)ncell, (unsigned)((nsd + 15) / 16)), dim3(256), 0, c->stream,
+                       (const int32_t*)c->d_co_cell_ptr.p, (const int32_t*)c->d_co_val[c->co_sorted].p, dofs, nsd,
+                       (const double*)c->d_gd_phi.p, d_rv, c->d_co_part.p);
+    const dim3 ge((unsigned)((n_ent * dofs + 255) / 256)), blk(256);
+    if (dim == 3) hipLaunchKernelGGL(k_gd_restrict_ent<3>, ge, blk, 0, c->stream, cg, dofs, n_ent, (const double*)c->d_co_part.p, d_r0);
+    else hipLaunchKernelGGL(k_gd_restrict_ent<2>, ge, blk, 0, c->stream, cg, dofs, n_ent, (const double*)c->d_co_part.p, d_r0);
+    return 0;
+}
+
+template <bool ADD>
+static int gdsw_prolong(fedd_ctx* c, const double* d_z0, double* d_z) {
+    const CoarseGeom cg = c->co_geom;
+    const dim3 gr((unsigned)((c->n_rows + 255) / 256)), blk(256);
+    if (c->dim == 3)
+        hipLaunchKernelGGL((k_gd_prolong<3, ADD>), gr, blk, 0, c->stream, cg, (const int32_t*)c->d_gd_ent.p, c->dofs, c->n_rows,
+                           (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, d_z0, d_z);
+    else
+        hipLaunchKernelGGL((k_gd_prolong<2, ADD>), gr, blk, 0, c->stream, cg, (const int32_t*)c->d_gd_ent.p, c->dofs, c->n_rows,
+                           (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, d_z0, d_z);
+    return 0;
+}
+
+static int gdsw_setup(fedd_ctx* c) {
+    ScopedTimer timer(c, FEDD_T_COARSE_SETUP);
+    const int dim = c->dim, dofs = c->dofs;
+    const int32_t n_own = (int32_t)c->n_own;
+    const int64_t n_rows = c->n_rows;
+    FEDD_CHECK(n_own > 0 && dofs >= 1 && dofs <= MAX_DOFS, "GDSW setup: %d owned nodes, %d dofs per node", n_own, dofs);
+    FEDD_CHECK(c->have_adj, "GDSW setup: no node -> element adjacency (fedd_pattern_build first)");
+    FEDD_CHECK(n_rows == (int64_t)n_own * dofs, "GDSW setup: node-interleaved systems only");
+    double lo[3], hi[3], n_global = 0.0;
+    FEDD_TRY(global_box(c, n_own, lo, hi, &n_global));
+    // ---- the coarse decomposition: cells of a regular lattice, g_d = max(1, floor(L_d / H + 0.5)) ----
+    // default: one cell per 1000 nodes, at most 8^3 (scalar) / 5^3 (vector) cells: (2 g - 1)^dim * dofs coarse dofs
+    double target = c->co_cells_target;
+    if (!(target > 0)) target = std::min(dofs == 1 ? 512.0 : 125.0, std::max(1.0, std::floor(n_global / 1000.0)));
+    CoarseGeom cg;
+    cg.dim = dim;
+    double V = 1.0;
+    for (int d = 0; d < dim; ++d) V *= (hi[d] - lo[d] > 0 ? hi[d] - lo[d] : 1.0);
+    const double H = std::pow(V / target, 1.0 / dim);
+    int64_t ncell = 1, n_ent = 1;
+    for (int d = 0; d < 3; ++d) {
+        cg.g[d] = 1;
+        cg.np[d] = 1;
+        cg.lo[d] = 0.0;
+        cg.L[d] = 1.0;
+        if (d >= dim) continue;
+        const double Ld = hi[d] - lo[d];
+        cg.lo[d] = lo[d];
+        cg.L[d] = Ld > 0 ? Ld : 1.0;
+        int g = (int)std::floor(cg.L[d] / H + 0.5);
+        if (g < 1 || !(Ld > 0)) g = 1;
+        cg.g[d] = g;
+        cg.np[d] = g + 1;
+        ncell *= g;
+        n_ent *= 2 * g - 1;
+    }
+    const int64_t n0 = n_ent * dofs;
+    FEDD_CHECK(n0 <= COARSE_MAX_DOFS, "GDSW setup: %lld coarse dofs ((2g - 1)^dim entities x %d), the dense coarse solver takes at "
+               "most %d; lower fedd_schwarz_set_coarse (now %g cells)", (long long)n0, dofs, COARSE_MAX_DOFS, target);
+    const int64_t ld = (n0 + NB - 1) / NB * NB;
+    c->co_geom = cg;
+    c->co_ncell = ncell;
+    c->co_nlat = n_ent;     // (the coarse index space: entities of the doubled lattice)
+    c->co_n0 = n0;
+    c->co_ld = ld;
+    const int ncls = dim == 3 ? 26 : 8, nsd = ncls * dofs;
+    const dim3 blk(256), gn((n_own + 255) / 256), gr((unsigned)((n_rows + 255) / 256));
+    // ---- entity and home cell of every owned node; nodes grouped by home cell (stable radix split) ----
+    for (int q = 0; q < 2; ++q) {
+        FEDD_TRY(c->d_co_key[q].ensure((size_t)n_own));
+        FEDD_TRY(c->d_co_val[q].ensure((size_t)n_own));
+    }
+    FEDD_TRY(c->d_co_cell_ptr.ensure((size_t)ncell + 1));
+    FEDD_TRY(c->d_itmp0.ensure((size_t)n_own));
+    FEDD_TRY(c->d_gd_ent.ensure((size_t)n_own));
+    if (dim == 3)
+        hipLaunchKernelGGL(k_gd_node_entity<3>, gn, blk, 0, c->stream, cg, (const int32_t*)c->d_conn.p, c->nen, (const double*)c->d_xyz.p,
+                           (const int32_t*)c->d_n2e_ptr.p, (const int32_t*)c->d_n2e.p, n_own, c->d_gd_ent.p, c->d_co_key[0].p, c->d_co_val[0].p);
+    else
+        hipLaunchKernelGGL(k_gd_node_entity<2>, gn, blk, 0, c->stream, cg, (const int32_t*)c->d_conn.p, c->nen, (const double*)c->d_xyz.p,
+                           (const int32_t*)c->d_n2e_ptr.p, (const int32_t*)c->d_n2e.p, n_own, c->d_gd_ent.p, c->d_co_key[0].p, c->d_co_val[0].p);
+    int cur = 0;
+    for (int bit = 0; ((int64_t)1 << bit) < ncell; ++bit) {
+        hipLaunchKernelGGL(k_split_flags, gn, blk, 0, c->stream, (const int32_t*)c->d_co_key[cur].p, n_own, bit, c->d_itmp0.p);
+        FEDD_TRY(exclusive_scan_i32(c, c->d_itmp0.p, c->d_itmp0.p, n_own, nullptr));
+        hipLaunchKernelGGL(k_split_scatter, gn, blk, 0, c->stream, (const int32_t*)c->d_co_key[cur].p,
+                           (const int32_t*)c->d_co_val[cur].p, (const int32_t*)c->d_itmp0.p, n_own, bit,
+                           c->d_co_key[1 - cur].p, c->d_co_val[1 - cur].p);
+        cur = 1 - cur;
+    }
+    c->co_sorted = cur;
+    hipLaunchKernelGGL(k_cell_bounds, gn, blk, 0, c->stream, (const int32_t*)c->d_co_key[cur].p, n_own, (int32_t)ncell,
+                       c->d_co_cell_ptr.p);
+    // ---- Dirichlet mask over the column space ----
+    FEDD_TRY(c->d_co_mask.ensure((size_t)c->n_cols));
+    FEDD_TRY(c->d_flags.ensure(16));
+    int32_t* d_bad = c->d_flags.p + 3;
+    FEDD_HIP(hipMemsetAsync(d_bad, 0, 3 * sizeof(int32_t), c->stream));
+    hipLaunchKernelGGL(k_mask, gr, blk, 0, c->stream, (const int32_t*)c->d_isdir.p, n_rows, c->d_co_mask.p, d_bad + 2);
+    if (c->n_cols != c->n_rows || !c->halo.peers.empty()) FEDD_TRY(halo_import(c, c->d_co_mask.p, dofs));
+    // ---- Phi_Gamma, then the harmonic extensions: one constrained solve per (class, component) ----
+    FEDD_TRY(c->d_gd_phi.ensure((size_t)n_rows * nsd));
+    FEDD_TRY(c->d_gd_imask.ensure((size_t)n_rows));
+    const int64_t nc = (std::max<int64_t>(n_rows, c->n_cols) + 15) & ~(int64_t)15;
+    FEDD_TRY(c->d_gd_tmp.ensure((size_t)nc + 3 * (size_t)n_rows));
+    double* v = c->d_gd_tmp.p;              // [nc] column-space vector (ghost tail)
+    double* w = v + nc;
+    double* b = w + n_rows;
+    double* x = b + n_rows;
+    if (dim == 3) hipLaunchKernelGGL(k_gd_phi_init<3>, gr, blk, 0, c->stream, cg, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, (const double*)c->d_co_mask.p, c->d_gd_phi.p, c->d_gd_imask.p);
+    else hipLaunchKernelGGL(k_gd_phi_init<2>, gr, blk, 0, c->stream, cg, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, (const double*)c->d_co_mask.p, c->d_gd_phi.p, c->d_gd_imask.p);
+    FEDD_TRY(c->d_co_part.ensure((size_t)ncell * nsd));
+    FEDD_TRY(c->d_co_r0.ensure(std::max<size_t>((size_t)ld, c->d_co_r0.cap)));
+    FEDD_TRY(c->d_co_z0.ensure((size_t)ld));
+    int its_max = 0;
+    double rel_max = 0.0;
+    for (int slot = 0; slot < nsd; ++slot) {
+        FEDD_HIP(hipMemsetAsync(v, 0, (size_t)nc * sizeof(double), c->stream));
+        hipLaunchKernelGGL(k_gd_gamma_col, gr, blk, 0, c->stream, (const double*)c->d_gd_phi.p, (const double*)c->d_gd_imask.p, n_rows,
+                           nsd, slot, (const double*)c->d_co_mask.p, v);
+        FEDD_TRY(spmv_owned(c, v, w, true));
+        hipLaunchKernelGGL(k_gd_rhs, gr, blk, 0, c->stream, (const double*)c->d_gd_imask.p, (const double*)w, n_rows, b);
+        int its = 0;
+        double rel = 0.0;
+        c->gm_mask = c->d_gd_imask.p;
+        const int rc = gmres_solve(c, b, x, c->gdsw_tol, 1000, 100, 1, &its, &rel);
+        c->gm_mask = nullptr;
+        if (rc) return rc;
+        its_max = std::max(its_max, its);
+        rel_max = std::max(rel_max, rel);
+        hipLaunchKernelGGL(k_gd_store, gr, blk, 0, c->stream, (const double*)c->d_gd_imask.p, (const double*)x, n_rows, nsd, slot, c->d_gd_phi.p);
+    }
+    c->gdsw_ext_its = its_max;
+    c->gdsw_ext_rel = rel_max;
+    FEDD_CHECK(rel_max <= std::max(1e3 * c->gdsw_tol, 1e-6), "GDSW setup: an extension solve stopped at relative residual %.2e "
+               "(tolerance %.1e)", rel_max, c->gdsw_tol);
+    // ---- K0 = Phi^T A Phi, a colour (entity coordinates modulo 5) and a component at a time ----
+    FEDD_TRY(c->d_co_K.ensure((size_t)ld * ld));
+    FEDD_HIP(hipMemsetAsync(c->d_co_K.p, 0, (size_t)ld * ld * sizeof(double), c->stream));
+    const dim3 ge((unsigned)((n0 + 255) / 256));
+    int ncol[3] = {1, 1, 1};
+    for (int d = 0; d < dim; ++d) ncol[d] = std::min(5, 2 * cg.g[d] - 1);
+    for (int c2 = 0; c2 < ncol[2]; ++c2)
+        for (int c1 = 0; c1 < ncol[1]; ++c1)
+            for (int c0 = 0; c0 < ncol[0]; ++c0)
+                for (int k = 0; k < dofs; ++k) {
+                    GdCol col;
+                    col.c[0] = c0; col.c[1] = c1; col.c[2] = c2;
+                    if (dim == 3) hipLaunchKernelGGL(k_gd_colour<3>, ge, blk, 0, c->stream, cg, dofs, n_ent, k, col, c->d_co_z0.p);
+                    else hipLaunchKernelGGL(k_gd_colour<2>, ge, blk, 0, c->stream, cg, dofs, n_ent, k, col, c->d_co_z0.p);
+                    FEDD_HIP(hipMemsetAsync(v, 0, (size_t)nc * sizeof(double), c->stream));
+                    FEDD_TRY(gdsw_prolong<false>(c, c->d_co_z0.p, v));
+                    FEDD_TRY(spmv_owned(c, v, w, true));
+                    FEDD_TRY(gdsw_restrict(c, w, c->d_co_r0.p));
+                    if (c->nranks > 1) FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, (int)n0));
+                    if (dim == 3) hipLaunchKernelGGL(k_gd_scatter_col<3>, ge, blk, 0, c->stream, cg, dofs, n_ent, k, col, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
+                    else hipLaunchKernelGGL(k_gd_scatter_col<2>, ge, blk, 0, c->stream, cg, dofs, n_ent, k, col, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
+                }
+    hipLaunchKernelGGL(k_fix_diag, dim3((unsigned)((ld + 3) / 4)), blk, 0, c->stream, c->d_co_K.p, ld, n0);
+    FEDD_TRY(dense_invert_batched(c, c->d_co_K.p, ld, 1, ld * ld, nullptr, (int)(ld / NB), 1, d_bad + 1));
+    int32_t bad[3] = {0, 0, 0};
+    FEDD_HIP(hipMemcpyAsync(bad, d_bad, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    if (c->nranks > 1) {
+        double hb = (double)bad[1];
+        FEDD_HIP(hipMemcpyAsync(c->d_co_r0.p, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
+        FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, 1));
+        FEDD_HIP(hipMemcpyAsync(&hb, c->d_co_r0.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        bad[1] = hb != 0.0;
+    }
+    FEDD_CHECK(!bad[1], "GDSW setup: K0 is not positive definite (the interior extensions were not solved well enough, or the "
+                        "matrix is not SPD on its free dofs)");
+    FEDD_HIP(hipGetLastError());
+    c->have_coarse = true;
+    return 0;
+}
+
+static int gdsw_apply_add(fedd_ctx* c, const double* d_r_owned, double* d_z_owned) {
+    ScopedTimer timer(c, FEDD_T_COARSE_APPLY);
+    const int64_t n0 = c->co_n0, ld = c->co_ld;
+    FEDD_TRY(gdsw_restrict(c, d_r_owned, c->d_co_r0.p));
+    if (c->nranks > 1) {
+        timer.stop();
+        FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, (int)n0));
+        timer.resume();
+    }
+    hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)((n0 + 3) / 4)), dim3(256), 0, c->stream, (const double*)c->d_co_K.p, ld, n0,
+                       (const double*)c->d_co_r0.p, c->d_co_z0.p);
+    FEDD_TRY(gdsw_prolong<true>(c, c->d_co_z0.p, d_z_owned));
+    FEDD_HIP(hipGetLastError());
+    return 0;
+}
+
 int coarse_setup(fedd_ctx* c) {
+    if (c->co_kind == FEDD_COARSE_GDSW) return gdsw_setup(c);
     ScopedTimer timer(c, FEDD_T_COARSE_SETUP);
     const int dim = c->dim, dofs = c->dofs;
     const int32_t n_own = (int32_t)c->n_own;
@@ -565,6 +1061,7 @@ int coarse_setup(fedd_ctx* c) {
 }
 
 int coarse_apply_add(fedd_ctx* c, const double* d_r_owned, double* d_z_owned) {
+    if (c->co_kind == FEDD_COARSE_GDSW) return gdsw_apply_add(c, d_r_owned, d_z_owned);
     ScopedTimer timer(c, FEDD_T_COARSE_APPLY);
     const int dim = c->dim, dofs = c->dofs;
     const CoarseGeom cg = c->co_geom;

@@ -233,6 +233,14 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_dense_ws;            // dense_invert_batched: per matrix Dinv [64*64] | R [64*ld] | C [ld*64]
     fedd::DevBuf<double> d_co_part, d_co_r0, d_co_z0;
     bool have_coarse = false;
+    int co_kind = FEDD_COARSE_Q1;               // FEDD_COARSE_Q1 (lattice hat functions) / FEDD_COARSE_GDSW
+    double gdsw_tol = 1e-10;                    // option "gdsw_tol": relative residual of the interior extension solves
+    int gdsw_ext_its = 0;                       // most iterations / largest final residual of the last setup's extension solves
+    double gdsw_ext_rel = 0.0;
+    fedd::DevBuf<int32_t> d_gd_ent;             // [n_own] interface entity (doubled-lattice id) of every owned node
+    fedd::DevBuf<double> d_gd_phi;              // [n_rows * (3^dim - 1) * dofs] coarse basis, row-wise by class of the home cell
+    fedd::DevBuf<double> d_gd_imask;            // [n_rows] 1 = free interior dof
+    fedd::DevBuf<double> d_gd_tmp;
 
     // ---- GMRES workspace ----
     fedd::DevBuf<double> d_V, d_Z;              // [(m+1)*n_rows], [n_cols] scratch
@@ -241,6 +249,7 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_small;               // H, cs, sn, g, h, scalars
     double* h_pinned = nullptr;                 // small pinned host mirror
     int gm_restart_alloc = 0;
+    const double* gm_mask = nullptr;            // != nullptr: GMRES solves the constrained system (dofs with mask 0 held), see gmres.hip
 
     // ---- generic scratch ----
     fedd::DevBuf<int32_t> d_itmp0, d_itmp1, d_itmp2;

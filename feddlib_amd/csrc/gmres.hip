@@ -508,6 +508,13 @@ __global__ __launch_bounds__(256) void k_axpy2(double* __restrict__ V, int64_t l
     }
 }
 
+// out = m o a + (1 - m) o b  (m = 0 / 1 mask): the constrained operator of the interior solves, see gmres_solve
+__global__ void k_mask_mix(const double* __restrict__ m, const double* __restrict__ a, const double* __restrict__ b,
+                           double* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = m[i] != 0.0 ? a[i] : b[i];
+}
+
 __global__ void k_axpby(double a, const double* __restrict__ x, double b, const double* __restrict__ y,
                         double* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -583,9 +590,22 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
         hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, out, nblk, (const int32_t*)nullptr);
         return allreduce_sum(c, out, 1);
     };
+    // c->gm_mask != nullptr: the constrained system  A^ = D A D + (I - D),  M^^-1 = D M^-1 D + (I - D)  with
+    // D = diag(mask): dofs with mask 0 are held at the value the right-hand side gives them and decouple (the
+    // discrete harmonic extensions of the GDSW coarse space: interface dofs held, interiors solved).  The inputs
+    // already carry D x = x wherever it matters: in = D in + (I - D) in.
+    const double* mk = c->gm_mask;
     auto apply_B = [&](const double* in, double* out) -> int {  // out = A M^-1 in
         const bool tail = in == u;     // u, z and r have a ghost tail, a basis column does not
         if (use_prec) FEDD_TRY(schwarz_apply(c, in, z, tail));
+        if (mk) {
+            // z <- D M^-1 D in + (I - D) in   (M^-1 D in: the masked entries of `in` are excluded by a copy)
+            if (use_prec) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)z, in, z, n);
+            else FEDD_HIP(hipMemcpyAsync(z, in, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            FEDD_TRY(spmv_owned(c, z, out, true));
+            hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)out, (const double*)z, out, n);
+            return 0;
+        }
         return spmv_owned(c, use_prec ? z : in, out, use_prec ? true : tail);
     };
 
@@ -695,12 +715,14 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
         hipLaunchKernelGGL(k_combine, gn, blk, 0, st, (const double*)V, ldv, n, kfin, (const double*)(S + o.y), r);
         if (use_prec) {
             FEDD_TRY(schwarz_apply(c, r, z, true));
+            if (mk) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)z, (const double*)r, z, n);
             hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)z, d_x, n);
         } else {
             hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)r, d_x, n);
         }
         if (!converged && (its < max_it || broke)) {
             FEDD_TRY(spmv_owned(c, d_x, r));
+            if (mk) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)r, (const double*)d_x, r, n);
             hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, d_b, -1.0, (const double*)r, r, n);
             FEDD_TRY(norm2_into(r, S + o.nrm + 3));
             if (broke) {   // rare path: the host reads the true residual (every rank takes the same decision)
@@ -720,7 +742,7 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
 
 int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart, int use_prec,
                 int* its_out, double* relres_out) {
-    if (c->gmres_kind == 0) return gmres_solve_dcgs2(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
+    if (c->gmres_kind == 0 || c->gm_mask) return gmres_solve_dcgs2(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
     const int64_t n = c->n_rows;
     const int m = std::min(restart, max_it);
     const int64_t ldv = (n + 15) & ~(int64_t)15;  // 128-byte aligned basis columns

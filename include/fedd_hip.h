@@ -233,6 +233,14 @@ int fedd_spmv_info(fedd_ctx* ctx, int64_t* nnz_pattern, int64_t* nnz_streamed);
  * (DESIGN.md "two-level" gives the normative definition and why it stands in for GDSW here);
  * K0 = Phi^T A Phi is formed and inverted on the device, replicated on every rank. */
 #define FEDD_COARSE_Q1 1
+/* FEDD_COARSE_GDSW: FROSch's GDSWCoarseOperator on a second, coarse decomposition -- the cells of the same regular lattice
+ * (fedd_schwarz_set_coarse; default one cell per 1000 nodes, at most 8^3 cells for scalar and 5^3 for vector problems):
+ * interface nodes are classified into the faces / edges / vertices between the cells, the coarse basis is the null space
+ * (constants per dof component: what FROSch has without node coordinates, parametersPrec.xml:5 "Use node lists" = false)
+ * restricted to each interface component and extended discrete-harmonically into the cell interiors (device GMRES +
+ * one-level Schwarz on the constrained operator, option "gdsw_tol", default 1e-10), K0 = Phi^T A Phi inverted on the
+ * matrix cores.  (2g - 1)^dim * dofs coarse dofs for g cells per direction. */
+#define FEDD_COARSE_GDSW 2
 int fedd_schwarz_setup(fedd_ctx* ctx, int overlap, int combine, int two_level, int coarse_kind);
 /* target_nodes = 0 (the default): 27 nodes for scalar problems, 27 / dofs-per-node for vector ones */
 int fedd_schwarz_set_target(fedd_ctx* ctx, int target_nodes, double scale);

@@ -1015,6 +1015,76 @@ class CoarseQ1:
         return self.Phi @ (self.K0inv @ (self.Phi.T @ r))
 
 
+class CoarseGDSW:
+    """GDSW coarse level (FROSch GDSWCoarseOperator, parametersPrec.xml:13-23, 62-122) on a second, coarse
+    decomposition -- normative definition of the product's FEDD_COARSE_GDSW (feddlib_amd/csrc/coarse.hip):
+      * coarse subdomains = cells of the regular lattice `coarse_lattice(lo, L, cells_target)`; an element belongs to
+        the cell of its centroid (mean of its first dim + 1 vertices; cell index = clamp(floor((c - lo) / L * g)));
+      * a node whose incident elements lie in the cell index box [imin, imax] sits on the interface entity with the
+        doubled-lattice coordinates e = imin + imax (e_d odd: between cells in direction d); all e_d even: interior;
+      * Phi_Gamma[(node, a), (entity, a)] = 1 for free interface dofs (null space = constants per component);
+      * Phi_I = -A_II^-1 A_IGamma Phi_Gamma on the free interior dofs (exact sparse solve here);
+      * K0 = Phi^T A Phi over ALL (2g - 1)^dim entities x dofs (cell interiors and empty entities: unit diagonal, the
+        rest a relative diagonal shift of 1e-12); the level adds Phi K0^-1 Phi^T."""
+
+    def __init__(self, A: sp.csr_matrix, conn: np.ndarray, xyz: np.ndarray, is_dir: np.ndarray, dofs: int = 1,
+                 cells_target: float = 8.0, lo=None, L=None):
+        import scipy.sparse.linalg as spla
+        n_nodes, dim = xyz.shape
+        lo = xyz.min(axis=0) if lo is None else np.asarray(lo, dtype=float)
+        L = (xyz.max(axis=0) - lo) if L is None else np.asarray(L, dtype=float)
+        g = coarse_lattice(lo, L, cells_target)
+        Lpos = np.where(L > 0, L, 1.0)
+        cen = xyz[conn[:, :dim + 1]].sum(axis=1) / (dim + 1)
+        ecell = np.clip(np.floor((cen - lo) / Lpos * g).astype(np.int64), 0, g - 1)        # [E, dim]
+        imin = np.full((n_nodes, dim), np.iinfo(np.int64).max)
+        imax = np.full((n_nodes, dim), -1)
+        for k in range(conn.shape[1]):
+            np.minimum.at(imin, conn[:, k], ecell)
+            np.maximum.at(imax, conn[:, k], ecell)
+        lone = imax[:, 0] < 0
+        imin[lone] = 0
+        imax[lone] = 0
+        e = imin + imax                                            # entity coordinates
+        m = 2 * g - 1
+        stride = np.ones(dim, dtype=np.int64)
+        for d in range(1, dim):
+            stride[d] = stride[d - 1] * m[d - 1]
+        ent = (e * stride).sum(axis=1)
+        on_gamma = (e % 2 == 1).any(axis=1)
+        n_ent = int(np.prod(m))
+        n = dofs * n_nodes
+        free = ~np.asarray(is_dir, dtype=bool)
+        gamma_dof = np.repeat(on_gamma, dofs)
+        comp = np.tile(np.arange(dofs), n_nodes)
+        col = np.repeat(ent, dofs) * dofs + comp
+        sel = gamma_dof & free
+        self.n0 = n_ent * dofs
+        PhiG = sp.csr_matrix((np.ones(sel.sum()), (np.nonzero(sel)[0], col[sel])), shape=(n, self.n0))
+        A = A.tocsr()
+        I = np.nonzero(~gamma_dof & free)[0]
+        Phi = PhiG.tolil()
+        if I.shape[0]:
+            AII = A[I][:, I].tocsc()
+            rhs = -(A[I] @ PhiG).toarray()
+            X = spla.splu(AII).solve(rhs)
+            nz = np.abs(rhs).sum(axis=0) > 0
+            Phi = (PhiG + sp.csr_matrix((X[:, nz].ravel(), (np.repeat(I, nz.sum()), np.tile(np.nonzero(nz)[0], I.shape[0]))),
+                                        shape=(n, self.n0))).tocsr()
+        self.g = g
+        self.Phi = sp.csr_matrix(Phi)
+        K0 = (self.Phi.T @ A @ self.Phi).toarray()
+        d = np.diag(K0).copy()
+        empty = ~(np.abs(K0).sum(axis=1) > 0)
+        K0[np.diag_indices(self.n0)] = np.where(empty, 1.0, d * (1.0 + 1e-12))
+        self.K0 = K0
+        self.K0inv = np.linalg.inv(K0)
+        self.n_interface_entities = int(np.unique(ent[on_gamma]).shape[0])
+
+    def apply(self, r: np.ndarray) -> np.ndarray:
+        return self.Phi @ (self.K0inv @ (self.Phi.T @ r))
+
+
 def gmres_right(A, b, M=None, rtol=1e-8, max_it=100, restart=100, x0=None):
     """Right-preconditioned restarted GMRES, block size 1 (what Stratimikos/Belos 'Block GMRES'
     with an 'unspecified'-side Thyra preconditioner runs; parametersSolver.xml:5-15), classical

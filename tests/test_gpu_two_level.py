@@ -126,3 +126,90 @@ def test_two_level_misuse(fedd_lib, ctx):
     ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_Q1)
     g, Kinv = ctx.schwarz_coarse()
     assert tuple(g) == (1, 1, 1) and Kinv.shape == (8, 8)    # default: 343 nodes / 500 -> one cell
+
+
+@pytest.mark.parametrize("dim,M,cells", [(3, 12, 8), (3, 12, 27), (2, 24, 16), (3, 9, 1)])
+def test_gdsw_coarse_matrix_and_apply(fedd_lib, dim, M, cells):
+    """FEDD_COARSE_GDSW against the oracle's CoarseGDSW (exact sparse interior solves): interface classification,
+    harmonic extensions (device GMRES on the constrained operator, solved to 1e-13 here), K0^-1 and the operator."""
+    c = fedd_lib.Context(device=0)
+    try:
+        m, om, A_bc, rhs_bc, is_dir = laplace_setup(fedd_lib, c, dim, M)
+        tgt = 27 if dim == 3 else 9
+        c.schwarz_set_target(tgt, 1.0)
+        c.schwarz_set_coarse(cells)
+        c.set_option("gdsw_tol", 1e-13)
+        c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_GDSW)
+        g, Kinv = c.schwarz_coarse()
+        co = fo.CoarseGDSW(A_bc, m["conn"], m["xyz"], is_dir, 1, cells_target=cells)
+        np.testing.assert_array_equal(g[:dim], co.g)
+        assert Kinv.shape == (co.n0, co.n0) and co.n0 == int(np.prod(2 * co.g - 1))
+        np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-9 * np.abs(co.K0inv).max())
+        node_bin, nb, _ = fo.schwarz_bins(m["xyz"], tgt)
+        ras = fo.RAS(A_bc, node_bin, nb)
+        rng = np.random.default_rng(5)
+        r = rng.standard_normal(A_bc.shape[0])
+        z = c.schwarz_apply(r)
+        zo = ras.apply(r) + co.apply(r)
+        np.testing.assert_allclose(z, zo, rtol=0, atol=1e-9 * np.abs(zo).max())
+        np.testing.assert_array_equal(c.schwarz_apply(r), c.schwarz_apply(r))
+        x, its, rel = c.gmres(None, rtol=1e-12, max_it=300, restart=100, use_prec=True)
+        xd = fo.direct_solve(A_bc, rhs_bc)
+        assert rel <= 1e-12
+        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
+    finally:
+        c.close()
+
+
+def test_gdsw_elasticity_and_iteration_counts(fedd_lib):
+    """3-dof elasticity (FULL blocks, steadyLinElas_Perf parameters, Dirichlet on flag 2): GDSW with translations per
+    interface component against the oracle; and the point of a coarse level: iteration counts that stay put when the
+    mesh is refined at fixed H / h (more and more coarse cells), where one level keeps growing."""
+    c = fedd_lib.Context(device=0)
+    try:
+        mu, nu = 2.0e6, 0.4
+        lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
+        M = 8
+        m = fedd_lib.structured_mesh(3, 1, M)
+        c.mesh_set_dict(m)
+        c.pattern_build(3, fedd_lib.BLOCK_FULL)
+        c.assemble(fedd_lib.FORM_LINELAS, [lam, mu])
+        c.assemble_rhs([0.0, 1.0, 0.0])
+        c.dirichlet([2], [0.0, 0.0, 0.0])
+        om = oracle_mesh(m)
+        A_bc, rhs_bc, _, _, flags = fo.linelas_problem(om, mu, nu)
+        is_dir = fo.dirichlet_rows(flags, (2,), dofs=3)
+        c.schwarz_set_coarse(8)
+        c.set_option("gdsw_tol", 1e-13)
+        c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_GDSW)
+        g, Kinv = c.schwarz_coarse()
+        co = fo.CoarseGDSW(A_bc, m["conn"], m["xyz"], is_dir, 3, cells_target=8)
+        assert Kinv.shape == (co.n0, co.n0) and co.n0 == 27 * 3
+        np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-8 * np.abs(co.K0inv).max())
+        x, its, rel = c.gmres(None, rtol=1e-12, max_it=400, restart=100, use_prec=True)
+        xd = fo.direct_solve(A_bc, rhs_bc)
+        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+        # Laplace, H / h = 8 fixed: 4^3, 6^3, 8^3 coarse cells (32^3 ... 64^3 fine cells)
+        c.set_option("gdsw_tol", 1e-10)
+        counts = {}
+        for cells_per_dir in (4, 6, 8):
+            m = fedd_lib.structured_mesh(3, 1, 8 * cells_per_dir)
+            c.mesh_set_dict(m)
+            c.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+            c.assemble(fedd_lib.FORM_LAPLACE)
+            c.assemble_rhs([1.0])
+            c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+            c.schwarz_set_target(27, 1.0)
+            c.schwarz_set_coarse(cells_per_dir ** 3)
+            c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_GDSW)
+            _, i2, r2 = c.gmres(None, rtol=1e-8, max_it=400, restart=100, use_prec=True)
+            c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+            _, i1, r1 = c.gmres(None, rtol=1e-8, max_it=400, restart=100, use_prec=True)
+            counts[cells_per_dir] = (i1, i2)
+            assert r1 <= 1e-8 and r2 <= 1e-8
+        print("one-level / GDSW iterations at H/h = 8:", counts)       # measured: (26, 26), (40, 29), (54, 30)
+        assert counts[8][1] <= counts[4][1] + 6            # GDSW: levels off as the number of cells grows
+        assert counts[8][0] >= counts[4][0] + 20           # one level: keeps growing
+        assert counts[8][1] < counts[8][0]
+    finally:
+        c.close()
