@@ -484,3 +484,87 @@ def test_bench_contract_n4_fixed_grid_rehearsal(fedd_lib):
     assert "1x2x2 blocks of 32x16x16 cells" in d["config"]["workload"]
     assert d["self_check"]["halo_spmv_max_rel_err"] <= 1e-12 and d["self_check"]["true_relres"] <= 1e-7
     assert "halo" in d["phases_device_ms_per_step"] and "allreduce" in d["phases_device_ms_per_step"]
+
+
+def _thread_rank_gdsw(capi, group, rank, dec, M, out, errs):
+    try:
+        world = group.world
+        m = capi.structured_mesh(3, dec, [M] * 3, rank, ghosts=4)
+        c = capi.Context(device=0, rank=rank, nranks=world, nccl_id=None)
+        c.mesh_set_dict(m)
+        c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, [M] * 3, m["gid_rep"]))
+        c.comm_set_thread_group(group)
+        mu, nu = 2.0e6, 0.4
+        lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
+        c.pattern_build(3, capi.BLOCK_FULL)
+        c.assemble(capi.FORM_LINELAS, [lam, mu])
+        c.assemble_rhs([0.0, 1.0, 0.0])
+        c.dirichlet([2], [0.0, 0.0, 0.0])
+        c.schwarz_set_coarse(8)                 # coarse decomposition = the 2 x 2 x 2 rank blocks
+        c.set_option("gdsw_tol", 1e-13)
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED, two_level=1, coarse_kind=capi.COARSE_GDSW)
+        g, Kinv = c.schwarz_coarse()
+        x, its, rel = c.gmres(None, rtol=1e-12, max_it=600, restart=100, use_prec=True)
+        out[rank] = dict(gu=m["gid_uni"], g=g, Kinv=Kinv, x=x, its=its, rel=rel)
+        c.close()
+    except Exception as e:      # pragma: no cover
+        import traceback
+        errs.append("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+        try:
+            group._barrier.abort()
+        except Exception:
+            pass
+
+
+def test_cfg5_miniature_gdsw_on_eight_ranks(fedd_lib):
+    """cfg 5 in miniature with the coarse space the config names: 3D P1 linear elasticity (steadyLinElas_Perf
+    parameters), 2 x 2 x 2 ranks (threads of this process), two-level Schwarz with the GDSW coarse level whose coarse
+    decomposition is the rank decomposition (8 cells: 1 vertex + 6 edges + 12 faces = 19 interface components x 3
+    translations).  K0^-1 (all-reduced Galerkin product, extensions solved by the distributed constrained GMRES) and
+    the solution against the single-domain oracle; same coarse matrix and iteration count on every rank; and the
+    same iteration count as the one-rank run of the same problem."""
+    import threading
+    dec, M = (2, 2, 2), 4
+    group = fedd_lib.ThreadGroup(8)
+    out, errs = [None] * 8, []
+    th = [threading.Thread(target=_thread_rank_gdsw, args=(fedd_lib, group, r, dec, M, out, errs)) for r in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    assert not errs, "\n".join(errs)
+    assert all(o is not None for o in out)
+    ref = fedd_lib.structured_mesh(3, (1, 1, 1), [2 * M] * 3, 0)
+    om = fo.Mesh(dim=3, fe="P1", conn=ref["conn"], xyz=ref["xyz"], gid_rep=ref["gid_rep"], flag_rep=ref["flag_rep"],
+                 gid_uni=ref["gid_uni"], flag_uni=ref["flag_uni"], xyz_uni=None, n_global=ref["n_global"])
+    A_bc, rhs_bc, _, _, flags = fo.linelas_problem(om, 2.0e6, 0.4)
+    is_dir = fo.dirichlet_rows(flags, (2,), dofs=3)
+    co = fo.CoarseGDSW(A_bc, ref["conn"], ref["xyz"], is_dir, 3, cells_target=8)
+    assert co.n_interface_entities == 19 and co.n0 == 27 * 3
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    x = np.zeros_like(xd)
+    for o in out:
+        np.testing.assert_array_equal(o["g"], [2, 2, 2])
+        np.testing.assert_allclose(o["Kinv"], co.K0inv, rtol=0, atol=1e-8 * np.abs(co.K0inv).max())
+        d = (3 * o["gu"][:, None] + np.arange(3)[None, :]).ravel()
+        x[d] = o["x"]
+        assert o["rel"] <= 1e-12
+    assert len({o["its"] for o in out}) == 1
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+    # one rank, same problem, same coarse decomposition: the same preconditioner (whole boxes + row ghosts make the first
+    # level independent of the number of ranks; the coarse level is defined on the global lattice)
+    c = fedd_lib.Context(device=0)
+    try:
+        c.mesh_set_dict(ref)
+        mu, nu = 2.0e6, 0.4
+        c.pattern_build(3, fedd_lib.BLOCK_FULL)
+        c.assemble(fedd_lib.FORM_LINELAS, [2.0 * mu * nu / (1.0 - 2.0 * nu), mu])
+        c.assemble_rhs([0.0, 1.0, 0.0])
+        c.dirichlet([2], [0.0, 0.0, 0.0])
+        c.schwarz_set_coarse(8)
+        c.set_option("gdsw_tol", 1e-13)
+        c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_GDSW)
+        _, its1, _ = c.gmres(None, rtol=1e-12, max_it=600, restart=100, use_prec=True)
+    finally:
+        c.close()
+    assert abs(out[0]["its"] - its1) <= 1
