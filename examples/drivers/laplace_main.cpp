@@ -2,8 +2,8 @@
 // the reference's driver is (feddlib/problems/tests/laplace/main.cpp:56-228): same XML parameter
 // files, same call sequence  Domain::buildMesh -> BCBuilder::addBC -> Laplace(...) ->
 // addRhsFunction -> addBoundaries -> initializeProblem -> assemble -> setBoundaries -> solve.
-// Output: iteration count on stdout, solution as text (the reference writes HDF5/XDMF through
-// ExporterParaView, out of scope here).
+// Output: iteration count on stdout, solution as text (--out, for the tests) and, like the reference's tail
+// (main.cpp:210-225), through ExporterParaView: solutionLaplace.xmf + raw binary data in the working directory.
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -12,6 +12,7 @@
 #include "feddlib/core/FEDDCore.hpp"
 #include "feddlib/core/FE/Domain.hpp"
 #include "feddlib/core/General/BCBuilder.hpp"
+#include "feddlib/core/General/ExporterParaView.hpp"
 #include "feddlib/problems/specific/Laplace.hpp"
 
 void zeroBC(double* x, double* res, double t, const double* parameters) { res[0] = 0.; }
@@ -110,6 +111,17 @@ int main(int argc, char* argv[]) {
         auto map = exportSolution->getMap();
         auto data = exportSolution->getData(0);
         for (size_t i = 0; i < data.size(); ++i) out << map->getGlobalElement((LO)i) << " " << data[i] << "\n";
+
+        bool boolExportSolution = true;
+        if (boolExportSolution) {
+            Teuchos::RCP<ExporterParaView<SC, LO, GO, NO> > exPara(new ExporterParaView<SC, LO, GO, NO>());
+            exPara->setup("solutionLaplace", domain->getMesh(), FEType);
+            if (vL)
+                exPara->addVariable(exportSolution, "u", "Vector", dim, domain->getMapUnique());
+            else
+                exPara->addVariable(exportSolution, "u", "Scalar", 1, domain->getMapUnique());
+            exPara->save(0.0);
+        }
     } catch (const std::exception& e) {
         std::cerr << "exception: " << e.what() << std::endl;
         return 1;

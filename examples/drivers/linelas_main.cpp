@@ -17,6 +17,7 @@
 #include "feddlib/core/FEDDCore.hpp"
 #include "feddlib/core/FE/Domain.hpp"
 #include "feddlib/core/General/BCBuilder.hpp"
+#include "feddlib/core/General/ExporterParaView.hpp"
 #include "feddlib/problems/specific/LinElas.hpp"
 
 void zeroDirichlet2D(double* x, double* res, double t, const double* parameters) { res[0] = 0.; res[1] = 0.; }
@@ -48,6 +49,9 @@ int main(int argc, char* argv[]) {
     }
     try {
         Teuchos::RCP<const Teuchos::Comm<int> > comm = Teuchos::rcp(new Teuchos::Comm<int>(0, 1));
+        // steadyLinElas_Perf/main.cpp:114-115: every FEDD timer goes into one stacked timer, reported at the end
+        Teuchos::RCP<Teuchos::StackedTimer> stackedTimer = Teuchos::rcp(new Teuchos::StackedTimer("Steady Linear Elasticity Performance Test"));
+        Teuchos::TimeMonitor::setStackedTimer(stackedTimer);
         ParameterListPtr_Type parameterListProblem = Teuchos::getParametersFromXmlFile(xmlProblemFile);
         ParameterListPtr_Type parameterListPrec = Teuchos::getParametersFromXmlFile(xmlPrecFile);
         ParameterListPtr_Type parameterListSolver = Teuchos::getParametersFromXmlFile(xmlSolverFile);
@@ -92,10 +96,18 @@ int main(int argc, char* argv[]) {
             linElas.addParemeterRhs(force);
             linElas.addParemeterRhs(degree);
 
+            fedd_timing_enable(domain->device()->ctx, 1);
             linElas.initializeProblem();
-            linElas.assemble();
-            linElas.setBoundaries();
-            its = linElas.solve();
+            {
+                Teuchos::TimeMonitor tm(*Teuchos::TimeMonitor::getNewCounter("Assemble Problem"));
+                linElas.assemble();
+                linElas.setBoundaries();
+            }
+            {
+                Teuchos::TimeMonitor tm(*Teuchos::TimeMonitor::getNewCounter("FEDD - Problem - Solve"));
+                its = linElas.solve();
+                addDeviceTimers(domain->device(), *stackedTimer);      // where the GPU time of assemble + solve went
+            }
         }
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::cout << "iterations " << its << " relres " << linElas.getLastRelativeResidual() << std::endl;
@@ -107,6 +119,19 @@ int main(int argc, char* argv[]) {
         auto map = exportSolution->getMap();
         auto data = exportSolution->getData(0);
         for (size_t i = 0; i < data.size(); ++i) out << map->getGlobalElement((LO)i) << " " << data[i] << "\n";
+
+        if (parameterListAll->sublist("General").get("ParaViewExport", false)) {       // main.cpp:228-240
+            Teuchos::RCP<ExporterParaView<SC, LO, GO, NO> > exPara(new ExporterParaView<SC, LO, GO, NO>());
+            exPara->setup("displacements", domain->getMesh(), discType);
+            exPara->addVariable(exportSolution, "values", "Vector", dim, domain->getMapUnique());
+            exPara->save(0.0);
+            exPara->closeExporter();
+        }
+        comm->barrier();
+        stackedTimer->stop("Steady Linear Elasticity Performance Test");                 // main.cpp:245-249
+        Teuchos::StackedTimer::OutputOptions options;
+        options.output_fraction = options.output_histogram = options.output_minmax = true;
+        stackedTimer->report(std::cout, comm, options);
     } catch (const std::exception& e) {
         std::cerr << "exception: " << e.what() << std::endl;
         return 1;

@@ -43,6 +43,10 @@ SIGNATURES = {
     "fedd_mesh_p2_sizes": [C.c_int, C.c_int64, _i32p, _i64p],
     "fedd_mesh_p2_build": [C.c_int, C.c_int64, C.c_int64, _i32p, _f64p, _i32p, C.c_int64, _i32p, _i32p, C.c_int,
                            _i32p, _f64p, _i32p],
+    "fedd_mesh_partition": [C.c_int, C.c_int, C.c_int64, _i32p, C.c_int64, _f64p, C.c_int, _i32p],
+    "fedd_mesh_partition_sizes": [C.c_int, C.c_int64, _i32p, C.c_int64, _i32p, C.c_int, C.c_int, C.c_int, _i64p, _i64p, _i64p, _i64p],
+    "fedd_mesh_partition_extract": [C.c_int, C.c_int, C.c_int64, _i32p, C.c_int64, _f64p, _i32p, _i32p, C.c_int, C.c_int, C.c_int,
+                                    _i32p, _f64p, _i64p, _i32p, _i32p, _i64p, _i32p, _i64p, _i32p, _i64p],
     "fedd_fe_quadrature": [C.c_int, C.c_int, _ip, _f64p, _f64p],
     "fedd_fe_basis": [C.c_int, C.c_int, C.c_int, _f64p, _f64p],
     "fedd_mesh_set": [C.c_void_p, C.c_int, C.c_int, C.c_int64, _i32p, C.c_int64, _f64p, _i64p, C.c_int64,
@@ -242,6 +246,44 @@ def p2_of_p1(m, volume_id=10):
     gid = np.arange(nv + ned.value, dtype=np.int64)
     return dict(dim=dim, nen=nen2, conn=conn2, xyz=xyz2, gid_rep=gid, flag_rep=flag2, gid_uni=gid.copy(),
                 flag_uni=flag2.copy(), n_global=nv + ned.value, n_p1=nv, elem_flag=m.get("elem_flag"))
+
+
+def partition_mesh(m, nparts):
+    """element -> part of a one-rank mesh dict (read_mesh / p2_of_p1 / structured_mesh on one block)"""
+    conn = np.ascontiguousarray(m["gid_rep"][m["conn"]], dtype=np.int32) if "gid_rep" in m else np.ascontiguousarray(m["conn"], np.int32)
+    xyz = np.ascontiguousarray(m["xyz"], dtype=np.float64)
+    part = np.zeros(conn.shape[0], dtype=np.int32)
+    _chk(lib().fedd_mesh_partition(m["dim"], conn.shape[1], conn.shape[0], _p(conn, _i32p), xyz.shape[0], _p(xyz, _f64p),
+                                   nparts, _p(part, _i32p)))
+    return part
+
+
+def partitioned_mesh(m, part, nparts, rank, ghosts=1):
+    """rank's mesh dict (what structured_mesh(..., rank, ghosts=L) returns for the structured grid) cut out of the
+    one-rank mesh dict m by the element partition `part`; carries owner_rep for Context.halo_set_owners"""
+    L = lib()
+    dim = m["dim"]
+    conn = np.ascontiguousarray(m["conn"], dtype=np.int32)
+    xyz = np.ascontiguousarray(m["xyz"], dtype=np.float64)
+    flag = np.ascontiguousarray(m["flag_rep"], dtype=np.int32)
+    part = np.ascontiguousarray(part, dtype=np.int32)
+    nen = conn.shape[1]
+    ne, nr, nu, ng = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    _chk(L.fedd_mesh_partition_sizes(nen, conn.shape[0], _p(conn, _i32p), xyz.shape[0], _p(part, _i32p), nparts, rank, int(ghosts),
+                                     C.byref(ne), C.byref(nr), C.byref(nu), C.byref(ng)))
+    out = dict(dim=dim, nen=nen, conn=np.zeros((ne.value, nen), np.int32), xyz=np.zeros((nr.value, dim)),
+               gid_rep=np.zeros(nr.value, np.int64), flag_rep=np.zeros(nr.value, np.int32), owner_rep=np.zeros(nr.value, np.int32),
+               gid_uni=np.zeros(nu.value, np.int64), flag_uni=np.zeros(nu.value, np.int32),
+               row_ghost_gid=np.zeros(ng.value, np.int64), row_ghost_flag=np.zeros(ng.value, np.int32),
+               elem_gid=np.zeros(ne.value, np.int64), n_global=xyz.shape[0], rank=rank)
+    _chk(L.fedd_mesh_partition_extract(dim, nen, conn.shape[0], _p(conn, _i32p), xyz.shape[0], _p(xyz, _f64p), _p(flag, _i32p),
+                                       _p(part, _i32p), nparts, rank, int(ghosts), _p(out["conn"], _i32p), _p(out["xyz"], _f64p),
+                                       _p(out["gid_rep"], _i64p), _p(out["flag_rep"], _i32p), _p(out["owner_rep"], _i32p),
+                                       _p(out["gid_uni"], _i64p), _p(out["flag_uni"], _i32p), _p(out["row_ghost_gid"], _i64p),
+                                       _p(out["row_ghost_flag"], _i32p), _p(out["elem_gid"], _i64p)))
+    if int(ghosts) < 2:
+        del out["row_ghost_gid"], out["row_ghost_flag"]
+    return out
 
 
 def fe_quadrature(dim, degree):

@@ -4,9 +4,11 @@
 // API subset mirrored: Teuchos::RCP / rcp / null / rcp_const_cast, Teuchos::ParameterList (get,
 // sublist, set, setParameters, isParameter, isSublist), Teuchos::getParametersFromXmlFile,
 // Teuchos::Comm<int> (getRank/getSize/barrier), Teuchos::ArrayRCP / ArrayView (pointer + size),
-// TEUCHOS_TEST_FOR_EXCEPTION.
+// TEUCHOS_TEST_FOR_EXCEPTION, Teuchos::Time / TimeMonitor / StackedTimer (report with OutputOptions).
 #pragma once
 #include <cstdlib>
+#include <ctime>
+#include <iostream>
 #include <fstream>
 #include <map>
 #include <memory>
@@ -189,5 +191,155 @@ inline RCP<ParameterList> getParametersFromXmlFile(const std::string& file) {
     TEUCHOS_TEST_FOR_EXCEPTION(root.is_null(), std::runtime_error, "no ParameterList in " << file);
     return root;
 }
+
+// ---- timers: the subset of Teuchos::Time / TimeMonitor / StackedTimer the drivers' tails use
+// (steadyLinElas_Perf/main.cpp:114-115, 245-249; FEDD_TIMER_START / FEDD_TIMER_STOP of the reference wrap TimeMonitor) ----
+typedef std::ostream FancyOStream;
+
+class StackedTimer {
+public:
+    struct OutputOptions {
+        bool output_fraction = false, output_total_updates = false, output_histogram = false, output_minmax = false,
+             print_warnings = true, align_columns = true, print_names_before_values = true;
+        int max_levels = 100;
+    };
+    explicit StackedTimer(const std::string& name) {
+        root_.name = name;
+        stack_.push_back(&root_);
+        begin(root_);
+    }
+    void start(const std::string& name) {
+        Node* parent = stack_.back();
+        Node* n = nullptr;
+        for (auto& ch : parent->children)
+            if (ch->name == name) n = ch.get();
+        if (!n) {
+            parent->children.emplace_back(new Node());
+            n = parent->children.back().get();
+            n->name = name;
+        }
+        stack_.push_back(n);
+        begin(*n);
+    }
+    void stop(const std::string& name) {
+        TEUCHOS_TEST_FOR_EXCEPTION(stack_.empty() || stack_.back()->name != name, std::runtime_error,
+                                   "StackedTimer::stop(\"" << name << "\"): the running timer is \""
+                                                           << (stack_.empty() ? std::string("<none>") : stack_.back()->name) << "\"");
+        end(*stack_.back());
+        stack_.pop_back();
+    }
+    // device-side or otherwise externally measured time as a child of the running timer
+    void addExternal(const std::string& name, double seconds, long count) {
+        Node* parent = stack_.empty() ? &root_ : stack_.back();
+        parent->children.emplace_back(new Node());
+        Node* n = parent->children.back().get();
+        n->name = name;
+        n->total = seconds;
+        n->count = count;
+    }
+    double accumulatedTime(const std::string& name) const {
+        const Node* n = find(&root_, name);
+        return n ? n->total : 0.0;
+    }
+    template <class CommPtr>
+    void report(std::ostream& os, const CommPtr&, const OutputOptions& options) const { report(os, options); }
+    template <class CommPtr>
+    void report(std::ostream& os, const CommPtr&) const { report(os); }
+    void report(std::ostream& os, const OutputOptions& options) const {
+        print(os, root_, 0, root_.total > 0 ? root_.total : 1.0, options);
+    }
+    void report(std::ostream& os) const {
+        OutputOptions options;
+        report(os, options);
+    }
+private:
+    struct Node {
+        std::string name;
+        double total = 0.0, t0 = 0.0;
+        long count = 0;
+        bool running = false;
+        std::vector<std::unique_ptr<Node>> children;
+    };
+    static double now() {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    }
+    static void begin(Node& n) { n.t0 = now(); n.running = true; }
+    static void end(Node& n) { n.total += now() - n.t0; n.count += 1; n.running = false; }
+    static const Node* find(const Node* n, const std::string& name) {
+        if (n->name == name) return n;
+        for (auto& ch : n->children)
+            if (const Node* f = find(ch.get(), name)) return f;
+        return nullptr;
+    }
+    static void print(std::ostream& os, const Node& n, int level, double parent_total, const OutputOptions& o) {
+        if (level > o.max_levels) return;
+        const double t = n.running ? n.total + (now() - n.t0) : n.total;
+        os << std::string(2 * level, ' ') << n.name << ": " << t << " [" << n.count << "]";
+        if (o.output_fraction && level > 0) os << " (" << (parent_total > 0 ? t / parent_total : 0.0) << ")";
+        os << "\n";
+        double sum = 0.0;
+        for (auto& ch : n.children) {
+            print(os, *ch, level + 1, t, o);
+            sum += ch->total;
+        }
+        if (!n.children.empty() && level < o.max_levels)
+            os << std::string(2 * (level + 1), ' ') << "Remainder: " << (t - sum) << "\n";
+    }
+    Node root_;
+    std::vector<Node*> stack_;
+};
+
+class Time {
+public:
+    explicit Time(const std::string& name, bool start_now = false) : name_(name) { if (start_now) start(); }
+    void start() { t0_ = wall(); running_ = true; }
+    double stop() { if (running_) { total_ += wall() - t0_; ++calls_; running_ = false; } return total_; }
+    double totalElapsedTime() const { return total_; }
+    int numCalls() const { return calls_; }
+    const std::string& name() const { return name_; }
+private:
+    static double wall() {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    }
+    std::string name_;
+    double total_ = 0.0, t0_ = 0.0;
+    int calls_ = 0;
+    bool running_ = false;
+};
+
+// RAII monitor; timers are registered by name, mirrored into the stacked timer when one is set
+class TimeMonitor {
+public:
+    explicit TimeMonitor(Time& t) : t_(&t) {
+        t_->start();
+        if (!stacked().is_null()) stacked()->start(t_->name());
+    }
+    ~TimeMonitor() {
+        t_->stop();
+        if (!stacked().is_null()) stacked()->stop(t_->name());
+    }
+    static RCP<Time> getNewCounter(const std::string& name) {
+        auto& reg = registry();
+        auto it = reg.find(name);
+        if (it == reg.end()) it = reg.emplace(name, rcp(new Time(name))).first;
+        return it->second;
+    }
+    static void setStackedTimer(const RCP<StackedTimer>& st) { stacked() = st; }
+    static RCP<StackedTimer> getStackedTimer() { return stacked(); }
+    static void summarize(std::ostream& os = std::cout) {
+        os << "TimeMonitor results\n";
+        for (auto& kv : registry())
+            os << "  " << kv.first << ": " << kv.second->totalElapsedTime() << " s (" << kv.second->numCalls() << ")\n";
+    }
+    static void report(std::ostream& os) { summarize(os); }
+private:
+    static std::map<std::string, RCP<Time>>& registry() { static std::map<std::string, RCP<Time>> r; return r; }
+    static RCP<StackedTimer>& stacked() { static RCP<StackedTimer> s; return s; }
+    Time* t_;
+};
 
 }  // namespace Teuchos

@@ -12,7 +12,9 @@
 //   FE                  feddlib/core/FE/FE_decl.hpp:40-488
 //   BCBuilder           feddlib/core/General/BCBuilder_decl.hpp:36-84
 //   Problem             feddlib/problems/abstract/Problem_decl.hpp:38-229
-//   Laplace / LinElas   feddlib/problems/specific/{Laplace,LinElas}_decl.hpp
+//   Laplace / LinElas / Stokes   feddlib/problems/specific/{Laplace,LinElas,Stokes}_decl.hpp
+//   MeshPartitioner     feddlib/core/Mesh/MeshPartitioner_decl.hpp (one rank: read)
+//   ExporterParaView    feddlib/core/General/ExporterParaView_decl.hpp (XDMF + raw binary)
 //   LinearSolver        feddlib/problems/Solver/LinearSolver_decl.hpp
 //
 // Differences that are deliberate: SoA mesh storage behind the same accessors; the matrix lives on
@@ -22,7 +24,9 @@
 #include <cmath>
 #include <functional>
 #include <iostream>
+#include <fstream>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../../include/fedd_hip.h"
@@ -74,9 +78,13 @@ public:
     GO getGlobalNumElements() const { return maxGid_ + 1; }
     GO getGlobalElement(LO i) const { return gids_.at(i); }
     GO getMaxAllGlobalIndex() const { return maxGid_; }
-    LO getLocalElement(GO g) const {
-        auto it = std::find(gids_.begin(), gids_.end(), g);
-        return it == gids_.end() ? (LO)-1 : (LO)(it - gids_.begin());
+    LO getLocalElement(GO g) const {     // hash lookup, the table is built on first use
+        if (lookup_.empty() && !gids_.empty()) {
+            lookup_.reserve(gids_.size() * 2);
+            for (size_t i = 0; i < gids_.size(); ++i) lookup_.emplace(gids_[i], (LO)i);
+        }
+        auto it = lookup_.find(g);
+        return it == lookup_.end() ? (LO)-1 : it->second;
     }
     CommConstPtr_Type getComm() const { return comm_; }
     // vector-field map: dof = dim*node + d   (Map_def.hpp:95-107)
@@ -89,6 +97,7 @@ public:
     const std::vector<GO>& gids() const { return gids_; }
 private:
     std::vector<GO> gids_;
+    mutable std::unordered_map<GO, LO> lookup_;
     GO maxGid_ = -1;
     CommConstPtr_Type comm_;
 };
@@ -132,7 +141,17 @@ public:
     void resumeFill() { filled_ = false; }
     // binding to the device matrix the assembly produced
     void bind(DeviceContextPtr dev, int dofs) { dev_ = dev; gen_ = dev->generation; dofs_ = dofs; hostValid_ = false; filled_ = true; }
-    bool isResident() const { return !dev_.is_null() && gen_ == dev_->generation; }
+    // block of a mixed problem held in a numbered slot beside the system matrix (fedd_matrix_store / fedd_assemble_div)
+    void bindSlot(DeviceContextPtr dev, int slot) { dev_ = dev; gen_ = dev->generation; slot_ = slot; hostValid_ = false; filled_ = true; }
+    int slot() const { return slot_; }
+    // Matrix::scale (used by Stokes::assemble, Stokes_def.hpp:83-85)
+    void scale(const SC& alpha) {
+        TEUCHOS_TEST_FOR_EXCEPTION(dev_.is_null(), std::runtime_error, "Matrix::scale: no assembled data");
+        feddCheck(fedd_matrix_scale(dev_->ctx, slot_, alpha), "fedd_matrix_scale");
+        hostValid_ = false;
+    }
+    void fillComplete(MapConstPtr_Type, MapConstPtr_Type) { filled_ = true; }
+    bool isResident() const { return !dev_.is_null() && (slot_ >= 0 || gen_ == dev_->generation); }
     DeviceContextPtr device() const { return dev_; }
     void invalidateHost() { hostValid_ = false; }
     GO getGlobalNumEntries() { pull(); return (GO)val_.size(); }
@@ -161,6 +180,14 @@ private:
         if (hostValid_) return;
         TEUCHOS_TEST_FOR_EXCEPTION(!isResident(), std::runtime_error, "Matrix: no assembled data");
         int64_t nr, nc, nnz;
+        if (slot_ >= 0) {      // a stored block: local column ids of the block's own column space
+            feddCheck(fedd_matrix_sizes(dev_->ctx, slot_, &nr, &nc, &nnz), "fedd_matrix_sizes");
+            rowptr_.resize(nr + 1); col_.resize(nnz); val_.resize(nnz); colGid_.resize(nc);
+            feddCheck(fedd_matrix_get(dev_->ctx, slot_, rowptr_.data(), col_.data(), val_.data()), "fedd_matrix_get");
+            for (int64_t i = 0; i < nc; ++i) colGid_[i] = i;
+            hostValid_ = true;
+            return;
+        }
         feddCheck(fedd_csr_sizes(dev_->ctx, &nr, &nc, &nnz), "fedd_csr_sizes");
         rowptr_.resize(nr + 1); col_.resize(nnz); val_.resize(nnz); colGid_.resize(nc);
         feddCheck(fedd_csr_get(dev_->ctx, rowptr_.data(), col_.data(), val_.data(), colGid_.data()), "fedd_csr_get");
@@ -169,7 +196,7 @@ private:
     MapConstPtr_Type map_;
     DeviceContextPtr dev_;
     long gen_ = -1;
-    int dofs_ = 1;
+    int dofs_ = 1, slot_ = -1;
     bool filled_ = false, hostValid_ = false;
     std::vector<int64_t> rowptr_, colGid_;
     std::vector<int32_t> col_;
@@ -182,6 +209,10 @@ public:
     typedef Matrix<SC, LO, GO, NO> Matrix_Type;
     typedef Teuchos::RCP<Matrix_Type> MatrixPtr_Type;
     BlockMatrix(UN size) : n_(size), blocks_(size * size) {}
+    // BlockMatrix::merge (BlockMatrix_def.hpp:119-148) happens on the device (fedd_block_merge); the flag says that the
+    // device's system matrix is the merged [A B^T; B C] of this block matrix
+    void setMerged(DeviceContextPtr dev) { mergedDev_ = dev; }
+    DeviceContextPtr mergedDevice() const { return mergedDev_; }
     UN size() const { return n_; }
     void addBlock(const MatrixPtr_Type& m, UN i, UN j) { blocks_.at(i * n_ + j) = m; }
     bool blockExists(UN i, UN j) const { return !blocks_.at(i * n_ + j).is_null(); }
@@ -192,6 +223,7 @@ public:
 private:
     UN n_;
     std::vector<MatrixPtr_Type> blocks_;
+    DeviceContextPtr mergedDev_;
 };
 
 template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
@@ -279,6 +311,43 @@ public:
         finishMesh(gidRep, gidUni, nen, ng);
     }
 
+    // what MeshPartitioner::readAndPartition leaves in the domain on one rank (MeshPartitioner_def.hpp:224-530,
+    // MeshUnstructured::readMeshSize / readMeshEntity): INRIA .mesh file, repeated = unique = identity numbering
+    void readMeshFile(const std::string& file, int dim, std::string FEType, int volumeID) {
+        TEUCHOS_TEST_FOR_EXCEPTION(comm_->getSize() > 1, std::logic_error, "Domain::readMeshFile: one rank in this build");
+        int64_t nv, ne, ns;
+        feddCheck(fedd_mesh_read_sizes(file.c_str(), dim, &nv, &ne, &ns), "fedd_mesh_read_sizes");
+        std::vector<double> xyz(nv * dim);
+        std::vector<int32_t> vflag(nv), conn(ne * (dim + 1)), eflag(ne);
+        surf_.assign(ns * dim, 0); surfFlag_.assign(ns, 0);
+        feddCheck(fedd_mesh_read(file.c_str(), dim, xyz.data(), vflag.data(), conn.data(), eflag.data(), surf_.data(), surfFlag_.data()), "fedd_mesh_read");
+        std::vector<int64_t> gid(nv);
+        for (int64_t i = 0; i < nv; ++i) gid[i] = i;
+        volumeID_ = volumeID;
+        setMesh(dim, FEType, dim + 1, conn, xyz, gid, gid, vflag);
+        flagRep_ = vflag;
+    }
+    // Domain::buildP2ofP1Domain (Domain_def.hpp -> MeshUnstructured::buildP2ofP1MeshEdge, MeshUnstructured_def.hpp:129-410)
+    void buildP2ofP1Domain(const Teuchos::RCP<Domain>& domainP1) {
+        TEUCHOS_TEST_FOR_EXCEPTION(comm_->getSize() > 1, std::logic_error, "Domain::buildP2ofP1Domain: one rank in this build");
+        const int dim = (int)domainP1->getDimension();
+        const int64_t ne = domainP1->getNumElements(), nv = domainP1->getNumPoints("Unique");
+        int64_t ned = 0;
+        feddCheck(fedd_mesh_p2_sizes(dim, ne, domainP1->conn_.data(), &ned), "fedd_mesh_p2_sizes");
+        const int nen2 = dim == 3 ? 10 : 6;
+        std::vector<int32_t> conn2(ne * nen2), flag2(nv + ned);
+        std::vector<double> xyz2((nv + ned) * dim);
+        feddCheck(fedd_mesh_p2_build(dim, nv, ne, domainP1->conn_.data(), domainP1->xyz_.data(), domainP1->flagRep_.data(),
+                                     (int64_t)domainP1->surfFlag_.size(), domainP1->surf_.data(), domainP1->surfFlag_.data(),
+                                     domainP1->volumeID_, conn2.data(), xyz2.data(), flag2.data()), "fedd_mesh_p2_build");
+        std::vector<int64_t> gid(nv + ned);
+        for (size_t i = 0; i < gid.size(); ++i) gid[i] = (int64_t)i;
+        setMesh(dim, "P2", nen2, conn2, xyz2, gid, gid, flag2);
+        flagRep_ = flag2;
+        nP1_ = nv;
+    }
+    int64_t numberOfP1Nodes() const { return nP1_; }      // P2-of-P1 domain: its first nodes are the P1 nodes
+
     LO getApproxEntriesPerRow() const {      // Domain_def.hpp:176-198 (allocation hint only)
         if (dim_ == 2) return FEType_ == "P1" ? 20 : 30;
         return FEType_ == "P1" ? 50 : (FEType_ == "P2" ? 80 : 100);
@@ -303,6 +372,9 @@ public:
             std::cout << "\t### Domain: dim " << dim_ << ", FE " << FEType_ << ", elements " << getNumElements() << ", nodes "
                       << mapUnique_->getGlobalNumElements() << " ###" << std::endl;
     }
+    // Domain::getMesh (Domain_decl.hpp): the facade's Domain holds the mesh arrays itself, so "the mesh" is a view of it
+    Teuchos::RCP<const Domain> getMesh() const { return Teuchos::RCP<const Domain>(std::shared_ptr<const Domain>(this, [](const Domain*) {})); }
+    const std::vector<int32_t>& connectivity() const { return conn_; }
     // facade internals
     DeviceContextPtr device() const { return dev_; }
     int nodesPerElement() const { return nen_; }
@@ -344,8 +416,10 @@ private:
     double length = 1., width = 1., height = 1.;
     int dim_ = 0, n_ = 0, m_ = 0, flagsOption_ = 0, nen_ = 0;
     std::string FEType_;
-    std::vector<int32_t> conn_, flagRep_, flagUni_, uniOfRep_;
+    std::vector<int32_t> conn_, flagRep_, flagUni_, uniOfRep_, surf_, surfFlag_;
     std::vector<double> xyz_;
+    int volumeID_ = 10;
+    int64_t nP1_ = 0;
     Teuchos::RCP<Map_Type> mapRepeated_, mapUnique_;
     DeviceContextPtr dev_;
 };
@@ -392,6 +466,21 @@ public:
         TEUCHOS_TEST_FOR_EXCEPTION(FEType == "P0", std::logic_error, "Not implemented for P0");
         const double p[2] = {lambda, mu};
         assembleInto(checkFE(dim, FEType), dim, FEDD_BLOCK_FULL, FEDD_FORM_LINELAS, p, A, callFillComplete);
+    }
+    // FE::assemblyDivAndDivT (FE_def.hpp:1932-2057): velocity = FEType1 on the first domain, pressure = P1 on the vertices,
+    // which are the first nodes of a P2-of-P1 velocity domain.  B and B^T land in slots 1 and 2 of the velocity domain's
+    // device context (the system slot is scratch for the node pattern), unscaled.
+    void assemblyDivAndDivT(int dim, std::string FEType1, std::string FEType2, int degree, MatrixPtr_Type& Bmat, MatrixPtr_Type& BTmat,
+                            Teuchos::RCP<const Map<LO, GO, NO>> map1, Teuchos::RCP<const Map<LO, GO, NO>> map2, bool callFillComplete = true) {
+        (void)degree; (void)map1; (void)callFillComplete;
+        TEUCHOS_TEST_FOR_EXCEPTION(FEType2 != "P1", std::logic_error, "assemblyDivAndDivT: the pressure space of this build is P1");
+        const UN loc1 = checkFE(dim, FEType1);
+        auto dom = domainVec_.at(loc1);
+        const int64_t n_p = (int64_t)map2->getNodeNumElements();
+        feddCheck(fedd_assemble_div(dom->device()->ctx, n_p, 1, 2), "fedd_assemble_div");
+        dom->device()->generation++;
+        Bmat->bindSlot(dom->device(), 1);
+        BTmat->bindSlot(dom->device(), 2);
     }
     // FE::assemblyRHS (FE_def.hpp:4694-4766): f evaluated once (constant); a lives on the REPEATED
     // map in the reference and is then export-added; here the owned entries are produced directly,
@@ -473,7 +562,12 @@ public:
         for (UN block = 0; block < blockMatrix->size(); ++block) {
             int loc0;
             if (!blockHasDirichletBC((int)block, loc0)) continue;
-            TEUCHOS_TEST_FOR_EXCEPTION(blockMatrix->size() > 1, std::logic_error, "block systems: Dirichlet rows of off-diagonal blocks are not built yet");
+            if (blockMatrix->size() > 1) {
+                // merged block system on the device: unit row on the merged row, i.e. setLocalRowOne on the diagonal block and
+                // setLocalRowZero on the off-diagonal blocks (BCBuilder_def.hpp:653-707), rhs <- boundary value
+                setMerged(blockMatrix, blockMV, (int)block, t);
+                continue;
+            }
             auto A = blockMatrix->getBlock(block, block);
             TEUCHOS_TEST_FOR_EXCEPTION(!A->isResident(), std::runtime_error, "BCBuilder: the matrix block is not resident on the device");
             auto dom = vecDomain_.at(loc0);
@@ -509,6 +603,49 @@ public:
         }
     }
 private:
+    void setMerged(const BlockMatrixPtr_Type& blockMatrix, const BlockMultiVectorPtr_Type& blockMV, int block, double t) const {
+        auto dev = blockMatrix->mergedDevice();
+        TEUCHOS_TEST_FOR_EXCEPTION(dev.is_null(), std::runtime_error, "BCBuilder: the block system has not been merged on the device");
+        int64_t rowOffset = 0;
+        for (int b = 0; b < block; ++b) rowOffset += (int64_t)blockMV->getBlock(b)->getLocalLength();
+        std::vector<int32_t> rows;
+        std::vector<double> values;
+        for (size_t k = 0; k < vecFlag_.size(); ++k) {
+            if (vecBlockID_[k] != block || vecBCType_[k].compare(0, 9, "Dirichlet") != 0) continue;
+            auto dom = vecDomain_[k];
+            const int dofs = vecDofs_[k], dim = (int)dom->getDimension();
+            vec_int_ptr_Type flags = dom->getBCFlagUnique();
+            vec2D_dbl_ptr_Type pts = dom->getPointsUnique();
+            const std::string& ty = vecBCType_[k];
+            vec_dbl_Type result(dofs, 0.), point(dim, 0.);
+            for (size_t i = 0; i < flags->size(); ++i) {
+                if ((*flags)[i] != vecFlag_[k]) continue;
+                for (int d = 0; d < dim; ++d) point[d] = (*pts)[i][d];
+                for (int d = 0; d < dofs; ++d) result[d] = d < dim ? (*pts)[i][d] : 0.;
+                vecBC_func_[k](point.data(), result.data(), t, vecBC_Parameters_[k].data());
+                for (int d = 0; d < dofs; ++d) {
+                    const bool on = ty == "Dirichlet" || (ty == "Dirichlet_X" && d == 0) || (ty == "Dirichlet_Y" && d == 1) ||
+                                    (ty == "Dirichlet_Z" && d == 2) || (ty == "Dirichlet_X_Y" && d != 2) ||
+                                    (ty == "Dirichlet_X_Z" && d != 1) || (ty == "Dirichlet_Y_Z" && d != 0);
+                    if (!on) continue;
+                    rows.push_back((int32_t)(rowOffset + (int64_t)i * dofs + d));
+                    values.push_back(result[d]);
+                }
+            }
+        }
+        // the merged rhs = the blocks' right-hand sides one after the other
+        std::vector<double> rhs;
+        for (UN b = 0; b < blockMV->size(); ++b) rhs.insert(rhs.end(), blockMV->getBlock(b)->raw().begin(), blockMV->getBlock(b)->raw().end());
+        feddCheck(fedd_rhs_set(dev->ctx, rhs.data()), "fedd_rhs_set");
+        feddCheck(fedd_dirichlet_rows(dev->ctx, (int64_t)rows.size(), rows.data(), values.data()), "fedd_dirichlet_rows");
+        feddCheck(fedd_rhs_get(dev->ctx, rhs.data()), "fedd_rhs_get");
+        size_t off = 0;
+        for (UN b = 0; b < blockMV->size(); ++b) {
+            auto& dst = blockMV->getBlockNonConst(b)->raw();
+            std::copy(rhs.begin() + off, rhs.begin() + off + dst.size(), dst.begin());
+            off += dst.size();
+        }
+    }
     std::vector<BC_func_Type> vecBC_func_;
     std::vector<int> vecFlag_, vecBlockID_, vecDofs_;
     std::vector<DomainPtr_Type> vecDomain_;
@@ -659,10 +796,11 @@ int LinearSolver<SC, LO, GO, NO>::solve(Problem_Type* problem, BlockMultiVectorP
     TEUCHOS_TEST_FOR_EXCEPTION(type != "Monolithic" && type != "MonolithicConstPrec", std::logic_error,
                                "Unknown solver type; only the monolithic path (LinearSolver_def.hpp:72-135) is built.");
     auto system = problem->getSystem();
-    TEUCHOS_TEST_FOR_EXCEPTION(system->size() != 1, std::logic_error, "block systems need BlockMatrix::merge (not built yet)");
-    auto A = system->getBlock(0, 0);
-    TEUCHOS_TEST_FOR_EXCEPTION(!A->isResident(), std::runtime_error, "solve: the system matrix is not resident on the device");
-    fedd_ctx* ctx = A->device()->ctx;
+    const bool blocks = system->size() > 1;
+    TEUCHOS_TEST_FOR_EXCEPTION(blocks && system->mergedDevice().is_null(), std::logic_error,
+                               "block system: it has not been merged on the device (BlockMatrix::merge, done by the problem's assemble)");
+    if (!blocks) TEUCHOS_TEST_FOR_EXCEPTION(!system->getBlock(0, 0)->isResident(), std::runtime_error, "solve: the system matrix is not resident on the device");
+    fedd_ctx* ctx = blocks ? system->mergedDevice()->ctx : system->getBlock(0, 0)->device()->ctx;
     auto pl = problem->getParameterList();
     // same keys the reference's XML files use (laplace/parametersSolver.xml, parametersPrec.xml)
     auto& belos = pl->sublist("ThyraSolver").sublist("Linear Solver Types").sublist("Belos");
@@ -683,19 +821,41 @@ int LinearSolver<SC, LO, GO, NO>::solve(Problem_Type* problem, BlockMultiVectorP
         // "TwoLevel" = true (parametersPrec.xml:17) switches the coarse level on.  The coarse space is
         // this library's lattice space, not FROSch's GDSW: say so.
         const bool twoLevel = frosch.get("TwoLevel", false);
-        if (twoLevel && problem->getVerbose())
-            std::cout << "-- note: TwoLevel runs the Q1-lattice coarse space of libfedd_hip, not GDSW --" << std::endl;
+        // "CoarseOperator Type" (parametersPrec.xml:23): GDSWCoarseOperator -> the library's GDSW level on the coarse
+        // lattice; RGDSW / IPOUHarmonic are not built and run GDSW too (said so); "Q1" selects the lattice hat functions
+        const std::string coarseType = frosch.get("CoarseOperator Type", "GDSWCoarseOperator");
+        const int coarseKind = coarseType == "Q1" ? FEDD_COARSE_Q1 : FEDD_COARSE_GDSW;
+        if (twoLevel && problem->getVerbose() && coarseType != "GDSWCoarseOperator" && coarseType != "Q1")
+            std::cout << "-- note: CoarseOperator Type " << coarseType << " is not built; running GDSWCoarseOperator --" << std::endl;
         const int target = frosch.get("Subdomain Nodes", 0);   // 0 = the library's default (27 / dofs per node)
         feddCheck(fedd_schwarz_set_target(ctx, target, 1.0), "fedd_schwarz_set_target");
         feddCheck(fedd_schwarz_set_coarse(ctx, frosch.get("Coarse Cells", 0.0)), "fedd_schwarz_set_coarse");
-        feddCheck(fedd_schwarz_setup(ctx, overlap, cmb, twoLevel ? 1 : 0, twoLevel ? FEDD_COARSE_Q1 : 0), "fedd_schwarz_setup");
+        // merged block systems: monolithic one-level Schwarz on the large-subdomain path; the coarse level takes
+        // node-interleaved systems only (said once)
+        if (blocks && twoLevel && problem->getVerbose())
+            std::cout << "-- note: the coarse level is not built for merged block systems; running one level --" << std::endl;
+        const bool two = twoLevel && !blocks;
+        feddCheck(fedd_schwarz_setup(ctx, overlap, cmb, two ? 1 : 0, two ? coarseKind : 0), "fedd_schwarz_setup");
     }
     auto b = rhs.is_null() ? problem->getRhs() : rhs;
     auto x = problem->getSolution();
     int its = 0;
     double rel = 0.;
-    feddCheck(fedd_gmres(ctx, b->getBlock(0)->raw().data(), x->getBlockNonConst(0)->raw().data(), tol, maxIt, numBlocks,
-                         usePrec ? 1 : 0, &its, &rel), "fedd_gmres");
+    if (!blocks) {
+        feddCheck(fedd_gmres(ctx, b->getBlock(0)->raw().data(), x->getBlockNonConst(0)->raw().data(), tol, maxIt, numBlocks,
+                             usePrec ? 1 : 0, &its, &rel), "fedd_gmres");
+    } else {       // merged vectors = the blocks one after the other (BlockMap::merge, BlockMap_def.hpp:55-80)
+        std::vector<double> bb, xx;
+        for (UN k = 0; k < b->size(); ++k) bb.insert(bb.end(), b->getBlock(k)->raw().begin(), b->getBlock(k)->raw().end());
+        xx.assign(bb.size(), 0.);
+        feddCheck(fedd_gmres(ctx, bb.data(), xx.data(), tol, maxIt, numBlocks, usePrec ? 1 : 0, &its, &rel), "fedd_gmres");
+        size_t off = 0;
+        for (UN k = 0; k < x->size(); ++k) {
+            auto& dst = x->getBlockNonConst(k)->raw();
+            std::copy(xx.begin() + off, xx.begin() + off + dst.size(), dst.begin());
+            off += dst.size();
+        }
+    }
     lastRelativeResidual = rel;
     return its;
 }
@@ -768,5 +928,216 @@ public:
         if (this->verbose_) std::cout << "done -- " << std::endl;
     }
 };
+
+// Stokes (feddlib/problems/specific/Stokes_def.hpp:26-138): A = nu * vector Laplacian, B and B^T = -div blocks; the
+// velocity domain is the P2 mesh built from the pressure domain's P1 mesh (its first nodes are the pressure nodes).
+// The blocks live in slots of the velocity domain's device context and are merged there at the end of assemble()
+// (BlockMatrix::merge at solve time in the reference); getBlock(i, j) gives host views of the blocks as assembled.
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class Stokes : public Problem<SC, LO, GO, NO> {
+public:
+    typedef Problem<SC, LO, GO, NO> Problem_Type;
+    typedef typename Problem_Type::DomainConstPtr_Type DomainConstPtr_Type;
+    typedef typename Problem_Type::Matrix_Type Matrix_Type;
+    typedef typename Problem_Type::MatrixPtr_Type MatrixPtr_Type;
+    typedef typename Problem_Type::BlockMatrix_Type BlockMatrix_Type;
+    Stokes(const DomainConstPtr_Type& domainVelocity, std::string FETypeVelocity, const DomainConstPtr_Type& domainPressure,
+           std::string FETypePressure, ParameterListPtr_Type parameterList)
+        : Problem_Type(parameterList, domainVelocity->getComm()) {
+        this->addVariable(domainVelocity, FETypeVelocity, "u", (int)domainVelocity->getDimension());
+        this->addVariable(domainPressure, FETypePressure, "p", 1);
+        this->dim_ = (int)this->getDomain(0)->getDimension();
+    }
+    void info() override { this->infoProblem(); }
+    void assemble(std::string type = "") const override {
+        (void)type;
+        if (this->verbose_) std::cout << "-- Assembly ... " << std::flush;
+        const double viscosity = this->parameterList_->sublist("Parameter").get("Viscosity", 1.);
+        TEUCHOS_TEST_FOR_EXCEPTION(this->parameterList_->sublist("Parameter").get("Symmetric gradient", false), std::logic_error,
+                                   "assemblyStress (symmetric gradient) is not built");
+        TEUCHOS_TEST_FOR_EXCEPTION(this->getFEType(1) != "P1", std::logic_error, "Stokes: P1 pressure in this build");
+        auto domV = this->getDomain(0);
+        auto dev = domV->device();
+        MatrixPtr_Type A(new Matrix_Type(domV->getMapVecFieldUnique(), domV->getApproxEntriesPerRow()));
+        MatrixPtr_Type BT(new Matrix_Type(domV->getMapVecFieldUnique(), this->getDomain(1)->getDimension() * this->getDomain(1)->getApproxEntriesPerRow()));
+        auto pressureMap = this->getDomain(1)->getMapUnique();
+        MatrixPtr_Type B(new Matrix_Type(pressureMap, domV->getDimension() * domV->getApproxEntriesPerRow()));
+        if (this->verbose_) std::cout << " A ... " << std::flush;
+        this->feFactory_->assemblyLaplaceVecField(this->dim_, this->domain_FEType_vec_.at(0), 2, A, true);
+        A->resumeFill();
+        feddCheck(fedd_matrix_scale(dev->ctx, -1, viscosity), "fedd_matrix_scale");        // A->scale(viscosity), Stokes_def.hpp:83
+        feddCheck(fedd_matrix_store(dev->ctx, 0), "fedd_matrix_store");
+        A->bindSlot(dev, 0);
+        if (this->verbose_) std::cout << "B and B^T ... " << std::flush;
+        this->feFactory_->assemblyDivAndDivT(this->dim_, this->getFEType(0), this->getFEType(1), 2, B, BT, domV->getMapVecFieldUnique(), pressureMap, true);
+        B->resumeFill();
+        BT->resumeFill();
+        B->scale(-1.);
+        BT->scale(-1.);
+        A->fillComplete(domV->getMapVecFieldUnique(), domV->getMapVecFieldUnique());
+        B->fillComplete(domV->getMapVecFieldUnique(), pressureMap);
+        BT->fillComplete(pressureMap, domV->getMapVecFieldUnique());
+        this->system_.reset(new BlockMatrix_Type(2));
+        this->system_->addBlock(A, 0, 0);
+        this->system_->addBlock(BT, 0, 1);
+        this->system_->addBlock(B, 1, 0);
+        TEUCHOS_TEST_FOR_EXCEPTION(this->getFEType(0) == "P1", std::logic_error, "Stokes: the P1/P1 Bochev-Dohrmann block is not built");
+        // BlockMatrix::merge: system <- [A B^T; B 0] on the device
+        feddCheck(fedd_block_merge(dev->ctx, 0, 2, 1, -1), "fedd_block_merge");
+        dev->generation++;
+        this->system_->setMerged(dev);
+        if (this->verbose_) std::cout << "done -- " << std::endl;
+    }
+};
+
+// MeshPartitioner (feddlib/core/Mesh/MeshPartitioner_decl.hpp): reads the mesh named by "Mesh 1 Name" into the domain;
+// on one rank no partitioning happens (MeshPartitioner_def.hpp:321-331).  The partitioner itself is in the library
+// (fedd_mesh_partition*); the facade is one rank.
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class MeshPartitioner {
+public:
+    typedef Domain<SC, LO, GO, NO> Domain_Type;
+    typedef Teuchos::RCP<Domain_Type> DomainPtr_Type;
+    typedef std::vector<DomainPtr_Type> DomainPtrArray_Type;
+    MeshPartitioner(DomainPtrArray_Type domains, ParameterListPtr_Type pL, std::string feType, int dimension)
+        : domains_(domains), pList_(pL), feType_(feType), dim_(dimension) {}
+    void readAndPartition(int volumeID = 10) {
+        for (size_t i = 0; i < domains_.size(); ++i) {
+            const std::string name = pList_->get("Mesh " + std::to_string(i + 1) + " Name", std::string("noName"));
+            domains_[i]->readMeshFile(name, dim_, feType_, volumeID);
+        }
+    }
+private:
+    DomainPtrArray_Type domains_;
+    ParameterListPtr_Type pList_;
+    std::string feType_;
+    int dim_;
+};
+
+// ExporterParaView (feddlib/core/General/ExporterParaView_decl.hpp:45-175, _def.hpp:484-601): nodal fields of the
+// unique map over the mesh, as an XDMF file ParaView opens.  The reference writes the heavy data through EpetraExt::HDF5;
+// HDF5 is not available here, so the DataItems use XDMF's raw binary format (little endian): <name>.xmf plus
+// <name>.conn.bin / <name>.xyz.bin / <name>.<variable>.<step>.bin.  One rank (the facade's scope); P2 meshes are written
+// with their vertex connectivity (mid-edge nodes stay in the point list).
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class ExporterParaView {
+public:
+    typedef Domain<SC, LO, GO, NO> Mesh_Type;
+    typedef Teuchos::RCP<const Mesh_Type> MeshPtr_Type;
+    typedef MultiVector<SC, LO, GO, NO> MultiVec_Type;
+    typedef Teuchos::RCP<const MultiVec_Type> MultiVecConstPtr_Type;
+    typedef Map<LO, GO, NO> Map_Type;
+    typedef Teuchos::RCP<const Map_Type> MapConstPtr_Type;
+
+    ExporterParaView() {}
+    void setup(std::string filename, MeshPtr_Type mesh, std::string FEType, ParameterListPtr_Type parameterList = Teuchos::null) {
+        setup(filename, mesh, FEType, 1, parameterList);
+    }
+    void setup(std::string filename, MeshPtr_Type mesh, std::string FEType, int saveTimestep, ParameterListPtr_Type = Teuchos::null) {
+        TEUCHOS_TEST_FOR_EXCEPTION(mesh.is_null(), std::runtime_error, "ExporterParaView::setup: null mesh");
+        TEUCHOS_TEST_FOR_EXCEPTION(mesh->getComm()->getSize() > 1, std::logic_error, "ExporterParaView: one rank only in this build");
+        filename_ = filename; mesh_ = mesh; FEType_ = FEType; saveTimestep_ = std::max(1, saveTimestep);
+        const int dim = (int)mesh->getDimension(), nen = mesh->nodesPerElement(), nv = dim + 1;
+        const auto& conn = mesh->connectivity();
+        const size_t ne = conn.size() / nen;
+        // connectivity in unique-local ids (values live on the unique map), vertices only
+        std::vector<int32_t> uniOfRepInv(mesh->getMapRepeated()->getNodeNumElements(), -1);
+        const auto& uor = mesh->uniqueLocalOfRepeated();
+        for (size_t u = 0; u < uor.size(); ++u) uniOfRepInv[uor[u]] = (int32_t)u;
+        std::vector<int32_t> c(ne * nv);
+        for (size_t e = 0; e < ne; ++e)
+            for (int j = 0; j < nv; ++j) {
+                const int32_t u = uniOfRepInv.at(conn[e * nen + j]);
+                TEUCHOS_TEST_FOR_EXCEPTION(u < 0, std::logic_error, "ExporterParaView: a repeated node is not owned (several ranks)");
+                c[e * nv + j] = u;
+            }
+        writeBin(filename_ + ".conn.bin", c.data(), c.size() * sizeof(int32_t));
+        auto pts = mesh->getPointsUnique();
+        nPoints_ = pts->size();
+        std::vector<double> xyz(nPoints_ * 3, 0.0);
+        for (size_t i = 0; i < nPoints_; ++i)
+            for (int d = 0; d < dim; ++d) xyz[i * 3 + d] = (*pts)[i][d];
+        writeBin(filename_ + ".xyz.bin", xyz.data(), xyz.size() * sizeof(double));
+        nElements_ = ne;
+        topology_ = dim == 3 ? "Tetrahedron" : "Triangle";
+        nv_ = nv;
+    }
+    void addVariable(MultiVecConstPtr_Type& u, std::string varName, std::string varType, int dofPerNode,
+                     MapConstPtr_Type mapUnique = Teuchos::null, MapConstPtr_Type mapUniqueLeading = Teuchos::null) {
+        (void)mapUnique; (void)mapUniqueLeading;
+        TEUCHOS_TEST_FOR_EXCEPTION(varType != "Scalar" && varType != "Vector", std::logic_error, "Unknown variable type for exporter.");
+        TEUCHOS_TEST_FOR_EXCEPTION(u->getLocalLength() != nPoints_ * (size_t)dofPerNode, std::logic_error,
+                                   "ExporterParaView::addVariable: vector length does not match the mesh");
+        vars_.push_back({u, varName, varType, dofPerNode});
+    }
+    void save(double time) { save(time, 0.); }
+    void save(double time, double dt) {
+        (void)dt;
+        if (timeIndex_ % saveTimestep_ == 0) {
+            for (auto& v : vars_) {
+                const auto& x = v.u->raw();
+                const int comps = v.type == "Vector" ? 3 : 1;
+                std::vector<double> out(nPoints_ * comps, 0.0);
+                for (size_t i = 0; i < nPoints_; ++i)
+                    for (int d = 0; d < v.dofs && d < comps; ++d) out[i * comps + d] = x[i * v.dofs + d];
+                writeBin(filename_ + "." + v.name + "." + std::to_string(nSaved_) + ".bin", out.data(), out.size() * sizeof(double));
+            }
+            times_.push_back(time);
+            ++nSaved_;
+            writeXmf();
+        }
+        ++timeIndex_;
+    }
+    void closeExporter() { writeXmf(); }
+private:
+    struct Var { MultiVecConstPtr_Type u; std::string name, type; int dofs; };
+    static void writeBin(const std::string& f, const void* p, size_t bytes) {
+        std::ofstream os(f, std::ios::binary);
+        TEUCHOS_TEST_FOR_EXCEPTION(!os, std::runtime_error, "ExporterParaView: cannot write " << f);
+        os.write((const char*)p, (std::streamsize)bytes);
+    }
+    static std::string base(const std::string& f) { const size_t p = f.find_last_of('/'); return p == std::string::npos ? f : f.substr(p + 1); }
+    void writeXmf() const {
+        std::ofstream os(filename_ + ".xmf");
+        TEUCHOS_TEST_FOR_EXCEPTION(!os, std::runtime_error, "ExporterParaView: cannot write " << filename_ << ".xmf");
+        const std::string b = base(filename_);
+        os << "<?xml version=\"1.0\" ?>\n<Xdmf Version=\"2.0\">\n<Domain>\n<Grid Name=\"" << b
+           << "\" GridType=\"Collection\" CollectionType=\"Temporal\">\n";
+        for (size_t k = 0; k < times_.size(); ++k) {
+            os << " <Grid Name=\"step" << k << "\" GridType=\"Uniform\">\n  <Time Value=\"" << times_[k] << "\"/>\n"
+               << "  <Topology TopologyType=\"" << topology_ << "\" NumberOfElements=\"" << nElements_ << "\">\n"
+               << "   <DataItem Format=\"Binary\" DataType=\"Int\" Precision=\"4\" Endian=\"Little\" Dimensions=\"" << nElements_ << " " << nv_
+               << "\">" << b << ".conn.bin</DataItem>\n  </Topology>\n"
+               << "  <Geometry GeometryType=\"XYZ\">\n   <DataItem Format=\"Binary\" DataType=\"Float\" Precision=\"8\" Endian=\"Little\" Dimensions=\""
+               << nPoints_ << " 3\">" << b << ".xyz.bin</DataItem>\n  </Geometry>\n";
+            for (auto& v : vars_) {
+                const bool vec = v.type == "Vector";
+                os << "  <Attribute Name=\"" << v.name << "\" AttributeType=\"" << (vec ? "Vector" : "Scalar") << "\" Center=\"Node\">\n"
+                   << "   <DataItem Format=\"Binary\" DataType=\"Float\" Precision=\"8\" Endian=\"Little\" Dimensions=\"" << nPoints_
+                   << (vec ? " 3" : "") << "\">" << b << "." << v.name << "." << k << ".bin</DataItem>\n  </Attribute>\n";
+            }
+            os << " </Grid>\n";
+        }
+        os << "</Grid>\n</Domain>\n</Xdmf>\n";
+    }
+    std::string filename_, FEType_, topology_;
+    MeshPtr_Type mesh_;
+    std::vector<Var> vars_;
+    std::vector<double> times_;
+    size_t nPoints_ = 0, nElements_ = 0;
+    int nv_ = 0, saveTimestep_ = 1, timeIndex_ = 0, nSaved_ = 0;
+};
+
+// device time of the kernel classes of the hot path (HIP events on the library's stream, fedd_timing_*) as children of
+// the running stacked timer: the StackedTimer report of the drivers' tails then shows where the GPU time went
+inline void addDeviceTimers(const DeviceContextPtr& dev, Teuchos::StackedTimer& st) {
+    static const char* names[FEDD_T_COUNT] = {"symbolic", "assemble", "rhs", "dirichlet", "spmv", "schwarz setup", "schwarz apply",
+                                             "orthogonalisation", "coarse setup", "coarse apply", "halo", "all-reduce", "spmv setup"};
+    for (int t = 0; t < FEDD_T_COUNT; ++t) {
+        double ms = 0.;
+        int64_t n = 0;
+        if (fedd_timing_get(dev->ctx, t, &ms, &n) == 0 && n > 0) st.addExternal(std::string("FEDD - device - ") + names[t], 1e-3 * ms, (long)n);
+    }
+}
 
 }  // namespace FEDD

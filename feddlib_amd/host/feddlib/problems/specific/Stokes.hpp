@@ -1,0 +1,3 @@
+// Forwarding header: same include path as the reference, one facade implementation.
+#pragma once
+#include "../../fedd_facade.hpp"

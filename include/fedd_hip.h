@@ -124,6 +124,33 @@ int fedd_mesh_p2_build(int dim, int64_t n_vert, int64_t n_elem, const int32_t* c
                        int volume_id, int32_t* conn_p2, double* xyz_p2, int32_t* flag_p2);
 
 /* ------------------------------------------------------------------------------------------------
+ * element partitioner for unstructured meshes, host side: replaces MeshPartitioner::readAndPartitionMesh and the maps
+ * it builds (feddlib/core/Mesh/MeshPartitioner_def.hpp:224-530; METIS_PartMeshDual :324, repeated map :358-397,
+ * Map::buildUniqueMap Map_def.hpp:184-210) with a deterministic balanced recursive coordinate bisection of the element
+ * centroids (every element on exactly one part).  conn holds GLOBAL node ids (0-based), nen nodes per element, the
+ * first dim + 1 of them the vertices.
+ *   fedd_mesh_partition          elem_part[n_elem] in [0, nparts)
+ *   fedd_mesh_partition_sizes    sizes of rank's mesh: its own elements + `ghost_layers` layers of elements around
+ *                                the owned nodes (1: owned rows complete; L >= 2: also the rows of the ghost nodes within
+ *                                L - 1 layers, the row ghosts of fedd_mesh_set_rows)
+ *   fedd_mesh_partition_extract  the rank's mesh in the form fedd_mesh_set / fedd_mesh_set_rows / fedd_halo_set_owners
+ *                                take: local connectivity, coordinates, repeated map (ascending global ids) with flags
+ *                                and owner ranks (lowest rank among the parts whose own elements hold the node),
+ *                                unique map, row ghosts; elem_gid = global ids of the local elements.  Any output may
+ *                                be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int fedd_mesh_partition(int dim, int nen, int64_t n_elem, const int32_t* conn, int64_t n_node, const double* xyz,
+                        int nparts, int32_t* elem_part);
+int fedd_mesh_partition_sizes(int nen, int64_t n_elem, const int32_t* conn, int64_t n_node, const int32_t* elem_part,
+                              int nparts, int rank, int ghost_layers, int64_t* n_elem_loc, int64_t* n_rep, int64_t* n_uni,
+                              int64_t* n_row_ghosts);
+int fedd_mesh_partition_extract(int dim, int nen, int64_t n_elem, const int32_t* conn, int64_t n_node, const double* xyz,
+                                const int32_t* flag, const int32_t* elem_part, int nparts, int rank, int ghost_layers,
+                                int32_t* conn_loc, double* xyz_loc, int64_t* gid_rep, int32_t* flag_rep, int32_t* owner_rep,
+                                int64_t* gid_uni, int32_t* flag_uni, int64_t* row_ghost_gid, int32_t* row_ghost_flag,
+                                int64_t* elem_gid);
+
+/* ------------------------------------------------------------------------------------------------
  * reference-element tables the assembly kernels stage in LDS (host side, no GPU needed): quadrature points and
  * weights of FE::getQuadratureValues (feddlib/core/FE/FE_def.hpp:6023-6727, degree remapping included) and the
  * values / gradients of FE::phi / FE::gradPhi (:4947-5087, :5565-5713) at those points.  Read-back for parity

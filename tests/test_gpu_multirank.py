@@ -9,6 +9,8 @@ import socket
 import numpy as np
 import pytest
 
+import scipy.sparse as sp
+
 import fedd_oracle as fo
 
 pytestmark = pytest.mark.gpu
@@ -568,3 +570,72 @@ def test_cfg5_miniature_gdsw_on_eight_ranks(fedd_lib):
     finally:
         c.close()
     assert abs(out[0]["its"] - its1) <= 1
+
+
+def _thread_rank_unstructured(capi, group, rank, m, part, layers, out, errs):
+    try:
+        world = group.world
+        pm = capi.partitioned_mesh(m, part, world, rank, ghosts=layers)
+        c = capi.Context(device=0, rank=rank, nranks=world, nccl_id=None)
+        c.mesh_set_dict(pm)
+        c.halo_set_owners(pm["gid_rep"], pm["owner_rep"])
+        c.comm_set_thread_group(group)
+        c.pattern_build(1, capi.BLOCK_SCALAR)
+        c.assemble(capi.FORM_LAPLACE)
+        c.assemble_rhs([1.0])
+        c.dirichlet([1, 2, 4], [0.0, 0.0, 0.0])
+        rowptr, col, val, gid = c.csr_get()
+        xg = np.random.default_rng(13).standard_normal(m["xyz"].shape[0])
+        y = c.spmv(xg[pm["gid_uni"]])
+        c.schwarz_set_target(8, 1.0)
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+        x, its, rel = c.gmres(None, rtol=1e-13, max_it=800, restart=200, use_prec=True)
+        out[rank] = dict(gu=pm["gid_uni"], x=x, its=its, rel=rel, y=y, rhs=c.rhs_get(), rowptr=rowptr, col=col, val=val, gid=gid)
+        c.close()
+    except Exception as e:      # pragma: no cover
+        import traceback
+        errs.append("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+        try:
+            group._barrier.abort()
+        except Exception:
+            pass
+
+
+@pytest.mark.parametrize("world,layers", [(2, 2), (4, 2), (4, 1)])
+def test_partitioned_unstructured_mesh_on_several_ranks(fedd_lib, world, layers):
+    """The reference's DFG3DCylinder_1k.mesh split by the element partitioner (mesh_partition.cpp: what
+    MeshPartitioner::readAndPartitionMesh + METIS do in the reference) over 2 and 4 ranks (threads, host-staged
+    transport): distributed assembly of the owned rows from the ghost-element layers, halo exchange, SpMV and the
+    Schwarz-preconditioned solve against the one-rank oracle of the whole mesh."""
+    import threading
+    GOLD = os.path.join(ROOT, "tests", "golden")
+    m = fedd_lib.read_mesh(os.path.join(GOLD, "DFG3DCylinder_1k.mesh"), 3)
+    part = fedd_lib.partition_mesh(m, world)
+    group = fedd_lib.ThreadGroup(world)
+    out, errs = [None] * world, []
+    th = [threading.Thread(target=_thread_rank_unstructured, args=(fedd_lib, group, r, m, part, layers, out, errs)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errs, "\n".join(errs)
+    om = fo.Mesh(dim=3, fe="P1", conn=m["conn"], xyz=m["xyz"], gid_rep=m["gid_rep"], flag_rep=m["flag_rep"],
+                 gid_uni=m["gid_uni"], flag_uni=m["flag_uni"], xyz_uni=None, n_global=m["n_global"])
+    A_bc, rhs_bc, _, _, _ = fo.laplace_problem(om, bc_flags=(1, 2, 4))
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    yref = A_bc @ np.random.default_rng(13).standard_normal(m["xyz"].shape[0])
+    x = np.zeros_like(xd)
+    covered = np.zeros(xd.shape[0], dtype=int)
+    for o in out:
+        covered[o["gu"]] += 1
+        x[o["gu"]] = o["x"]
+        n_own = o["gu"].shape[0]
+        # owned rows of the distributed matrix = the same rows of the one-rank matrix
+        Aloc = sp.csr_matrix((o["val"], o["gid"][o["col"]], o["rowptr"]), shape=(n_own, xd.shape[0]))
+        assert abs(Aloc - A_bc[o["gu"]]).max() <= 1e-12 * abs(A_bc).max()
+        np.testing.assert_allclose(o["rhs"], rhs_bc[o["gu"]], rtol=0, atol=1e-14 * np.abs(rhs_bc).max() + 1e-300)
+        np.testing.assert_allclose(o["y"], yref[o["gu"]], rtol=0, atol=1e-11 * np.abs(yref).max())
+        assert o["rel"] <= 1e-13
+    assert (covered == 1).all()
+    assert len({o["its"] for o in out}) == 1
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
