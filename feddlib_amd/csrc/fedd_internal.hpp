@@ -218,6 +218,7 @@ struct fedd_ctx {
     int sw_big_target = 0;                      // owned dofs per box of the bisection (0 = default 120)
     fedd::DevBuf<double> d_big_ws;              // dense matrices of one chunk of subdomains
     fedd::DevBuf<int32_t> d_big_nblk;           // 64-blocks per subdomain
+    fedd::DevBuf<int32_t> d_big_ids, d_big_pos; // subdomains taken by the batched dense inversion (compacted ids)
 
     // ---- coarse level (two-level Schwarz) ----
     int sw_two_level = 0;
@@ -351,6 +352,8 @@ int schwarz_setup_big(fedd_ctx* c);
 int schwarz_apply_big(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool r_has_tail);
 int schwarz_overlap_lists_big(fedd_ctx* c, int64_t nsub, int32_t* max_n, int32_t* max_own);
 int schwarz_slab_offsets(fedd_ctx* c, int64_t nsub, int restricted);
+int schwarz_dense_batched(fedd_ctx* c, int64_t nsub, int dstride, int n_lo, int32_t p_off, int restricted, int max_n,
+                          int32_t* d_bad);
 
 // invert_mfma.hip: local inverses of plain systems, n <= 128, on the f64 matrix cores
 int schwarz_invert_mfma(fedd_ctx* c, int restricted, int32_t* d_bad, int max_n);

@@ -449,87 +449,8 @@ __global__ __launch_bounds__(256, (T <= 7 ? 4 : 2)) void k_invert_reg(const int3
     }
 }
 
-// Extract A_i, invert it in place by Gauss-Jordan without pivoting (the local matrices are
-// unit rows for Dirichlet dofs plus an SPD free-free block, for which elimination in the natural
-// order is stable), write the needed rows of the inverse as a column-major slab [c][rp].
-// LDS = true: the matrix lives in LDS (n*ld*8 <= ~150 KB); else in a global workspace.
-// Fallback for subdomains with more than 128 dofs; smaller ones take k_invert_reg.
-template <bool LDS>
-__global__ __launch_bounds__(256) void k_invert(const int32_t* __restrict__ sub_n,
-                                                const int32_t* __restrict__ sub_nown,
-                                                const int32_t* __restrict__ sub_dofs,
-                                                const int32_t* __restrict__ rowptr,
-                                                const int32_t* __restrict__ colind,
-                                                const double* __restrict__ val, int32_t n_rows, int restricted,
-                                                const int64_t* __restrict__ inv_ptr, double* __restrict__ inv,
-                                                double* __restrict__ work, int64_t work_stride, int lds_nmax,
-                                                int32_t* __restrict__ bad, int first_bin, int only_large,
-                                                int n_skip, int32_t p_off) {
-    extern __shared__ double sm[];
-    __shared__ int32_t sdof[NMAX];
-    const int b = first_bin + blockIdx.x, tid = threadIdx.x;
-    const int n = sub_n[b];
-    if (n > NMAX || n <= n_skip) return;  // n <= n_skip: done by k_invert_reg
-    // the LDS launch skips subdomains that do not fit; the global launch takes only those
-    if (LDS && n > lds_nmax) return;
-    if (!LDS && only_large && n <= lds_nmax) return;
-    const int no = sub_nown[b];
-    const int ld = n | 1;  // odd leading dimension: column walks hit distinct banks
-    double* A = LDS ? sm : work + (int64_t)blockIdx.x * work_stride;
-    double* colbuf = LDS ? sm + (int64_t)lds_nmax * (lds_nmax | 1) : A + (int64_t)NMAX * (NMAX | 1);
-    double* rowbuf = colbuf + NMAX;
-    for (int k = tid; k < n; k += 256) sdof[k] = sub_dofs[(int64_t)b * NMAX + k];
-    for (int k = tid; k < n * ld; k += 256) A[k] = 0.0;
-    __syncthreads();
-    for (int r = tid; r < n; r += 256) {
-        const int32_t g = sdof[r];
-        if (g < n_rows) {
-            for (int32_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
-                const int32_t col = colind[p];
-                int cidx = bsearch_i32(sdof, no, col);
-                if (cidx < 0) {
-                    cidx = bsearch_i32(sdof + no, n - no, col);
-                    if (cidx >= 0) cidx += no;
-                }
-                if (cidx >= 0) A[r * ld + cidx] = val[p];
-            }
-        } else {
-            A[r * ld + r] = 1.0;  // ghost row (not stored on this rank): identity
-        }
-    }
-    __syncthreads();
-    const int tx = tid & 63, ty = tid >> 6;
-    const int npass = p_off == INT32_MAX ? 1 : 2;  // velocities first, then pressures (see k_invert_reg)
-    for (int pass = 0; pass < npass; ++pass)
-    for (int k = 0; k < n; ++k) {
-        if (npass == 2 && (sdof[k] >= p_off) != (pass == 1)) continue;
-        const double piv = A[k * ld + k];
-        if (tid == 0 && !(fabs(piv) > 1e-300)) bad[0] = 1;
-        const double pinv = 1.0 / piv;
-        for (int i = tid; i < n; i += 256) {
-            colbuf[i] = A[i * ld + k];
-            rowbuf[i] = A[k * ld + i] * pinv;
-        }
-        __syncthreads();
-        for (int i = ty; i < n; i += 4) {
-            const double f = colbuf[i];
-            double* Ai = A + i * ld;
-            if (i == k) {
-                for (int j = tx; j < n; j += 64) Ai[j] = j == k ? pinv : rowbuf[j];
-            } else {
-                for (int j = tx; j < n; j += 64) Ai[j] = j == k ? -f * pinv : Ai[j] - f * rowbuf[j];
-            }
-        }
-        __syncthreads();
-    }
-    const int nrow = restricted ? no : n;
-    const int rp = slab_ld(nrow);
-    double* slab = inv + inv_ptr[b];
-    for (int e = tid; e < n * rp; e += 256) {
-        const int c = e / rp, r = e - c * rp;
-        slab[e] = r < nrow ? A[r * ld + c] : 0.0;
-    }
-}
+// (Subdomains beyond the register-tiled classes, 161 .. 256 dofs, are inverted by the batched blocked Gauss-Jordan of
+// dense.hip through schwarz_dense_batched; the LDS / global-memory scalar sweep that used to take them ran at ~1 % of peak.)
 
 // z (+)= P_i A_i^-1 R_i r for every subdomain; thread (r, s) accumulates row r over columns
 // c == s (mod S), so the S*rp active lanes read the slab as one contiguous stream.
@@ -970,34 +891,11 @@ int schwarz_setup(fedd_ctx* c) {
 #undef INV_REG1
 #undef INV_REG
     }
+    // subdomains beyond the register-tiled classes (161 .. 256 dofs): batched blocked Gauss-Jordan on the f64 matrix
+    // cores (dense.hip).  (Before: an LDS / global-memory scalar sweep at ~1 % of peak: 166 375 subdomains of <= 216 dofs
+    // -- 64-node boxes on the 214^3 grid -- took 3.3 s, 27-node boxes with overlap 2, <= 343 -> 247 dofs, 23.7 s.)
     const int n_skip = 160;
-    if (max_n > n_skip) {
-        // largest n whose matrix (odd leading dimension) plus the two pivot buffers fits 150 KB of LDS
-        int lds_nmax = std::min(max_n, 134);
-        const size_t lds = ((size_t)lds_nmax * (lds_nmax | 1) + 2 * NMAX) * sizeof(double);
-        FEDD_HIP(hipFuncSetAttribute((const void*)k_invert<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (lds_nmax > n_skip)  // (the register-tiled classes now reach past what fits LDS)
-        hipLaunchKernelGGL(k_invert<true>, dim3((unsigned)nsub), blk, lds, c->stream, (const int32_t*)c->d_sub_n.p,
-                           (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const int32_t*)c->d_rowptr.p,
-                           (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, n_stored, restricted,
-                           (const int64_t*)c->d_inv_ptr.p, c->d_inv.p, (double*)nullptr, (int64_t)0, lds_nmax, d_bad, 0, 0,
-                           n_skip, p_off);
-        if (max_n > lds_nmax) {
-            // too large for LDS: same algorithm on a global (L2-resident) workspace, in chunks of
-            // 1024 workgroups so that the workspace stays bounded
-            const int64_t stride = (int64_t)NMAX * (NMAX | 1) + 2 * NMAX;
-            const int chunk = 1024;
-            FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)stride * chunk, c->d_w.cap)));
-            for (int64_t first = 0; first < nsub; first += chunk) {
-                const int nb = (int)std::min<int64_t>(chunk, nsub - first);
-                hipLaunchKernelGGL(k_invert<false>, dim3(nb), blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
-                                   (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
-                                   (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p,
-                                   (const double*)c->d_val.p, n_stored, restricted, (const int64_t*)c->d_inv_ptr.p,
-                                   c->d_inv.p, c->d_w.p, stride, lds_nmax, d_bad, (int)first, 1, n_skip, p_off);
-            }
-        }
-    }
+    if (max_n > n_skip) FEDD_TRY(schwarz_dense_batched(c, nsub, NMAX, n_skip, p_off, restricted, max_n, d_bad));
     int32_t bad = 0;
     FEDD_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     FEDD_HIP(hipStreamSynchronize(c->stream));

@@ -63,12 +63,14 @@ __global__ __launch_bounds__(256) void k_big_extract(const int32_t* __restrict__
                                                      const int32_t* __restrict__ sub_dofs,
                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                      const double* __restrict__ val, int32_t n_stored, int32_t p_off,
+                                                     const int32_t* __restrict__ ids, int dstride,
                                                      int first, double* __restrict__ Wall, int64_t ld, int64_t stride,
                                                      int32_t* __restrict__ nblk) {
     __shared__ int32_t sdof[NMB];
     __shared__ int16_t pos[NMB];
     __shared__ int32_t s_nv;
-    const int slot = blockIdx.x, b = first + slot, tid = threadIdx.x;
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const int b = ids ? ids[first + slot] : first + slot;
     const int n = sub_n[b], no = sub_nown[b];
     double* __restrict__ W = Wall + (int64_t)slot * stride;
     const int np = ((n + 63) / 64) * 64;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void k_big_extract(const int32_t* __restrict__
         nblk[slot] = np / 64;
         s_nv = 0;
     }
-    for (int k = tid; k < n; k += 256) sdof[k] = sub_dofs[(int64_t)b * NMB + k];
+    for (int k = tid; k < n; k += 256) sdof[k] = sub_dofs[(int64_t)b * dstride + k];
     __syncthreads();
     // velocities (dof < p_off) keep their relative order in front, pressures follow
     int nv_mine = 0;
@@ -138,14 +140,16 @@ __global__ __launch_bounds__(256) void k_big_extract(const int32_t* __restrict__
 // needed rows of the inverse -> slab [c][nrow] (column-major, schwarz.hip's layout), original dof order
 __global__ __launch_bounds__(256) void k_big_slab(const int32_t* __restrict__ sub_n, const int32_t* __restrict__ sub_nown,
                                                   const int32_t* __restrict__ sub_dofs, int32_t p_off, int restricted,
+                                                  const int32_t* __restrict__ ids, int dstride,
                                                   int first, const double* __restrict__ Wall, int64_t ld, int64_t stride,
                                                   const int64_t* __restrict__ inv_ptr, double* __restrict__ inv) {
     __shared__ int16_t pos[NMB];
     __shared__ int32_t s_nv;
-    const int slot = blockIdx.x, b = first + slot, tid = threadIdx.x;
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const int b = ids ? ids[first + slot] : first + slot;
     const int n = sub_n[b], no = sub_nown[b];
     const double* __restrict__ W = Wall + (int64_t)slot * stride;
-    const int32_t* __restrict__ sd = sub_dofs + (int64_t)b * NMB;
+    const int32_t* __restrict__ sd = sub_dofs + (int64_t)b * dstride;
     if (tid == 0) s_nv = 0;
     __syncthreads();
     int nv_mine = 0;
@@ -230,7 +234,56 @@ __global__ void k_div_big(double* __restrict__ z, const double* __restrict__ m, 
     if (i < n) z[i] = z[i] / m[i];
 }
 
+__global__ void k_big_flag(const int32_t* __restrict__ sub_n, int32_t nsub, int n_lo, int32_t* __restrict__ flag) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nsub) flag[b] = sub_n[b] > n_lo ? 1 : 0;
+}
+
+__global__ void k_big_compact(const int32_t* __restrict__ sub_n, int32_t nsub, int n_lo, const int32_t* __restrict__ pos,
+                              int32_t* __restrict__ ids) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nsub && sub_n[b] > n_lo) ids[pos[b]] = b;
+}
+
 }  // namespace
+
+// Dense inverses of every subdomain with more than n_lo dofs (lists in d_sub_dofs with `dstride` entries per
+// subdomain): extraction, batched Gauss-Jordan on the matrix cores, slab rows; a chunk of subdomains at a time.
+int schwarz_dense_batched(fedd_ctx* c, int64_t nsub, int dstride, int n_lo, int32_t p_off, int restricted, int max_n,
+                          int32_t* d_bad) {
+    FEDD_CHECK(max_n <= NMB && nsub < ((int64_t)1 << 31), "schwarz_dense_batched: subdomain of %d dofs", max_n);
+    const dim3 blk(256), gs((unsigned)((nsub + 255) / 256));
+    const int32_t* ids = nullptr;
+    int64_t nsel = nsub;
+    if (n_lo > 0) {
+        FEDD_TRY(c->d_big_ids.ensure((size_t)nsub + 1));
+        FEDD_TRY(c->d_big_pos.ensure((size_t)nsub + 1));
+        hipLaunchKernelGGL(k_big_flag, gs, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p, (int32_t)nsub, n_lo, c->d_big_pos.p);
+        FEDD_TRY(exclusive_scan_i32(c, c->d_big_pos.p, c->d_big_pos.p, nsub, &nsel));
+        if (nsel == 0) return 0;
+        hipLaunchKernelGGL(k_big_compact, gs, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p, (int32_t)nsub, n_lo,
+                           (const int32_t*)c->d_big_pos.p, c->d_big_ids.p);
+        ids = c->d_big_ids.p;
+    }
+    const int64_t ld = ((int64_t)max_n + 63) / 64 * 64, stride = ld * ld;
+    const int64_t budget = (int64_t)4 << 30;   // bytes of dense workspace
+    const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nsel, 65535), budget / (stride * 8)));
+    FEDD_TRY(c->d_big_ws.ensure((size_t)chunk * (size_t)stride));
+    FEDD_TRY(c->d_big_nblk.ensure((size_t)chunk));
+    for (int64_t first = 0; first < nsel; first += chunk) {
+        const int nb = (int)std::min<int64_t>(chunk, nsel - first);
+        hipLaunchKernelGGL(k_big_extract, dim3(nb), blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
+                           (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const int32_t*)c->d_rowptr.p,
+                           (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, (int32_t)c->n_rows_ext, p_off, ids, dstride,
+                           (int)first, c->d_big_ws.p, ld, stride, c->d_big_nblk.p);
+        FEDD_TRY(dense_invert_batched(c, c->d_big_ws.p, ld, nb, stride, c->d_big_nblk.p, (int)(ld / 64), 0, d_bad));
+        hipLaunchKernelGGL(k_big_slab, dim3(nb), blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
+                           (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, p_off, restricted, ids, dstride,
+                           (int)first, (const double*)c->d_big_ws.p, ld, stride, (const int64_t*)c->d_inv_ptr.p, c->d_inv.p);
+    }
+    FEDD_HIP(hipGetLastError());
+    return 0;
+}
 
 bool schwarz_use_big(const fedd_ctx* c) { return c->sw_big > 0 || (c->sw_big < 0 && c->merged); }
 
@@ -308,23 +361,8 @@ int schwarz_setup_big(fedd_ctx* c) {
     FEDD_TRY(c->d_flags.ensure(16));
     int32_t* d_bad = c->d_flags.p + 1;
     FEDD_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), c->stream));
-    const int64_t ld = ((int64_t)max_n + 63) / 64 * 64, stride = ld * ld;
-    const int64_t budget = (int64_t)4 << 30;   // bytes of dense workspace
-    const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nsub, 65535), budget / (stride * 8)));
-    FEDD_TRY(c->d_big_ws.ensure((size_t)chunk * (size_t)stride));
-    FEDD_TRY(c->d_big_nblk.ensure((size_t)chunk));
     const int32_t p_off = c->merged ? (int32_t)c->merged_nA : INT32_MAX;
-    for (int64_t first = 0; first < nsub; first += chunk) {
-        const int nb = (int)std::min<int64_t>(chunk, nsub - first);
-        hipLaunchKernelGGL(k_big_extract, dim3(nb), dim3(256), 0, c->stream, (const int32_t*)c->d_sub_n.p,
-                           (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const int32_t*)c->d_rowptr.p,
-                           (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, (int32_t)c->n_rows_ext, p_off, (int)first,
-                           c->d_big_ws.p, ld, stride, c->d_big_nblk.p);
-        FEDD_TRY(dense_invert_batched(c, c->d_big_ws.p, ld, nb, stride, c->d_big_nblk.p, (int)(ld / 64), 0, d_bad));
-        hipLaunchKernelGGL(k_big_slab, dim3(nb), dim3(256), 0, c->stream, (const int32_t*)c->d_sub_n.p,
-                           (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, p_off, restricted, (int)first,
-                           (const double*)c->d_big_ws.p, ld, stride, (const int64_t*)c->d_inv_ptr.p, c->d_inv.p);
-    }
+    FEDD_TRY(schwarz_dense_batched(c, nsub, NMB, 0, p_off, restricted, max_n, d_bad));
     int32_t bad = 0;
     FEDD_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     FEDD_HIP(hipStreamSynchronize(c->stream));

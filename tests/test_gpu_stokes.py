@@ -264,7 +264,12 @@ def test_cfg4_stokes_solve_on_the_6k_cylinder(fedd_lib):
         M = sp.csr_matrix((val, col, rowptr), shape=(n, n))
         b = c.rhs_get()
         assert np.linalg.norm(b - M @ x) / np.linalg.norm(b) <= 1e-11
-        xd = fo.direct_solve(M, b)
+        # the sparse direct solution of the ORACLE's system (tests/golden/make_stokes_fixture.py: scipy SuperLU with
+        # iterative refinement takes ten minutes, so it is a committed fixture); it must also solve the DEVICE's system
+        gold = np.load(os.path.join(GOLD, "stokes_6k_direct.npz"))
+        xd = gold["x"]
+        assert xd.shape[0] == n and int(gold["nv"]) == nv
+        assert np.linalg.norm(b - M @ xd) / np.linalg.norm(b) <= 1e-12
         err = np.abs(x - xd).max() / np.abs(xd).max()
         assert err <= 1e-9, err
         # velocity and pressure separately (the pressure is the badly scaled part of the vector)
