@@ -83,6 +83,20 @@ def _cycle_cols(its, restart):
     return full * restart * (restart + 1) // 2 + rest * (rest + 1) // 2
 
 
+def _recorded_full_cpu_run(full_cells):
+    """the full-grid CPU run of this round (bench.py --cpu-full on a GPU box, committed as profiles/cpu_full.json): the
+    measured partner of the extrapolated figure, quoted when it is of the same grid"""
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "cpu_full.json")))
+        if pj.get("cells") == full_cells:
+            cb = pj["cpu_baseline"]
+            return {"value": cb["value"], "seconds": cb["seconds"], "cores": cb["cores"], "sample": cb["sample"],
+                    "source": "profiles/cpu_full.json (" + pj.get("command", "") + ")"}
+    except Exception:
+        pass
+    return None
+
+
 def cpu_run(a, M, nthr):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c
@@ -126,7 +140,7 @@ def cpu_baseline(a, full_cells, gpu_its, full=False):
                       "recorded under profiles/ (bench.py --cpu-full)"
                       % (M, r["dofs"], desc, r["seconds"], r["dofs"] / r["seconds"], full_cells, scale, gpu_its, r["its"],
                          cols_f, cols_s, a.restart, t_full, a.target),
-            "seconds": t_full, "extrapolated": True,
+            "seconds": t_full, "extrapolated": True, "full_grid_measured": _recorded_full_cpu_run(full_cells),
             "sample_measured": {"cells": M, "dofs": r["dofs"], "seconds": r["seconds"], "value": r["dofs"] / r["seconds"],
                                 "gmres_iterations": r["its"]}}
 
