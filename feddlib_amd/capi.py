@@ -87,6 +87,7 @@ SIGNATURES = {
     "fedd_timing_reset": [C.c_void_p],
     "fedd_timing_get": [C.c_void_p, C.c_int, _f64p, _i64p],
     "fedd_read_bandwidth": [C.c_void_p, C.c_int64, C.c_int, _f64p],
+    "fedd_rccl_selftest": [C.c_void_p, C.c_int, _f64p],
     "fedd_halo_plan_sizes": [C.c_void_p, _ip, _i64p, _i64p],
     "fedd_halo_plan_get": [C.c_void_p, _i32p, _i64p, _i32p, _i64p, _i32p],
     "fedd_halo_set_owners": [C.c_void_p, C.c_int64, _i64p, _i32p],
@@ -660,6 +661,11 @@ class Context:
         from_me = np.array([int(everyone[p][0][rank]) for p in range(group.world)], dtype=np.int64)
         lists = [everyone[p][1][everyone[p][2][rank]:everyone[p][2][rank + 1]] for p in range(group.world)]
         self.halo_requests_set(from_me, np.concatenate(lists).astype(np.int64) if from_me.sum() else np.zeros(0, np.int64))
+
+    def rccl_selftest(self, n=4096):
+        e = C.c_double()
+        _chk(self._L.fedd_rccl_selftest(self._h, n, C.byref(e)))
+        return e.value
 
     def halo_exchange_setup(self):
         _chk(self._L.fedd_halo_exchange_setup(self._h))

@@ -8,6 +8,7 @@
 #include "fedd_internal.hpp"
 #include <rccl/rccl.h>
 #include <algorithm>
+#include <cmath>
 #include <unordered_map>
 
 namespace fedd {
@@ -235,6 +236,54 @@ extern "C" int fedd_halo_exchange_setup(fedd_ctx* c) {
     d_all.release();
     d_req.release();
     d_in.release();
+    return rc;
+}
+
+// One-rank RCCL self-test: the call shapes of this library's communication steps -- ncclCommInitRank, the grouped
+// ncclSend / ncclRecv of halo_import (to and from the only rank there is), ncclAllReduce(sum, f64) in place as in
+// allreduce_sum, ncclAllGather(int64) as in fedd_halo_exchange_setup -- on the context's stream, checked against the
+// expected values.  Development boxes have one GPU and RCCL refuses several ranks on one device, so this is the part
+// of the RCCL path that can run there; the multi-rank logic around it runs over the host-staged transport.
+extern "C" int fedd_rccl_selftest(fedd_ctx* c, int n, double* max_abs_err) {
+    FEDD_CHECK(c && c->device >= 0, "fedd_rccl_selftest needs a GPU context");
+    FEDD_CHECK(n > 0 && max_abs_err, "fedd_rccl_selftest: n %d", n);
+    FEDD_HIP(hipSetDevice(c->device));
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    FEDD_CHECK(r == ncclSuccess, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    ncclComm_t comm;
+    r = ncclCommInitRank(&comm, 1, id, 0);
+    FEDD_CHECK(r == ncclSuccess, "ncclCommInitRank(1 rank): %s", ncclGetErrorString(r));
+    DevBuf<double> a, b;
+    DevBuf<int64_t> g0, g1;
+    int rc = 0;
+    std::vector<double> h((size_t)n), out((size_t)n);
+    for (int i = 0; i < n; ++i) h[(size_t)i] = 0.5 + 1e-3 * i;
+    std::vector<int64_t> hg = {7, 11}, og(2, 0);
+    double err = 0.0;
+    do {
+        if ((rc = a.ensure((size_t)n)) || (rc = b.ensure((size_t)n)) || (rc = g0.ensure(2)) || (rc = g1.ensure(2))) break;
+        if (hipMemcpyAsync(a.p, h.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = 1; set_error("selftest: upload"); break; }
+        // grouped send / receive (halo_import's shape)
+        ncclResult_t bad = ncclGroupStart();
+        if (bad == ncclSuccess) bad = ncclSend(a.p, (size_t)n, ncclDouble, 0, comm, c->stream);
+        if (bad == ncclSuccess) bad = ncclRecv(b.p, (size_t)n, ncclDouble, 0, comm, c->stream);
+        r = ncclGroupEnd();
+        if (bad != ncclSuccess || r != ncclSuccess) { rc = 1; set_error("selftest send/recv: %s", ncclGetErrorString(bad != ncclSuccess ? bad : r)); break; }
+        // in-place all-reduce (allreduce_sum's shape): one rank -> unchanged
+        r = ncclAllReduce(b.p, b.p, (size_t)n, ncclDouble, ncclSum, comm, c->stream);
+        if (r != ncclSuccess) { rc = 1; set_error("selftest all-reduce: %s", ncclGetErrorString(r)); break; }
+        if (hipMemcpyAsync(g0.p, hg.data(), 16, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = 1; set_error("selftest: upload"); break; }
+        r = ncclAllGather(g0.p, g1.p, 2, ncclInt64, comm, c->stream);
+        if (r != ncclSuccess) { rc = 1; set_error("selftest all-gather: %s", ncclGetErrorString(r)); break; }
+        if (hipMemcpyAsync(out.data(), b.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(og.data(), g1.p, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { rc = 1; set_error("selftest: download"); break; }
+        for (int i = 0; i < n; ++i) err = std::max(err, std::abs(out[(size_t)i] - h[(size_t)i]));
+        if (og[0] != 7 || og[1] != 11) err = std::max(err, 1.0);
+    } while (false);
+    ncclCommDestroy(comm);
+    *max_abs_err = err;
     return rc;
 }
 

@@ -343,6 +343,11 @@ typedef int (*fedd_exchange_fn)(void* user, int n_peers, const int32_t* peers, c
 typedef int (*fedd_allreduce_fn)(void* user, double* buf, int n);
 int fedd_comm_set_host_callbacks(fedd_ctx* ctx, fedd_exchange_fn exchange, fedd_allreduce_fn allreduce, void* user);
 
+/* one-rank RCCL self-test on the context's device and stream: communicator, grouped send / receive, in-place
+ * all-reduce, all-gather -- the call shapes of the halo import and the Gram-Schmidt reductions (what can run of the
+ * RCCL path on a one-GPU box).  max_abs_err = deviation from the expected values (0 when RCCL works). */
+int fedd_rccl_selftest(fedd_ctx* ctx, int n, double* max_abs_err);
+
 int fedd_mesh_structured_owner(int dim, const int* decomp, const int* cells, int64_t n,
                                const int64_t* gid, int32_t* owner_rank);
 int fedd_halo_set_owners(fedd_ctx* ctx, int64_t n_rep, const int64_t* gid_rep, const int32_t* owner_rep);

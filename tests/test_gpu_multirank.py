@@ -639,3 +639,14 @@ def test_partitioned_unstructured_mesh_on_several_ranks(fedd_lib, world, layers)
     assert (covered == 1).all()
     assert len({o["its"] for o in out}) == 1
     np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
+
+
+def test_rccl_call_shapes_on_one_rank(fedd_lib):
+    """What can run of the RCCL path on a one-GPU box: a one-rank communicator on the library's stream, the grouped
+    ncclSend / ncclRecv of the halo import, the in-place f64 all-reduce of the Gram-Schmidt reductions and the int64
+    all-gather of the plan setup, against the expected values."""
+    c = fedd_lib.Context(device=0)
+    try:
+        assert c.rccl_selftest(100000) == 0.0
+    finally:
+        c.close()
