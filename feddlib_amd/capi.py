@@ -20,6 +20,7 @@ TIMER_NAMES = ["symbolic", "assemble", "rhs", "dirichlet", "spmv", "schwarz_setu
                "coarse_setup", "coarse_apply", "halo", "allreduce", "spmv_setup"]
 COARSE_Q1 = 1
 COARSE_GDSW = 2
+COARSE_RGDSW = 3
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)

@@ -542,9 +542,9 @@ extern "C" int fedd_schwarz_setup(fedd_ctx* c, int overlap, int combine, int two
     FEDD_CHECK(c->have_pattern, "fedd_schwarz_setup: assemble the matrix first");
     FEDD_CHECK(overlap >= 0 && overlap <= 4, "fedd_schwarz_setup: overlap %d", overlap);
     FEDD_CHECK(combine >= 0 && combine <= 2, "fedd_schwarz_setup: combine mode %d", combine);
-    FEDD_CHECK(two_level == 0 || coarse_kind == FEDD_COARSE_Q1 || coarse_kind == FEDD_COARSE_GDSW,
-               "fedd_schwarz_setup: coarse_kind %d is not built (FEDD_COARSE_Q1 = %d and FEDD_COARSE_GDSW = %d are)", coarse_kind,
-               FEDD_COARSE_Q1, FEDD_COARSE_GDSW);
+    FEDD_CHECK(two_level == 0 || coarse_kind == FEDD_COARSE_Q1 || coarse_kind == FEDD_COARSE_GDSW || coarse_kind == FEDD_COARSE_RGDSW,
+               "fedd_schwarz_setup: coarse_kind %d is not built (FEDD_COARSE_Q1 = %d, FEDD_COARSE_GDSW = %d and FEDD_COARSE_RGDSW = %d are)",
+               coarse_kind, FEDD_COARSE_Q1, FEDD_COARSE_GDSW, FEDD_COARSE_RGDSW);
     FEDD_CHECK(two_level == 0 || !c->merged,
                "fedd_schwarz_setup: the coarse level takes node-interleaved systems, not a merged block system");
     FEDD_HIP(hipSetDevice(c->device));

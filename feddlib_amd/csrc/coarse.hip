@@ -386,6 +386,60 @@ __device__ __forceinline__ void gd_entity_coords(const CoarseGeom& cg, int32_t i
     }
 }
 
+// Coarse dof numbering.  GDSW: every entity of the doubled lattice is a coarse "node" (id = entity id; cell interiors
+// and empty entities get a unit diagonal in K0).  RGDSW (cg.reduced): only the COARSE NODES -- the entities with an odd
+// coordinate in every direction that has more than one cell (the vertices of the decomposition; for slab / pencil
+// decompositions the faces / edges that have no lower-dimensional neighbour) -- numbered compactly:
+// id = sum_d ((e_d - 1) / 2) * stride over the directions with g_d >= 2.
+template <int DIM>
+__device__ __forceinline__ bool gd_is_coarse_node(const CoarseGeom& cg, const int e[3]) {
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) ok = ok && (cg.g[d] >= 2 ? (e[d] & 1) == 1 : e[d] == 0);
+    return ok;
+}
+
+template <int DIM>
+__device__ __forceinline__ int64_t gd_coarse_count(const CoarseGeom& cg) {
+    int64_t n = 1;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) n *= cg.reduced ? (cg.g[d] >= 2 ? cg.g[d] - 1 : 1) : 2 * cg.g[d] - 1;
+    return n;
+}
+
+// coarse id of entity e, -1 if it carries no coarse dof
+template <int DIM>
+__device__ __forceinline__ int32_t gd_coarse_id(const CoarseGeom& cg, const int e[3]) {
+    if (!cg.reduced) return gd_entity_id<DIM>(cg, e);
+    if (!gd_is_coarse_node<DIM>(cg, e)) return -1;
+    int32_t id = 0, mul = 1;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d)
+        if (cg.g[d] >= 2) {
+            id += mul * ((e[d] - 1) >> 1);
+            mul *= cg.g[d] - 1;
+        }
+    return id;
+}
+
+// entity coordinates of coarse id
+template <int DIM>
+__device__ __forceinline__ void gd_coarse_coords(const CoarseGeom& cg, int32_t id, int e[3]) {
+    if (!cg.reduced) {
+        gd_entity_coords<DIM>(cg, id, e);
+        return;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) e[d] = 0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d)
+        if (cg.g[d] >= 2) {
+            const int m = cg.g[d] - 1;
+            e[d] = 2 * (id % m) + 1;
+            id /= m;
+        }
+}
+
 // entity and home cell of every owned node from the cells of its incident elements
 template <int DIM>
 __global__ void k_gd_node_entity(CoarseGeom cg, const int32_t* __restrict__ conn, int nen, const double* __restrict__ xyz,
@@ -440,7 +494,27 @@ __global__ void k_gd_phi_init(CoarseGeom cg, const int32_t* __restrict__ ent, in
     const int cls = gd_class<DIM>(e);
     const int nsd = NCLS * dofs;
     for (int s = 0; s < nsd; ++s) phi[r * nsd + s] = 0.0;
-    if (cls >= 0) phi[r * nsd + cls * dofs + a] = mask[r];
+    if (cls >= 0 && !cg.reduced) phi[r * nsd + cls * dofs + a] = mask[r];
+    if (cls >= 0 && cg.reduced) {
+        // RGDSW, option 1 (Dohrmann, Widlund 2017): an interface node of entity e gets the value 1 / |C(e)| for every
+        // coarse node of C(e), the coarse nodes adjacent to e: e_d odd stays, an even e_d (direction with >= 2 cells)
+        // moves to e_d - 1 or e_d + 1 where that lies inside the lattice.  All of them are corners of the home cell.
+        int h[3] = {0, 0, 0};
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) h[d] = e[d] >> 1;
+        int count = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int c2 = 0; c2 < NCLS; ++c2) {
+                int v[3] = {0, 0, 0};
+                if (!gd_entity_of<DIM>(cg, h, c2, v) || !gd_is_coarse_node<DIM>(cg, v)) continue;
+                bool adj = true;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) adj = adj && ((e[d] & 1) ? v[d] == e[d] : (cg.g[d] >= 2 ? (v[d] == e[d] - 1 || v[d] == e[d] + 1) : v[d] == e[d]));
+                if (!adj) continue;
+                if (pass == 0) ++count;
+                else phi[r * nsd + c2 * dofs + a] = mask[r] / (double)count;
+            }
+    }
     imask[r] = cls < 0 ? mask[r] : 0.0;
 }
 
@@ -507,7 +581,7 @@ __global__ void k_gd_restrict_ent(CoarseGeom cg, int dofs, int64_t n_ent, const 
     const int32_t E = (int32_t)(t / dofs);
     const int k = (int)(t - (int64_t)E * dofs);
     int e[3];
-    gd_entity_coords<DIM>(cg, E, e);
+    gd_coarse_coords<DIM>(cg, E, e);
     const int cls = gd_class<DIM>(e);
     double sum = 0.0;
     if (cls >= 0) {
@@ -549,7 +623,8 @@ __global__ void k_gd_prolong(CoarseGeom cg, const int32_t* __restrict__ ent, int
     for (int cls = 0; cls < NCLS; ++cls) {
         int ee[3] = {0, 0, 0};
         if (!gd_entity_of<DIM>(cg, h, cls, ee)) continue;
-        const int64_t E = gd_entity_id<DIM>(cg, ee);
+        const int64_t E = gd_coarse_id<DIM>(cg, ee);
+        if (E < 0) continue;
         for (int k = 0; k < dofs; ++k) sum = fma(phi[r * nsd + cls * dofs + k], z0[E * dofs + k], sum);
     }
     if (ADD) z[r] += sum * mask[r];
@@ -566,7 +641,7 @@ __global__ void k_gd_colour(CoarseGeom cg, int dofs, int64_t n_ent, int k, GdCol
     const int32_t E = (int32_t)(t / dofs);
     const int kk = (int)(t - (int64_t)E * dofs);
     int e[3];
-    gd_entity_coords<DIM>(cg, E, e);
+    gd_coarse_coords<DIM>(cg, E, e);
     bool on = kk == k && gd_class<DIM>(e) >= 0;
 #pragma unroll
     for (int d = 0; d < DIM; ++d) on = on && (e[d] % 5) == col.c[d];
@@ -581,7 +656,7 @@ __global__ void k_gd_scatter_col(CoarseGeom cg, int dofs, int64_t n_ent, int k, 
     if (t >= n_ent * dofs) return;
     const int32_t E = (int32_t)(t / dofs);
     int e[3], ep[3] = {0, 0, 0};
-    gd_entity_coords<DIM>(cg, E, e);
+    gd_coarse_coords<DIM>(cg, E, e);
     if (gd_class<DIM>(e) < 0) return;
     bool ok = true;
 #pragma unroll
@@ -592,7 +667,8 @@ __global__ void k_gd_scatter_col(CoarseGeom cg, int dofs, int64_t n_ent, int k, 
         ok = ok && ep[d] >= 0 && ep[d] <= 2 * cg.g[d] - 2;
     }
     if (!ok || gd_class<DIM>(ep) < 0) return;
-    const int64_t Ep = gd_entity_id<DIM>(cg, ep);
+    const int64_t Ep = gd_coarse_id<DIM>(cg, ep);
+    if (Ep < 0) return;
     K[t * ld + Ep * dofs + k] = r0[t];
 }
 
@@ -760,10 +836,12 @@ static int gdsw_setup(fedd_ctx* c) {
     FEDD_TRY(global_box(c, n_own, lo, hi, &n_global));
     // ---- the coarse decomposition: cells of a regular lattice, g_d = max(1, floor(L_d / H + 0.5)) ----
     // default: one cell per 1000 nodes, at most 8^3 (scalar) / 5^3 (vector) cells: (2 g - 1)^dim * dofs coarse dofs
+    const bool reduced = c->co_kind == FEDD_COARSE_RGDSW;
     double target = c->co_cells_target;
-    if (!(target > 0)) target = std::min(dofs == 1 ? 512.0 : 125.0, std::max(1.0, std::floor(n_global / 1000.0)));
+    if (!(target > 0)) target = std::min(reduced ? 1728.0 : (dofs == 1 ? 512.0 : 125.0), std::max(1.0, std::floor(n_global / 1000.0)));
     CoarseGeom cg;
     cg.dim = dim;
+    cg.reduced = reduced ? 1 : 0;
     double V = 1.0;
     for (int d = 0; d < dim; ++d) V *= (hi[d] - lo[d] > 0 ? hi[d] - lo[d] : 1.0);
     const double H = std::pow(V / target, 1.0 / dim);
@@ -782,10 +860,10 @@ static int gdsw_setup(fedd_ctx* c) {
         cg.g[d] = g;
         cg.np[d] = g + 1;
         ncell *= g;
-        n_ent *= 2 * g - 1;
+        n_ent *= reduced ? (g >= 2 ? g - 1 : 1) : 2 * g - 1;
     }
     const int64_t n0 = n_ent * dofs;
-    FEDD_CHECK(n0 <= COARSE_MAX_DOFS, "GDSW setup: %lld coarse dofs ((2g - 1)^dim entities x %d), the dense coarse solver takes at "
+    FEDD_CHECK(n0 <= COARSE_MAX_DOFS, "GDSW setup: %lld coarse dofs ((2g - 1)^dim entities, RGDSW: (g - 1)^dim coarse nodes, x %d), the dense coarse solver takes at "
                "most %d; lower fedd_schwarz_set_coarse (now %g cells)", (long long)n0, dofs, COARSE_MAX_DOFS, target);
     const int64_t ld = (n0 + NB - 1) / NB * NB;
     c->co_geom = cg;
@@ -845,6 +923,15 @@ static int gdsw_setup(fedd_ctx* c) {
     int its_max = 0;
     double rel_max = 0.0;
     for (int slot = 0; slot < nsd; ++slot) {
+        if (reduced) {   // only the classes of coarse nodes carry functions: code 1 or 2 wherever there is more than one cell
+            int code = slot / dofs + 1;
+            bool vertex_class = true;
+            for (int d = 0; d < dim; ++d) {
+                vertex_class = vertex_class && (cg.g[d] >= 2 ? code % 3 != 0 : code % 3 == 0);
+                code /= 3;
+            }
+            if (!vertex_class) continue;
+        }
         FEDD_HIP(hipMemsetAsync(v, 0, (size_t)nc * sizeof(double), c->stream));
         hipLaunchKernelGGL(k_gd_gamma_col, gr, blk, 0, c->stream, (const double*)c->d_gd_phi.p, (const double*)c->d_gd_imask.p, n_rows,
                            nsd, slot, (const double*)c->d_co_mask.p, v);
@@ -869,7 +956,7 @@ static int gdsw_setup(fedd_ctx* c) {
     FEDD_HIP(hipMemsetAsync(c->d_co_K.p, 0, (size_t)ld * ld * sizeof(double), c->stream));
     const dim3 ge((unsigned)((n0 + 255) / 256));
     int ncol[3] = {1, 1, 1};
-    for (int d = 0; d < dim; ++d) ncol[d] = std::min(5, 2 * cg.g[d] - 1);
+    for (int d = 0; d < dim; ++d) ncol[d] = std::min(5, 2 * cg.g[d] - 1);   // (RGDSW: colours without a coarse node give zero columns)
     for (int c2 = 0; c2 < ncol[2]; ++c2)
         for (int c1 = 0; c1 < ncol[1]; ++c1)
             for (int c0 = 0; c0 < ncol[0]; ++c0)
@@ -923,7 +1010,7 @@ static int gdsw_apply_add(fedd_ctx* c, const double* d_r_owned, double* d_z_owne
 }
 
 int coarse_setup(fedd_ctx* c) {
-    if (c->co_kind == FEDD_COARSE_GDSW) return gdsw_setup(c);
+    if (c->co_kind == FEDD_COARSE_GDSW || c->co_kind == FEDD_COARSE_RGDSW) return gdsw_setup(c);
     ScopedTimer timer(c, FEDD_T_COARSE_SETUP);
     const int dim = c->dim, dofs = c->dofs;
     const int32_t n_own = (int32_t)c->n_own;
@@ -1061,7 +1148,7 @@ int coarse_setup(fedd_ctx* c) {
 }
 
 int coarse_apply_add(fedd_ctx* c, const double* d_r_owned, double* d_z_owned) {
-    if (c->co_kind == FEDD_COARSE_GDSW) return gdsw_apply_add(c, d_r_owned, d_z_owned);
+    if (c->co_kind == FEDD_COARSE_GDSW || c->co_kind == FEDD_COARSE_RGDSW) return gdsw_apply_add(c, d_r_owned, d_z_owned);
     ScopedTimer timer(c, FEDD_T_COARSE_APPLY);
     const int dim = c->dim, dofs = c->dofs;
     const CoarseGeom cg = c->co_geom;

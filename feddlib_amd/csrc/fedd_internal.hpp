@@ -111,6 +111,7 @@ struct CoarseGeom {
     int dim = 0;
     int g[3] = {1, 1, 1}, np[3] = {1, 1, 1};
     double lo[3] = {0, 0, 0}, L[3] = {1, 1, 1};
+    int reduced = 0;   // GDSW family: 1 = RGDSW (coarse dofs on the coarse nodes only), 0 = GDSW (every interface entity)
 };
 constexpr int COARSE_MAX_DOFS = 8192;   // dense K0^-1: 8192^2 * 8 B = 512 MiB
 

@@ -821,11 +821,11 @@ int LinearSolver<SC, LO, GO, NO>::solve(Problem_Type* problem, BlockMultiVectorP
         // "TwoLevel" = true (parametersPrec.xml:17) switches the coarse level on.  The coarse space is
         // this library's lattice space, not FROSch's GDSW: say so.
         const bool twoLevel = frosch.get("TwoLevel", false);
-        // "CoarseOperator Type" (parametersPrec.xml:23): GDSWCoarseOperator -> the library's GDSW level on the coarse
-        // lattice; RGDSW / IPOUHarmonic are not built and run GDSW too (said so); "Q1" selects the lattice hat functions
+        // "CoarseOperator Type" (parametersPrec.xml:23): GDSWCoarseOperator / RGDSWCoarseOperator -> the library's GDSW /
+        // RGDSW level on the coarse lattice; IPOUHarmonic is not built and runs GDSW (said so); "Q1" = lattice hat functions
         const std::string coarseType = frosch.get("CoarseOperator Type", "GDSWCoarseOperator");
-        const int coarseKind = coarseType == "Q1" ? FEDD_COARSE_Q1 : FEDD_COARSE_GDSW;
-        if (twoLevel && problem->getVerbose() && coarseType != "GDSWCoarseOperator" && coarseType != "Q1")
+        const int coarseKind = coarseType == "Q1" ? FEDD_COARSE_Q1 : (coarseType == "RGDSWCoarseOperator" ? FEDD_COARSE_RGDSW : FEDD_COARSE_GDSW);
+        if (twoLevel && problem->getVerbose() && coarseType != "GDSWCoarseOperator" && coarseType != "RGDSWCoarseOperator" && coarseType != "Q1")
             std::cout << "-- note: CoarseOperator Type " << coarseType << " is not built; running GDSWCoarseOperator --" << std::endl;
         const int target = frosch.get("Subdomain Nodes", 0);   // 0 = the library's default (27 / dofs per node)
         feddCheck(fedd_schwarz_set_target(ctx, target, 1.0), "fedd_schwarz_set_target");

@@ -268,6 +268,12 @@ int fedd_spmv_info(fedd_ctx* ctx, int64_t* nnz_pattern, int64_t* nnz_streamed);
  * one-level Schwarz on the constrained operator, option "gdsw_tol", default 1e-10), K0 = Phi^T A Phi inverted on the
  * matrix cores.  (2g - 1)^dim * dofs coarse dofs for g cells per direction. */
 #define FEDD_COARSE_GDSW 2
+/* FEDD_COARSE_RGDSW: the reduced GDSW space (FROSch RGDSWCoarseOperator, the one steadyLinElas_Perf/parametersPrec.xml:18
+ * names; Dohrmann & Widlund 2017, option 1): coarse functions only for the coarse nodes of the same decomposition (its
+ * vertices; for slab / pencil decompositions the interface components without lower-dimensional neighbours), an interface
+ * node of component e carrying 1 / |C(e)| for each adjacent coarse node; harmonic extensions and K0 as for GDSW.
+ * (g - 1)^dim * dofs coarse dofs: the default lattice may be as fine as the Q1 one (one cell per 1000 nodes, <= 12^3). */
+#define FEDD_COARSE_RGDSW 3
 int fedd_schwarz_setup(fedd_ctx* ctx, int overlap, int combine, int two_level, int coarse_kind);
 /* target_nodes = 0 (the default): 27 nodes for scalar problems, 27 / dofs-per-node for vector ones */
 int fedd_schwarz_set_target(fedd_ctx* ctx, int target_nodes, double scale);

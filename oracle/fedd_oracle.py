@@ -1028,7 +1028,12 @@ class CoarseGDSW:
         rest a relative diagonal shift of 1e-12); the level adds Phi K0^-1 Phi^T."""
 
     def __init__(self, A: sp.csr_matrix, conn: np.ndarray, xyz: np.ndarray, is_dir: np.ndarray, dofs: int = 1,
-                 cells_target: float = 8.0, lo=None, L=None):
+                 cells_target: float = 8.0, lo=None, L=None, reduced: bool = False):
+        """reduced = True: RGDSW, option 1 (FEDD_COARSE_RGDSW): coarse dofs only on the coarse nodes -- entities with
+        an odd coordinate in every direction that has >= 2 cells --, numbered compactly ((e_d - 1) / 2 per such
+        direction); an interface node of entity e carries 1 / |C(e)| for every coarse node of C(e) (odd e_d kept, even
+        e_d of a direction with >= 2 cells moved to e_d - 1 or e_d + 1 inside the lattice)."""
+        import itertools
         import scipy.sparse.linalg as spla
         n_nodes, dim = xyz.shape
         lo = xyz.min(axis=0) if lo is None else np.asarray(lo, dtype=float)
@@ -1060,7 +1065,35 @@ class CoarseGDSW:
         col = np.repeat(ent, dofs) * dofs + comp
         sel = gamma_dof & free
         self.n0 = n_ent * dofs
-        PhiG = sp.csr_matrix((np.ones(sel.sum()), (np.nonzero(sel)[0], col[sel])), shape=(n, self.n0))
+        if not reduced:
+            PhiG = sp.csr_matrix((np.ones(sel.sum()), (np.nonzero(sel)[0], col[sel])), shape=(n, self.n0))
+        else:
+            multi = g >= 2
+            cstride = np.ones(dim, dtype=np.int64)
+            ncoarse = 1
+            for d in range(dim):
+                cstride[d] = ncoarse
+                ncoarse *= (g[d] - 1) if multi[d] else 1
+            self.n0 = ncoarse * dofs
+            rows, cols, vals = [], [], []
+            for node in np.nonzero(on_gamma)[0]:
+                opts = []
+                for d in range(dim):
+                    if not multi[d]:
+                        opts.append([0])
+                    elif e[node, d] % 2 == 1:
+                        opts.append([e[node, d]])
+                    else:
+                        opts.append([v for v in (e[node, d] - 1, e[node, d] + 1) if 1 <= v <= 2 * g[d] - 3])
+                adj = list(itertools.product(*opts))
+                for v in adj:
+                    cid = sum(cstride[d] * ((v[d] - 1) // 2) for d in range(dim) if multi[d])
+                    for a in range(dofs):
+                        if free[node * dofs + a]:
+                            rows.append(node * dofs + a)
+                            cols.append(cid * dofs + a)
+                            vals.append(1.0 / len(adj))
+            PhiG = sp.csr_matrix((vals, (rows, cols)), shape=(n, self.n0))
         A = A.tocsr()
         I = np.nonzero(~gamma_dof & free)[0]
         Phi = PhiG.tolil()

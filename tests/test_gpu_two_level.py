@@ -128,10 +128,14 @@ def test_two_level_misuse(fedd_lib, ctx):
     assert tuple(g) == (1, 1, 1) and Kinv.shape == (8, 8)    # default: 343 nodes / 500 -> one cell
 
 
-@pytest.mark.parametrize("dim,M,cells", [(3, 12, 8), (3, 12, 27), (2, 24, 16), (3, 9, 1)])
-def test_gdsw_coarse_matrix_and_apply(fedd_lib, dim, M, cells):
-    """FEDD_COARSE_GDSW against the oracle's CoarseGDSW (exact sparse interior solves): interface classification,
-    harmonic extensions (device GMRES on the constrained operator, solved to 1e-13 here), K0^-1 and the operator."""
+@pytest.mark.parametrize("dim,M,cells,kind", [(3, 12, 8, "gdsw"), (3, 12, 27, "gdsw"), (2, 24, 16, "gdsw"), (3, 9, 1, "gdsw"),
+                                              (3, 12, 8, "rgdsw"), (3, 12, 27, "rgdsw"), (3, 16, 64, "rgdsw"),
+                                              (2, 24, 16, "rgdsw"), (3, 9, 1, "rgdsw"), (3, 12, 2, "rgdsw")])
+def test_gdsw_coarse_matrix_and_apply(fedd_lib, dim, M, cells, kind):
+    """FEDD_COARSE_GDSW / FEDD_COARSE_RGDSW against the oracle's CoarseGDSW (exact sparse interior solves): interface
+    classification, coarse nodes and weights of the reduced space, harmonic extensions (device GMRES on the constrained
+    operator, solved to 1e-13 here), K0^-1 and the operator.  (cells = 2: a slab decomposition, whose coarse nodes are
+    faces.)"""
     c = fedd_lib.Context(device=0)
     try:
         m, om, A_bc, rhs_bc, is_dir = laplace_setup(fedd_lib, c, dim, M)
@@ -139,11 +143,14 @@ def test_gdsw_coarse_matrix_and_apply(fedd_lib, dim, M, cells):
         c.schwarz_set_target(tgt, 1.0)
         c.schwarz_set_coarse(cells)
         c.set_option("gdsw_tol", 1e-13)
-        c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_GDSW)
+        reduced = kind == "rgdsw"
+        c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1,
+                        coarse_kind=fedd_lib.COARSE_RGDSW if reduced else fedd_lib.COARSE_GDSW)
         g, Kinv = c.schwarz_coarse()
-        co = fo.CoarseGDSW(A_bc, m["conn"], m["xyz"], is_dir, 1, cells_target=cells)
+        co = fo.CoarseGDSW(A_bc, m["conn"], m["xyz"], is_dir, 1, cells_target=cells, reduced=reduced)
         np.testing.assert_array_equal(g[:dim], co.g)
-        assert Kinv.shape == (co.n0, co.n0) and co.n0 == int(np.prod(2 * co.g - 1))
+        assert Kinv.shape == (co.n0, co.n0)
+        assert co.n0 == (int(np.prod(np.where(co.g >= 2, co.g - 1, 1))) if reduced else int(np.prod(2 * co.g - 1)))
         np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-9 * np.abs(co.K0inv).max())
         node_bin, nb, _ = fo.schwarz_bins(m["xyz"], tgt)
         ras = fo.RAS(A_bc, node_bin, nb)
