@@ -14,7 +14,7 @@ for per_dir, hh in ((2, 8), (4, 8), (6, 8), (8, 8), (4, 16), (6, 16)):
     c.schwarz_set_target(27, 1.0)
     c.schwarz_set_coarse(per_dir ** 3)
     out = {}
-    for name, kw in (("one", dict()), ("q1", dict(two_level=1, coarse_kind=capi.COARSE_Q1)), ("gdsw", dict(two_level=1, coarse_kind=capi.COARSE_GDSW))):
+    for name, kw in (("one", dict()), ("q1", dict(two_level=1, coarse_kind=capi.COARSE_Q1)), ("gdsw", dict(two_level=1, coarse_kind=capi.COARSE_GDSW)), ("rgdsw", dict(two_level=1, coarse_kind=capi.COARSE_RGDSW))):
         t0 = time.time()
         c.schwarz_setup(1, capi.COMBINE_RESTRICTED, **kw)
         c.sync()
