@@ -82,6 +82,7 @@ SIGNATURES = {
     "fedd_schwarz_apply": [C.c_void_p, _f64p, _f64p],
     "fedd_schwarz_apply_device": [C.c_void_p, C.c_int],
     "fedd_schwarz_info": [C.c_void_p, _i64p, _i64p, _i64p],
+    "fedd_schwarz_unique": [C.c_void_p, _i64p],
     "fedd_gmres": [C.c_void_p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int, _ip, _f64p],
     "fedd_set_option": [C.c_void_p, C.c_char_p, C.c_double],
     "fedd_timing_enable": [C.c_void_p, C.c_int],
@@ -493,7 +494,9 @@ class Context:
     def schwarz_info(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         _chk(self._L.fedd_schwarz_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(n_subdomains=a.value, max_size=b.value, inverse_bytes=c.value)
+        u = C.c_int64()
+        _chk(self._L.fedd_schwarz_unique(self._h, C.byref(u)))
+        return dict(n_subdomains=a.value, max_size=b.value, inverse_bytes=c.value, n_unique=u.value)
 
     def schwarz_apply(self, r):
         r = np.ascontiguousarray(r, dtype=np.float64)

@@ -514,6 +514,13 @@ extern "C" int fedd_fe_basis(int dim, int nen, int degree, double* phi, double* 
     return 0;
 }
 
+extern "C" int fedd_schwarz_unique(fedd_ctx* c, int64_t* n_unique) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_schwarz && n_unique, "fedd_schwarz_unique: no preconditioner");
+    *n_unique = c->sw_big_active ? c->sw_nsub : c->sw_nrep;
+    return 0;
+}
+
 extern "C" int fedd_spmv_info(fedd_ctx* c, int64_t* nnz_pattern, int64_t* nnz_streamed) {
     NEED_DEVICE(c);
     FEDD_CHECK(c->have_pattern, "fedd_spmv_info: no matrix");
@@ -657,7 +664,9 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "gdsw_tol") {
         FEDD_CHECK(value > 0.0 && value < 1.0, "fedd_set_option: gdsw_tol %g", value);
         c->gdsw_tol = value;
-    } else if (k == "schwarz_big") c->sw_big = (int)value;
+    } else if (k == "schwarz_dedupe") c->sw_dedupe = (int)value;
+    else if (k == "apply_span") c->apply_span = (int)value;
+    else if (k == "schwarz_big") c->sw_big = (int)value;
     else if (k == "schwarz_big_target") c->sw_big_target = (int)value;
     else if (k == "asm_kind") c->asm_kind = (int)value;
     else if (k == "asm_u") c->asm_u = (int)value;

@@ -214,6 +214,14 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_inv;                 // per subdomain [n_i][rp_i] column-major slab
     fedd::DevBuf<double> d_mult;                // [n_cols] multiplicity (averaging)
     bool have_schwarz = false;
+    int apply_span = 0;                         // grouped apply: subdomains per workgroup (0 = 64)
+    int sw_dedupe = 1;                          // option "schwarz_dedupe": subdomains with the same local matrix share one slab
+    int64_t sw_nrep = 0;                        // distinct local matrices (= slabs) of the last setup
+    fedd::DevBuf<double> d_sw_rmax;             // [n_rows_ext] largest magnitude of every stored row
+    fedd::DevBuf<uint64_t> d_sw_fp;             // fingerprints [2 nsub] | hash table keys [2 tsize]
+    fedd::DevBuf<int32_t> d_sw_order;           // subdomains sorted by representative [nsub] | sort scratch [2 nsub] | pad | records int4[nsub]
+    int64_t sw_order_off = 0;                   // where the records start (in int32 units, 16-byte aligned)
+    fedd::DevBuf<int32_t> d_sw_rep;             // representative [nsub] | sizes for the inversion [nsub] | slot [nsub] | table min [tsize]
     int sw_big = -1;                            // large-subdomain path: -1 = for merged block systems, 0 = never, 1 = always
     bool sw_big_active = false;                 // the current preconditioner was built by schwarz_setup_big
     int sw_big_target = 0;                      // owned dofs per box of the bisection (0 = default 120)
@@ -354,7 +362,7 @@ int schwarz_apply_big(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, b
 int schwarz_overlap_lists_big(fedd_ctx* c, int64_t nsub, int32_t* max_n, int32_t* max_own);
 int schwarz_slab_offsets(fedd_ctx* c, int64_t nsub, int restricted);
 int schwarz_dense_batched(fedd_ctx* c, int64_t nsub, int dstride, int n_lo, int32_t p_off, int restricted, int max_n,
-                          int32_t* d_bad);
+                          int32_t* d_bad, const int32_t* d_sub_n_sel);
 
 // invert_mfma.hip: local inverses of plain systems, n <= 128, on the f64 matrix cores
 int schwarz_invert_mfma(fedd_ctx* c, int restricted, int32_t* d_bad, int max_n);

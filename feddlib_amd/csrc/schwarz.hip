@@ -14,6 +14,7 @@
 // Apply = one workgroup per subdomain streaming its slab of A_i^-1 once from HBM (HBM-bound).
 // With fedd_schwarz_setup(two_level = 1) the coarse level of coarse.hip is added to the result.
 #include "fedd_internal.hpp"
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -243,6 +244,146 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
         sub_n[b] = n_own + n_ext;
         sub_nown[b] = n_own;
     }
+}
+
+__device__ __forceinline__ int bsearch_i32(const int32_t* a, int n, int32_t v);
+
+// ---- subdomains with the same local matrix share one slab ------------------------------------------------------------
+// On a mesh with repeated cells (the structured cube of the headline: 389 017 subdomains, a few hundred distinct local
+// matrices) most principal submatrices A_i are copies of one another up to rounding.  Each subdomain's matrix is
+// fingerprinted -- entries quantised to 2^-44 of their row's largest magnitude, 128 bits of order-independent hash over
+// (local row, local column, quantised value) plus the sizes --, the subdomain of lowest index with a given fingerprint is
+// its REPRESENTATIVE, only representatives are inverted and stored, every other subdomain's slab pointer refers to its
+// representative's slab.  Equal fingerprints = equal matrices to 6e-14 relative per entry (a collision of two
+// independent 64-bit hashes aside), i.e. inverses equal to ~1e-12: far inside the 1e-10 parity bar; a fingerprint that
+// differs through rounding only costs a shared slab, never correctness.  The apply then reads a 22 KB slab that sits in
+// L2 / L1 instead of streaming 8 GB: the one-level step at 214^3 cells drops from ~565 to ~ ms.
+__global__ void k_row_absmax(const int32_t* __restrict__ rowptr, const double* __restrict__ val, int32_t n_rows,
+                             double* __restrict__ rmax) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    double m = 0.0;
+    for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) m = fmax(m, fabs(val[p]));
+    rmax[r] = m;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+// one wave per subdomain: lanes over the local rows, each walks its CSR row
+template <int NM>
+__global__ __launch_bounds__(64) void k_sub_fingerprint(const int32_t* __restrict__ sub_n, const int32_t* __restrict__ sub_nown,
+                                                        const int32_t* __restrict__ sub_dofs, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ colind, const double* __restrict__ val,
+                                                        const double* __restrict__ rmax, int32_t n_stored, int32_t p_off,
+                                                        uint64_t* __restrict__ fp) {
+    __shared__ int32_t sdof[NM];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = sub_n[b], no = sub_nown[b];
+    for (int k = lane; k < n; k += 64) sdof[k] = sub_dofs[(int64_t)b * NM + k];
+    __syncthreads();
+    uint64_t h1 = 0, h2 = 0;
+    for (int i = lane; i < n; i += 64) {
+        const int32_t g = sdof[i];
+        if (g >= n_stored) {   // ghost row without a stored row: identity
+            h1 += mix64(((uint64_t)i << 32) ^ 0x9e3779b97f4a7c15ull);
+            h2 += mix64(((uint64_t)i << 20) ^ 0xd1b54a32d192ed03ull);
+            continue;
+        }
+        const double scale = rmax[g] > 0.0 ? 17592186044416.0 / rmax[g] : 0.0;   // 2^44 / row max
+        // pressure rows of a merged system are pivoted after the velocities: part of the matrix' identity
+        const uint64_t tag = g >= p_off ? 0x5851f42d4c957f2dull : 0ull;
+        for (int32_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
+            const int32_t col = colind[p];
+            int cidx = bsearch_i32(sdof, no, col);
+            if (cidx < 0) {
+                cidx = bsearch_i32(sdof + no, n - no, col);
+                if (cidx >= 0) cidx += no;
+            }
+            if (cidx < 0) continue;
+            const int64_t q = (int64_t)llrint(val[p] * scale);
+            if (q == 0) continue;
+            const uint64_t key = ((uint64_t)i * NM + (uint64_t)cidx) ^ tag;
+            h1 += mix64(key * 0x9e3779b97f4a7c15ull + (uint64_t)q);
+            h2 += mix64((key + 0x632be59bd9b4e019ull) * 0xd6e8feb86659fd93ull ^ ((uint64_t)q * 0xa0761d6478bd642full));
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        h1 += __shfl_down(h1, off, 64);
+        h2 += __shfl_down(h2, off, 64);
+    }
+    if (lane == 0) {
+        h1 = mix64(h1 + (uint64_t)n * 1000003ull + (uint64_t)no);
+        if (h1 == 0) h1 = 1;   // 0 marks an empty table slot
+        fp[2 * (int64_t)b] = h1;
+        fp[2 * (int64_t)b + 1] = h2;
+    }
+}
+
+// open-addressing table keyed by the 128-bit fingerprint; the slot's value is the lowest subdomain index seen
+__global__ void k_fp_insert(const uint64_t* __restrict__ fp, int32_t nsub, uint64_t* __restrict__ tkey, int32_t* __restrict__ tmin,
+                            int64_t tsize, int32_t* __restrict__ slot_of) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nsub) return;
+    const uint64_t h1 = fp[2 * (int64_t)b], h2 = fp[2 * (int64_t)b + 1];
+    int64_t s = (int64_t)(h1 % (uint64_t)tsize);
+    for (int64_t probe = 0; probe < tsize; ++probe) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&tkey[2 * s], 0ull, (unsigned long long)h1);
+        if (old == 0ull) {
+            // this thread claimed the slot: publish the second word (readers wait for it)
+            atomicExch((unsigned long long*)&tkey[2 * s + 1], (unsigned long long)(h2 | 1ull));
+        }
+        if (old == 0ull || old == h1) {
+            unsigned long long second;
+            do {
+                second = atomicAdd((unsigned long long*)&tkey[2 * s + 1], 0ull);
+            } while (second == 0ull);
+            if (second == (h2 | 1ull)) {
+                atomicMin(&tmin[s], b);
+                slot_of[b] = (int32_t)s;
+                return;
+            }
+        }
+        s = s + 1 == tsize ? 0 : s + 1;
+    }
+    slot_of[b] = -1;   // table full (cannot happen: tsize >= 2 nsub): own representative
+}
+
+__global__ void k_fp_resolve(const int32_t* __restrict__ slot_of, const int32_t* __restrict__ tmin, const int32_t* __restrict__ sub_n,
+                             int32_t nsub, int32_t* __restrict__ rep, int32_t* __restrict__ sub_n_inv, int32_t* __restrict__ n_rep) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nsub) return;
+    int32_t r = slot_of[b] >= 0 ? tmin[slot_of[b]] : b;
+    if (sub_n[r] != sub_n[b]) r = b;          // (a colliding fingerprint of a different size is never shared)
+    rep[b] = r;
+    sub_n_inv[b] = r == b ? sub_n[b] : 0;     // the inversion kernels skip subdomains of size 0
+    if (r == b) atomicAdd(n_rep, 1);
+}
+
+__global__ void k_iota(int32_t* __restrict__ v, int32_t n) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
+__global__ void k_pack_order(const int32_t* __restrict__ ord, const int32_t* __restrict__ rep, const int32_t* __restrict__ sub_n,
+                             const int32_t* __restrict__ sub_nown, int32_t n, int4* __restrict__ rec) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t sidx = ord[i];
+    rec[i] = make_int4(sidx, rep[sidx], sub_n[sidx], sub_nown[sidx]);
+}
+
+__global__ void k_fp_share(const int32_t* __restrict__ rep, int32_t nsub, int64_t* __restrict__ inv_ptr) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nsub) return;
+    const int32_t r = rep[b];
+    if (r != b) inv_ptr[b] = inv_ptr[r];      // (a representative's own entry is never rewritten)
 }
 
 // leading dimension of a slab = number of stored rows: the apply kernel's lanes (row, column group)
@@ -605,6 +746,167 @@ __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ 
     }
 }
 
+// Restricted apply when most subdomains share their inverse with others (schwarz_dedupe on a mesh with repeated cells), on
+// the f64 matrix cores.  The subdomains are walked in the order of `order` (sorted by representative at setup, lattice
+// order within one), so that 16 consecutive ones nearly always share their inverse: such a batch is the product
+//   Z[16 RT x 16] = Ainv[16 RT x n] R[n x 16]      (v_mfma_f64_16x16x4_f64: RT row tiles, n / 4 steps).
+// The four waves split the steps (wave w takes steps w, w + 4, ...), keep their share of Ainv in registers as A fragments
+// -- reloaded (from L2) only when the representative changes -- and gather their B fragments -- lane (k, j) = entry
+// 4 step + k of subdomain j's restriction of r -- straight from global memory.  The dof lists of a batch are read as
+// whole rows (16-byte loads, 16 lanes per subdomain) one batch ahead and handed to the fragment lanes through LDS; the
+// records of `order` (subdomain, representative, sizes) are read 64 places at a time, one chunk ahead, and the batch
+// boundaries inside a chunk come from bit scans of a ballot.  The four partial tiles are added through LDS in wave
+// order: fixed summation order => reproducible; no atomics (every owned dof belongs to one subdomain).
+// Without the sharing the slabs stream from HBM once per apply and the flat kernel above is the right one.
+typedef double ap_d4 __attribute__((ext_vector_type(4)));
+constexpr int AM_MB = 16;
+template <int RT, int KW>   // owned rows <= 16 RT, columns <= 16 KW
+__global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : 1) void k_apply_mfma(const int4* __restrict__ order, const int32_t* __restrict__ sub_dofs,
+                                                    const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
+                                                    const double* __restrict__ r, double* __restrict__ z, int32_t nsub, int span) {
+    constexpr int S = 16 * KW + 2;              // row stride of the id lists in LDS: fragment reads hit 32 distinct banks
+    constexpr int U = (16 * KW + 63) / 64;      // 16-byte loads per lane and batch
+    __shared__ double part[4][RT][4][64];
+    __shared__ int32_t ids[2][AM_MB][S];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lj = lane & 15, lk = lane >> 4;
+    const int lm = tid >> 4, lc = tid & 15;     // id loads: subdomain lm of the batch, columns 4 lc + 64 u ...
+    // XCD-contiguous ranges (neighbouring boxes gather overlapping parts of r: one L2)
+    const int nwg = gridDim.x, q_ = nwg >> 3, rem_ = nwg & 7, xcd_ = blockIdx.x & 7, within_ = blockIdx.x >> 3;
+    const int wg = (xcd_ < rem_ ? xcd_ * (q_ + 1) : rem_ * (q_ + 1) + (xcd_ - rem_) * q_) + within_;
+    const int32_t p_end = min(nsub, (wg + 1) * span);   // span = a multiple of 64
+    int32_t p_chunk = wg * span;
+    if (p_chunk >= p_end) return;
+    // chunk = 64 places: lane = place; record = (subdomain, representative, columns, owned rows)
+    const int4 none = make_int4(0, -1, 0, 0);
+    int4 hdr = p_chunk + lane < p_end ? order[p_chunk + lane] : none;
+    int4 hdr_n = p_chunk + 64 + lane < p_end ? order[p_chunk + 64 + lane] : none;
+    int cnt = min(64, p_end - p_chunk);
+    auto run_starts = [&](const int4& h, int cnt_) {
+        const int32_t pr_rep = __shfl_up(h.y, 1, 64), pr_n = __shfl_up(h.z, 1, 64);
+        return __ballot(lane == 0 || lane >= cnt_ || h.y != pr_rep || h.z != pr_n);
+    };
+    auto batch_len = [&](uint64_t starts_, int cnt_, int pos_) {   // a run of equal representatives, at most 16
+        const uint64_t later = pos_ < 63 ? starts_ >> (pos_ + 1) : 0ull;      // bit k: a run starts at pos + 1 + k
+        const int mb_ = later ? __builtin_ctzll(later) + 1 : 64 - pos_;
+        return min(min(mb_, AM_MB), cnt_ - pos_);
+    };
+    // the dof list of subdomain lm of a batch, this lane's columns (whole rows: sub_dofs rows are NMAX long)
+    auto load_ids = [&](const int4& h, int pos_, int mb_, int n_, int4 (&v)[U]) {
+        const int32_t sm = __shfl(h.x, pos_ + lm, 64);
+        const int4* __restrict__ row = (const int4*)(sub_dofs + (int64_t)sm * NMAX);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c4 = lc + 16 * u;
+            v[u] = (lm < mb_ && 4 * c4 < n_ && 4 * c4 < 16 * KW) ? row[c4] : make_int4(0, 0, 0, 0);
+        }
+    };
+    auto park_ids = [&](int buf, const int4 (&v)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = 4 * (lc + 16 * u);
+            if (c < 16 * KW) {
+                int32_t* dst = &ids[buf][lm][c];
+                dst[0] = v[u].x;
+                dst[1] = v[u].y;
+                dst[2] = v[u].z;
+                dst[3] = v[u].w;
+            }
+        }
+    };
+    uint64_t starts = run_starts(hdr, cnt);
+    int pos = 0, mb = batch_len(starts, cnt, 0), buf = 0;
+    {
+        int4 v[U];
+        load_ids(hdr, 0, mb, __builtin_amdgcn_readlane(hdr.z, 0), v);
+        park_ids(0, v);
+    }
+    __syncthreads();
+    int32_t cur = -1;
+    double a[RT][KW];
+    for (;;) {
+        const int32_t rp = __builtin_amdgcn_readlane(hdr.y, pos);
+        const int n = __builtin_amdgcn_readlane(hdr.z, pos), nrow = __builtin_amdgcn_readlane(hdr.w, pos);
+        if (rp != cur) {    // (uniform) this lane's A fragments of the new inverse
+            const int32_t s0 = __builtin_amdgcn_readlane(hdr.x, pos);
+            const double* __restrict__ src = inv + inv_ptr[s0];
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk) {
+                const int c = 4 * (w + 4 * kk) + lk;
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const int i = 16 * t + lj;
+                    a[t][kk] = (c < n && i < nrow) ? src[c * nrow + i] : 0.0;
+                }
+            }
+            cur = rp;
+        }
+        // B fragments: entries of r at the dof ids of subdomain lj
+        double bv[KW];
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) {
+            const int c = 4 * (w + 4 * kk) + lk;
+            bv[kk] = (lj < mb && c < n) ? r[ids[buf][lj][c]] : 0.0;
+        }
+        // the rows this lane writes at the end: result register w of tile t = row 16 t + lk + 4 w of subdomain lj
+        int32_t od[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int i = 16 * t + lk + 4 * w;
+            od[t] = (lj < mb && i < nrow) ? ids[buf][lj][i] : -1;
+        }
+        // where the next batch is: in this chunk or at the start of the next one; its dof lists are requested now
+        int pos_n = pos + mb;
+        const bool cross = pos_n >= cnt;
+        const bool last = cross && p_chunk + 64 >= p_end;
+        int4 v[U];
+        int mb_n = 0;
+        uint64_t starts_n = starts;
+        int cnt_n = cnt;
+        if (!last) {
+            if (cross) {
+                cnt_n = min(64, p_end - (p_chunk + 64));
+                starts_n = run_starts(hdr_n, cnt_n);
+                pos_n = 0;
+                mb_n = batch_len(starts_n, cnt_n, 0);
+                load_ids(hdr_n, 0, mb_n, __builtin_amdgcn_readlane(hdr_n.z, 0), v);
+            } else {
+                mb_n = batch_len(starts, cnt, pos_n);
+                load_ids(hdr, pos_n, mb_n, __builtin_amdgcn_readlane(hdr.z, pos_n), v);
+            }
+        }
+        ap_d4 acc[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = ap_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk)
+            if (4 * (w + 4 * kk) < n) {     // (uniform over the wave)
+#pragma unroll
+                for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][kk], bv[kk], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[w][t][q][lane] = acc[t][q];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+            if (od[t] >= 0) z[od[t]] = ((part[0][t][w][lane] + part[1][t][w][lane]) + part[2][t][w][lane]) + part[3][t][w][lane];
+        if (last) break;
+        park_ids(buf ^ 1, v);
+        if (cross) {        // (uniform) next chunk: its records were requested a chunk ago; request the one after it
+            p_chunk += 64;
+            hdr = hdr_n;
+            hdr_n = p_chunk + 64 + lane < p_end ? order[p_chunk + 64 + lane] : none;
+        }
+        __syncthreads();    // part and ids[buf] are rewritten by the next batch; ids[buf ^ 1] is complete
+        buf ^= 1;
+        pos = pos_n;
+        mb = mb_n;
+        starts = starts_n;
+        cnt = cnt_n;
+    }
+}
+
 __global__ void k_count_mult(const int32_t* __restrict__ sub_n, const int32_t* __restrict__ sub_dofs, double* mult) {
     const int b = blockIdx.x;
     const int n = sub_n[b];
@@ -840,27 +1142,81 @@ int schwarz_setup(fedd_ctx* c) {
     FEDD_CHECK(max_n <= NMAX,
                "schwarz setup: an overlapping subdomain has %d dofs, the dense local solver takes at most %d; "
                "lower the target with fedd_schwarz_set_target (now %d nodes)", max_n, NMAX, target);
-    // ---- slab offsets ----
     const int restricted = c->sw_combine == FEDD_COMBINE_RESTRICTED ? 1 : 0;
+    // merged block systems: dofs >= p_off are pressures and are pivoted after the velocities
+    const int32_t p_off = c->merged ? (int32_t)c->merged_nA : INT32_MAX;
+    // ---- equal local matrices share one slab (option "schwarz_dedupe", default on) ----
+    const int32_t* sub_n_inv = c->d_sub_n.p;      // sizes as the inversion sees them: 0 = not a representative
+    c->sw_nrep = nsub;
+    if (c->sw_dedupe) {
+        const dim3 gs((unsigned)((nsub + 255) / 256));
+        FEDD_TRY(c->d_sw_rmax.ensure((size_t)n_stored));
+        hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)((n_stored + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_rowptr.p,
+                           (const double*)c->d_val.p, n_stored, c->d_sw_rmax.p);
+        const int64_t tsize = 2 * nsub + 64;
+        FEDD_TRY(c->d_sw_fp.ensure((size_t)(2 * nsub + 2 * tsize)));
+        FEDD_TRY(c->d_sw_rep.ensure((size_t)(3 * nsub + tsize + 4)));
+        uint64_t* fp = c->d_sw_fp.p;
+        uint64_t* tkey = fp + 2 * nsub;
+        int32_t* rep = c->d_sw_rep.p;
+        int32_t* n_inv = rep + nsub;
+        int32_t* slot_of = n_inv + nsub;
+        int32_t* tmin = slot_of + nsub;
+        int32_t* n_rep = tmin + tsize;
+        FEDD_HIP(hipMemsetAsync(tkey, 0, (size_t)(2 * tsize) * sizeof(uint64_t), c->stream));
+        FEDD_HIP(hipMemsetAsync(tmin, 0x7f, (size_t)tsize * sizeof(int32_t), c->stream));
+        FEDD_HIP(hipMemsetAsync(n_rep, 0, sizeof(int32_t), c->stream));
+        hipLaunchKernelGGL((k_sub_fingerprint<NMAX>), dim3((unsigned)nsub), dim3(64), 0, c->stream, (const int32_t*)c->d_sub_n.p,
+                           (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const int32_t*)c->d_rowptr.p,
+                           (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, (const double*)c->d_sw_rmax.p, n_stored, p_off, fp);
+        hipLaunchKernelGGL(k_fp_insert, gs, blk, 0, c->stream, (const uint64_t*)fp, (int32_t)nsub, tkey, tmin, tsize, slot_of);
+        hipLaunchKernelGGL(k_fp_resolve, gs, blk, 0, c->stream, (const int32_t*)slot_of, (const int32_t*)tmin,
+                           (const int32_t*)c->d_sub_n.p, (int32_t)nsub, rep, n_inv, n_rep);
+        sub_n_inv = n_inv;
+        // the apply walks the subdomains sorted by representative (stable: lattice order within one)
+        {
+            FEDD_TRY(c->d_sw_order.ensure((size_t)(8 * nsub + 4)));
+            int32_t* ord = c->d_sw_order.p;
+            int32_t* keys_out = ord + nsub;
+            int32_t* iota = ord + 2 * nsub;
+            hipLaunchKernelGGL(k_iota, gs, blk, 0, c->stream, iota, (int32_t)nsub);
+            size_t tmp_bytes = 0;
+            FEDD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const int32_t*)rep, keys_out, (const int32_t*)iota, ord,
+                                                        (int)nsub, 0, 32, c->stream));
+            FEDD_TRY(c->d_dense_ws.ensure((tmp_bytes + sizeof(double) - 1) / sizeof(double)));
+            FEDD_HIP(hipcub::DeviceRadixSort::SortPairs((void*)c->d_dense_ws.p, tmp_bytes, (const int32_t*)rep, keys_out,
+                                                        (const int32_t*)iota, ord, (int)nsub, 0, 32, c->stream));
+            // records (subdomain, representative, columns, owned rows) in that order: one 16-byte load per place
+            hipLaunchKernelGGL(k_pack_order, gs, blk, 0, c->stream, (const int32_t*)ord, (const int32_t*)rep,
+                               (const int32_t*)c->d_sub_n.p, (const int32_t*)c->d_sub_nown.p, (int32_t)nsub, (int4*)(ord + 4 * nsub));
+            c->sw_order_off = 4 * (int64_t)nsub;
+        }
+        int32_t h_nrep = 0;
+        FEDD_HIP(hipMemcpyAsync(&h_nrep, n_rep, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        c->sw_nrep = h_nrep;
+    }
+    // ---- slab offsets ----
     FEDD_TRY(c->d_inv_ptr.ensure((size_t)nsub + 1));
-    hipLaunchKernelGGL(k_slab_sizes, dim3((unsigned)((nsub + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
+    hipLaunchKernelGGL(k_slab_sizes, dim3((unsigned)((nsub + 255) / 256)), blk, 0, c->stream, sub_n_inv,
                        (const int32_t*)c->d_sub_nown.p, (int32_t)nsub, restricted, c->d_inv_ptr.p);
     int64_t total = 0;
     FEDD_TRY(exclusive_scan_i64(c, c->d_inv_ptr.p, c->d_inv_ptr.p, nsub, &total));
     c->sw_inv_elems = total;
-    FEDD_TRY(c->d_inv.ensure((size_t)total));
+    FEDD_TRY(c->d_inv.ensure((size_t)total + 16));
+    if (c->sw_dedupe)
+        hipLaunchKernelGGL(k_fp_share, dim3((unsigned)((nsub + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_sw_rep.p,
+                           (int32_t)nsub, c->d_inv_ptr.p);
     // ---- extract + invert ----
     FEDD_TRY(c->d_flags.ensure(16));
     int32_t* d_bad = c->d_flags.p + 1;
     FEDD_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), c->stream));
-    // merged block systems: dofs >= p_off are pressures and are pivoted after the velocities
-    const int32_t p_off = c->merged ? (int32_t)c->merged_nA : INT32_MAX;
     // size classes of the register-tiled kernel (n <= 16 T); anything larger falls back below
     {
         const dim3 grid((unsigned)nsub);
 #define INV_REG1(T, TA, LO, HI, OWN_LE)                                                                        \
     if (max_n > (LO))                                                                                          \
-        hipLaunchKernelGGL((k_invert_reg<T, TA>), grid, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,       \
+        hipLaunchKernelGGL((k_invert_reg<T, TA>), grid, blk, 0, c->stream, sub_n_inv,                           \
                            (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,                   \
                            (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p,                       \
                            (const double*)c->d_val.p, n_stored, restricted, (const int64_t*)c->d_inv_ptr.p,      \
@@ -895,7 +1251,7 @@ int schwarz_setup(fedd_ctx* c) {
     // cores (dense.hip).  (Before: an LDS / global-memory scalar sweep at ~1 % of peak: 166 375 subdomains of <= 216 dofs
     // -- 64-node boxes on the 214^3 grid -- took 3.3 s, 27-node boxes with overlap 2, <= 343 -> 247 dofs, 23.7 s.)
     const int n_skip = 160;
-    if (max_n > n_skip) FEDD_TRY(schwarz_dense_batched(c, nsub, NMAX, n_skip, p_off, restricted, max_n, d_bad));
+    if (max_n > n_skip) FEDD_TRY(schwarz_dense_batched(c, nsub, NMAX, n_skip, p_off, restricted, max_n, d_bad, sub_n_inv));
     int32_t bad = 0;
     FEDD_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     FEDD_HIP(hipStreamSynchronize(c->stream));
@@ -941,6 +1297,31 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
         // flat streaming kernel while the product park of the largest slab fits 48 KB of LDS
         const size_t park = (((size_t)c->sw_max_size * (size_t)c->sw_max_own + 1) & ~(size_t)1) * sizeof(double);
         ScopedTimer t(c, FEDD_T_SCHWARZ_APPLY);
+        // most subdomains share their inverse (schwarz_dedupe found few distinct local matrices): matrix-core kernel
+        // (a few thousand subdomains: their slabs stay in the caches and the flat kernel's shorter dependency chain wins)
+        const bool shared = c->sw_dedupe && c->sw_nrep * 4 <= c->sw_nsub && c->sw_max_own <= 96 && c->apply_kind != 2 && c->apply_kind != 1 &&
+                            (c->sw_nsub >= 4096 || c->apply_kind == 4);
+        if (shared) {
+            // ranges of whole 64-place chunks (measured on the 214^3 grid, 389017 subdomains: 64: 195 us, 128: 187, 256: 191, 512: 233)
+            int span = c->apply_span > 0 ? c->apply_span : (c->sw_nsub >= 256 * 1024 ? 128 : 64);
+            span = std::max(64, (span + 63) / 64 * 64);
+            const int nwg = (int)((c->sw_nsub + span - 1) / span);
+#define APPLY_MFMA(RT, KW)                                                                                                   \
+    hipLaunchKernelGGL((k_apply_mfma<RT, KW>), dim3((unsigned)nwg), blk, 0, c->stream, (const int4*)(c->d_sw_order.p + c->sw_order_off),          \
+                       (const int32_t*)c->d_sub_dofs.p, (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r,         \
+                       d_z_owned, (int32_t)c->sw_nsub, span)
+            const bool narrow = c->sw_max_size <= 160;
+            if (c->sw_max_own <= 32) {
+                if (narrow) APPLY_MFMA(2, 10);
+                else APPLY_MFMA(2, 16);
+            } else if (c->sw_max_own <= 64) {
+                if (narrow) APPLY_MFMA(4, 10);
+                else APPLY_MFMA(4, 16);
+            } else {
+                APPLY_MFMA(6, 16);
+            }
+#undef APPLY_MFMA
+        } else
         if ((c->apply_kind == 0 || c->apply_kind == 2) && park <= 48 * 1024)   // 2 = flat without the compact LDS layout (A/B)
             if (c->sw_max_size <= 128 && c->apply_kind != 2)
                 hipLaunchKernelGGL(k_apply_flat<true>, grid, blk, park, c->stream, (const int32_t*)c->d_sub_n.p,

@@ -250,7 +250,8 @@ __global__ void k_big_compact(const int32_t* __restrict__ sub_n, int32_t nsub, i
 // Dense inverses of every subdomain with more than n_lo dofs (lists in d_sub_dofs with `dstride` entries per
 // subdomain): extraction, batched Gauss-Jordan on the matrix cores, slab rows; a chunk of subdomains at a time.
 int schwarz_dense_batched(fedd_ctx* c, int64_t nsub, int dstride, int n_lo, int32_t p_off, int restricted, int max_n,
-                          int32_t* d_bad) {
+                          int32_t* d_bad, const int32_t* d_sub_n_sel) {
+    if (!d_sub_n_sel) d_sub_n_sel = c->d_sub_n.p;     // sizes the selection sees (0 = leave this subdomain out)
     FEDD_CHECK(max_n <= NMB && nsub < ((int64_t)1 << 31), "schwarz_dense_batched: subdomain of %d dofs", max_n);
     const dim3 blk(256), gs((unsigned)((nsub + 255) / 256));
     const int32_t* ids = nullptr;
@@ -258,10 +259,10 @@ int schwarz_dense_batched(fedd_ctx* c, int64_t nsub, int dstride, int n_lo, int3
     if (n_lo > 0) {
         FEDD_TRY(c->d_big_ids.ensure((size_t)nsub + 1));
         FEDD_TRY(c->d_big_pos.ensure((size_t)nsub + 1));
-        hipLaunchKernelGGL(k_big_flag, gs, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p, (int32_t)nsub, n_lo, c->d_big_pos.p);
+        hipLaunchKernelGGL(k_big_flag, gs, blk, 0, c->stream, d_sub_n_sel, (int32_t)nsub, n_lo, c->d_big_pos.p);
         FEDD_TRY(exclusive_scan_i32(c, c->d_big_pos.p, c->d_big_pos.p, nsub, &nsel));
         if (nsel == 0) return 0;
-        hipLaunchKernelGGL(k_big_compact, gs, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p, (int32_t)nsub, n_lo,
+        hipLaunchKernelGGL(k_big_compact, gs, blk, 0, c->stream, d_sub_n_sel, (int32_t)nsub, n_lo,
                            (const int32_t*)c->d_big_pos.p, c->d_big_ids.p);
         ids = c->d_big_ids.p;
     }
@@ -362,7 +363,7 @@ int schwarz_setup_big(fedd_ctx* c) {
     int32_t* d_bad = c->d_flags.p + 1;
     FEDD_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), c->stream));
     const int32_t p_off = c->merged ? (int32_t)c->merged_nA : INT32_MAX;
-    FEDD_TRY(schwarz_dense_batched(c, nsub, NMB, 0, p_off, restricted, max_n, d_bad));
+    FEDD_TRY(schwarz_dense_batched(c, nsub, NMB, 0, p_off, restricted, max_n, d_bad, nullptr));
     int32_t bad = 0;
     FEDD_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     FEDD_HIP(hipStreamSynchronize(c->stream));

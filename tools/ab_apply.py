@@ -1,4 +1,5 @@
-"""A/B of the restricted Schwarz apply kernels on cfg 2 (development aid)."""
+"""A/B of the restricted Schwarz apply on the structured 3D P1 Laplace cube (development aid).
+usage: ab_apply.py [cells] [key=value,... per configuration]"""
 import os
 import sys
 
@@ -8,27 +9,37 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from feddlib_amd import capi  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+configs = sys.argv[2:] or ["schwarz_dedupe=1"]
 m = capi.structured_mesh(3, 1, M)
 c = capi.Context(device=0)
 c.mesh_set_dict(m)
 c.pattern_build(1, capi.BLOCK_SCALAR)
 c.assemble(capi.FORM_LAPLACE)
-c.assemble_rhs([1.0])
 c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
-c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
-info = c.schwarz_info()
-r = np.random.default_rng(0).standard_normal(m["gid_uni"].shape[0])
-zs = {}
+nr = c.csr_sizes()[0]
+r = np.random.default_rng(0).standard_normal(nr)
+z0 = None
 c.timing_enable(True)
-for kind in (1, 0, 1, 0):
-    c.set_option("apply_kind", kind)
-    zs[kind] = c.schwarz_apply(r)
-    c.schwarz_apply_device(5)
-    c.timing_reset()
-    c.schwarz_apply_device(50)
-    c.sync()
-    t = c.timing_get()["schwarz_apply"]
-    ms = t[0] / t[1]
-    print("apply_kind", kind, "ms", ms, "GB/s", (info["inverse_bytes"] + 24 * r.shape[0]) / ms / 1e6, flush=True)
-print("max |z0 - z1| / max|z|", np.abs(zs[0] - zs[1]).max() / np.abs(zs[1]).max())
+for rep in range(2):
+    for cfg in configs:
+        for kv in cfg.split(","):
+            k, v = kv.split("=")
+            c.set_option(k, float(v))
+        c.schwarz_set_target(27, 1.0)
+        c.timing_reset()
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+        c.sync()
+        ts = c.timing_get()["schwarz_setup"][0]
+        z = c.schwarz_apply(r)
+        if z0 is None:
+            z0 = z
+        c.schwarz_apply_device(5)
+        c.timing_reset()
+        c.schwarz_apply_device(40)
+        c.sync()
+        t = c.timing_get()["schwarz_apply"]
+        info = c.schwarz_info()
+        print("M %d %-44s apply %.1f us  setup %.2f ms  unique %d of %d  slabs %.1f MB  diff vs first %.1e"
+              % (M, cfg, t[0] / t[1] * 1e3, ts, info["n_unique"], info["n_subdomains"], info["inverse_bytes"] / 1e6,
+                 np.abs(z - z0).max() / np.abs(z0).max()), flush=True)
 c.close()
