@@ -17,7 +17,7 @@ COMBINE_RESTRICTED, COMBINE_AVERAGING, COMBINE_FULL = range(3)
 (T_SYMBOLIC, T_ASSEMBLE, T_RHS, T_DIRICHLET, T_SPMV, T_SCHWARZ_SETUP, T_SCHWARZ_APPLY, T_ORTHO, T_COARSE_SETUP,
  T_COARSE_APPLY, T_HALO, T_ALLREDUCE, T_SPMV_SETUP) = range(13)
 TIMER_NAMES = ["symbolic", "assemble", "rhs", "dirichlet", "spmv", "schwarz_setup", "schwarz_apply", "ortho",
-               "coarse_setup", "coarse_apply", "halo", "allreduce", "spmv_setup"]
+               "coarse_setup", "coarse_apply", "halo", "allreduce", "spmv_setup", "gs_dot", "gs_update"]
 COARSE_Q1 = 1
 COARSE_GDSW = 2
 COARSE_RGDSW = 3
@@ -83,6 +83,7 @@ SIGNATURES = {
     "fedd_schwarz_apply_device": [C.c_void_p, C.c_int],
     "fedd_schwarz_info": [C.c_void_p, _i64p, _i64p, _i64p],
     "fedd_schwarz_unique": [C.c_void_p, _i64p],
+    "fedd_schwarz_sizes": [C.c_void_p, _i64p, _i64p],
     "fedd_gmres": [C.c_void_p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int, _ip, _f64p],
     "fedd_set_option": [C.c_void_p, C.c_char_p, C.c_double],
     "fedd_timing_enable": [C.c_void_p, C.c_int],
@@ -496,7 +497,12 @@ class Context:
         _chk(self._L.fedd_schwarz_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         u = C.c_int64()
         _chk(self._L.fedd_schwarz_unique(self._h, C.byref(u)))
-        return dict(n_subdomains=a.value, max_size=b.value, inverse_bytes=c.value, n_unique=u.value)
+        out = dict(n_subdomains=a.value, max_size=b.value, inverse_bytes=c.value, n_unique=u.value)
+        if a.value and b.value <= 256:      # (the large-subdomain path keeps no per-box lists)
+            ss, so = C.c_int64(), C.c_int64()
+            if self._L.fedd_schwarz_sizes(self._h, C.byref(ss), C.byref(so)) == 0:
+                out.update(sum_sizes=ss.value, sum_owned=so.value)
+        return out
 
     def schwarz_apply(self, r):
         r = np.ascontiguousarray(r, dtype=np.float64)

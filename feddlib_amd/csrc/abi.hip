@@ -521,6 +521,23 @@ extern "C" int fedd_schwarz_unique(fedd_ctx* c, int64_t* n_unique) {
     return 0;
 }
 
+extern "C" int fedd_schwarz_sizes(fedd_ctx* c, int64_t* sum_sizes, int64_t* sum_owned) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_schwarz && !c->sw_big_active, "fedd_schwarz_sizes: no preconditioner of the small-subdomain path");
+    FEDD_HIP(hipSetDevice(c->device));
+    FEDD_TRY(c->d_itmp0.ensure((size_t)c->sw_nsub + 1));
+    int64_t t = 0;
+    if (sum_sizes) {
+        FEDD_TRY(exclusive_scan_i32(c, c->d_sub_n.p, c->d_itmp0.p, c->sw_nsub, &t));
+        *sum_sizes = t;
+    }
+    if (sum_owned) {
+        FEDD_TRY(exclusive_scan_i32(c, c->d_sub_nown.p, c->d_itmp0.p, c->sw_nsub, &t));
+        *sum_owned = t;
+    }
+    return 0;
+}
+
 extern "C" int fedd_spmv_info(fedd_ctx* c, int64_t* nnz_pattern, int64_t* nnz_streamed) {
     NEED_DEVICE(c);
     FEDD_CHECK(c->have_pattern, "fedd_spmv_info: no matrix");

@@ -289,7 +289,8 @@ struct ScopedTimer {
             // around each of several hundred small launches per solve costs a few percent
             const bool per_iteration = timer == FEDD_T_SPMV || timer == FEDD_T_SCHWARZ_APPLY ||
                                        timer == FEDD_T_ORTHO || timer == FEDD_T_COARSE_APPLY ||
-                                       timer == FEDD_T_HALO || timer == FEDD_T_ALLREDUCE;
+                                       timer == FEDD_T_HALO || timer == FEDD_T_ALLREDUCE || timer == FEDD_T_GS_DOT ||
+                                       timer == FEDD_T_GS_UPDATE;
             const int64_t k = c->timers[id].seen++;
             if (per_iteration && c->timing_stride > 1 && k % c->timing_stride != 0) return;
             sampled = true;

@@ -675,19 +675,24 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
             {
                 ScopedTimer t(c, FEDD_T_ORTHO);
                 const int ncg = (k + 1 + MD2_CG - 1) / MD2_CG;
+                ScopedTimer td(c, FEDD_T_GS_DOT);
                 if (md2_nch == 2)
                     hipLaunchKernelGGL(k_multidot2<2>, dim3(nblkd, std::min(md2_gy, ncg)), blk, 0, st, (const double*)V, ldv, n,
                                        k, (const double*)u, (const double*)wt, c->d_part.p, nblkd);
                 else
                     hipLaunchKernelGGL(k_multidot2<4>, dim3(nblkd, std::min(md2_gy, ncg)), blk, 0, st, (const double*)V, ldv, n,
                                        k, (const double*)u, (const double*)wt, c->d_part.p, nblkd);
+                td.stop();
                 hipLaunchKernelGGL(k_reduce_cols, dim3(2 * k + 2), blk, 0, st, (const double*)c->d_part.p, S + o2.st, nblkd,
                                    (const int32_t*)nullptr);
                 FEDD_TRY(allreduce_sum(c, S + o2.st, 2 * k + 2));
                 hipLaunchKernelGGL(k_dcgs2_small, dim3(1), blk, (size_t)(6 * m + 8) * sizeof(double), st, S, o, o2, k, m);
-                if (k < m)  // the last step of a cycle needs no further basis vector
+                if (k < m) {  // the last step of a cycle needs no further basis vector
+                    ScopedTimer tu(c, FEDD_T_GS_UPDATE);
                     hipLaunchKernelGGL(k_axpy2, dim3(nblk2), blk, 0, st, V, ldv, n, k, (const double*)(S + o2.cf), m, u,
                                        (const double*)wt);
+                    tu.stop();
+                }
                 t.stop();
             }
             FEDD_HIP(hipMemcpyAsync(c->h_pinned + 4 * (j & 1), S + o.misc, 3 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -256,8 +256,8 @@ __device__ __forceinline__ int bsearch_i32(const int32_t* a, int n, int32_t v);
 // its REPRESENTATIVE, only representatives are inverted and stored, every other subdomain's slab pointer refers to its
 // representative's slab.  Equal fingerprints = equal matrices to 6e-14 relative per entry (a collision of two
 // independent 64-bit hashes aside), i.e. inverses equal to ~1e-12: far inside the 1e-10 parity bar; a fingerprint that
-// differs through rounding only costs a shared slab, never correctness.  The apply then reads a 22 KB slab that sits in
-// L2 / L1 instead of streaming 8 GB: the one-level step at 214^3 cells drops from ~565 to ~ ms.
+// differs through rounding only costs a shared slab, never correctness.  The apply then works from a few slabs that sit in
+// L2 instead of streaming 8 GB (k_apply_mfma below): the one-level step at 214^3 cells drops from 564 to 341 ms.
 __global__ void k_row_absmax(const int32_t* __restrict__ rowptr, const double* __restrict__ val, int32_t n_rows,
                              double* __restrict__ rmax) {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,11 +327,8 @@ __global__ __launch_bounds__(64) void k_sub_fingerprint(const int32_t* __restric
 }
 
 // open-addressing table keyed by the 128-bit fingerprint; the slot's value is the lowest subdomain index seen
-__global__ void k_fp_insert(const uint64_t* __restrict__ fp, int32_t nsub, uint64_t* __restrict__ tkey, int32_t* __restrict__ tmin,
-                            int64_t tsize, int32_t* __restrict__ slot_of) {
-    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nsub) return;
-    const uint64_t h1 = fp[2 * (int64_t)b], h2 = fp[2 * (int64_t)b + 1];
+__device__ __forceinline__ int32_t fp_insert_one(uint64_t h1, uint64_t h2, int32_t b, uint64_t* __restrict__ tkey,
+                                                 int32_t* __restrict__ tmin, int64_t tsize) {
     int64_t s = (int64_t)(h1 % (uint64_t)tsize);
     for (int64_t probe = 0; probe < tsize; ++probe) {
         const unsigned long long old = atomicCAS((unsigned long long*)&tkey[2 * s], 0ull, (unsigned long long)h1);
@@ -346,13 +343,36 @@ __global__ void k_fp_insert(const uint64_t* __restrict__ fp, int32_t nsub, uint6
             } while (second == 0ull);
             if (second == (h2 | 1ull)) {
                 atomicMin(&tmin[s], b);
-                slot_of[b] = (int32_t)s;
-                return;
+                return (int32_t)s;
             }
         }
         s = s + 1 == tsize ? 0 : s + 1;
     }
-    slot_of[b] = -1;   // table full (cannot happen: tsize >= 2 nsub): own representative
+    return -1;   // table full (cannot happen: tsize >= 2 nsub): own representative
+}
+
+// The lanes of a wave that carry the same fingerprint (on a structured mesh: nearly all 64) send ONE of them to the
+// table -- the lowest lane = the lowest subdomain index of the group: a few hundred thousand atomics on a few dozen
+// addresses serialise in L2 otherwise (5.8 ms at 389 017 subdomains, more than the inversions that are left).
+__global__ void k_fp_insert(const uint64_t* __restrict__ fp, int32_t nsub, uint64_t* __restrict__ tkey, int32_t* __restrict__ tmin,
+                            int64_t tsize, int32_t* __restrict__ slot_of) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool active = b < nsub;
+    const unsigned long long h1 = active ? fp[2 * (int64_t)b] : 0ull, h2 = active ? fp[2 * (int64_t)b + 1] : 0ull;
+    uint64_t todo = __ballot(active);
+    int32_t my_slot = -1;
+    while (todo) {      // (uniform over the wave)
+        const int leader = __builtin_ctzll(todo);
+        const unsigned long long l1 = __shfl(h1, leader, 64), l2 = __shfl(h2, leader, 64);
+        const uint64_t same = __ballot(active && h1 == l1 && h2 == l2) & todo;
+        int32_t s_found = -1;
+        if (lane == leader) s_found = fp_insert_one(h1, h2, b, tkey, tmin, tsize);
+        s_found = __shfl(s_found, leader, 64);
+        if ((same >> lane) & 1ull) my_slot = s_found;
+        todo &= ~same;
+    }
+    if (active) slot_of[b] = my_slot;
 }
 
 __global__ void k_fp_resolve(const int32_t* __restrict__ slot_of, const int32_t* __restrict__ tmin, const int32_t* __restrict__ sub_n,

@@ -1132,7 +1132,8 @@ private:
 // the running stacked timer: the StackedTimer report of the drivers' tails then shows where the GPU time went
 inline void addDeviceTimers(const DeviceContextPtr& dev, Teuchos::StackedTimer& st) {
     static const char* names[FEDD_T_COUNT] = {"symbolic", "assemble", "rhs", "dirichlet", "spmv", "schwarz setup", "schwarz apply",
-                                             "orthogonalisation", "coarse setup", "coarse apply", "halo", "all-reduce", "spmv setup"};
+                                             "orthogonalisation", "coarse setup", "coarse apply", "halo", "all-reduce", "spmv setup",
+                                             "orthogonalisation: dot sweep", "orthogonalisation: update sweep"};
     for (int t = 0; t < FEDD_T_COUNT; ++t) {
         double ms = 0.;
         int64_t n = 0;

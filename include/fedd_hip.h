@@ -61,7 +61,9 @@ enum fedd_timer {
     FEDD_T_HALO     = 10, /* ghost import: pack, send / receive, unpack (several ranks)  */
     FEDD_T_ALLREDUCE= 11, /* all-reduce calls (inside the classes that issue them)        */
     FEDD_T_SPMV_SETUP = 12, /* compaction of the solver's SpMV stream (once per assembled matrix) */
-    FEDD_T_COUNT    = 13
+    FEDD_T_GS_DOT   = 13, /* Gram-Schmidt sweep 1 alone: the multi-dot kernel over the Krylov basis (inside ORTHO)   */
+    FEDD_T_GS_UPDATE= 14, /* Gram-Schmidt sweep 2 alone: the multi-axpy kernel over the Krylov basis (inside ORTHO)  */
+    FEDD_T_COUNT    = 15
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -290,6 +292,9 @@ int fedd_schwarz_info(fedd_ctx* ctx, int64_t* n_subdomains, int64_t* max_size, i
  * largest entry; option "schwarz_dedupe", default 1) share one stored inverse, which fedd_schwarz_info's inverse_bytes
  * counts once.  On the structured cube of the headline a few hundred of the 389 017 subdomains are distinct. */
 int fedd_schwarz_unique(fedd_ctx* ctx, int64_t* n_unique);
+/* sum over this rank's subdomains of their sizes (owned + overlap dofs) and of their owned dofs: what one apply gathers
+ * and scatters (byte model of the apply kernel in bench.py); either output may be NULL */
+int fedd_schwarz_sizes(fedd_ctx* ctx, int64_t* sum_sizes, int64_t* sum_owned);
 
 /* right-preconditioned restarted GMRES (replaces Thyra::solve on the Belos "Block GMRES"
  * LOWS, feddlib/problems/Solver/LinearSolver_def.hpp:72-135; parametersSolver.xml:5-15).
