@@ -27,7 +27,8 @@ typedef default_no NO;
 
 using namespace FEDD;
 
-int main(int argc, char* argv[]) {
+// the body every rank runs (the reference's main between MPI_Init and MPI_Finalize)
+static int run(int argc, char* argv[]) {
     std::string xmlProblemFile = "parametersProblem.xml", xmlPrecFile = "parametersPrec.xml", xmlSolverFile = "parametersSolver.xml";
     std::string outFile = "solutionLaplace.txt";
     double length = 4.;
@@ -43,12 +44,13 @@ int main(int argc, char* argv[]) {
         if (val("problemfile", xmlProblemFile) || val("precfile", xmlPrecFile) || val("solverfile", xmlSolverFile) || val("out", outFile)) continue;
         if (val("length", tmp)) { length = std::atof(tmp.c_str()); continue; }
         if (a == "--vectorLaplace") { vL = true; continue; }
+        if (val("ranks-as-threads", tmp)) continue;     // handled by main
         std::cerr << "unknown option " << a << std::endl;
         return 2;
     }
     (void)length;
     try {
-        Teuchos::RCP<const Teuchos::Comm<int> > comm = Teuchos::rcp(new Teuchos::Comm<int>(0, 1));
+        Teuchos::RCP<const Teuchos::Comm<int> > comm = Teuchos::DefaultComm<int>::getComm();
         ParameterListPtr_Type parameterListProblem = Teuchos::getParametersFromXmlFile(xmlProblemFile);
         ParameterListPtr_Type parameterListPrec = Teuchos::getParametersFromXmlFile(xmlPrecFile);
         ParameterListPtr_Type parameterListSolver = Teuchos::getParametersFromXmlFile(xmlSolverFile);
@@ -103,16 +105,17 @@ int main(int argc, char* argv[]) {
             laplace.setBoundaries();
             its = laplace.solve();
         }
-        std::cout << "iterations " << its << " relres " << laplace.getLastRelativeResidual() << std::endl;
+        if (comm->getRank() == 0) std::cout << "iterations " << its << " relres " << laplace.getLastRelativeResidual() << std::endl;
 
         Teuchos::RCP<const MultiVector<SC, LO, GO, NO> > exportSolution = laplace.getSolution()->getBlock(0);
-        std::ofstream out(outFile);
+        // several ranks: every rank writes the entries of its unique map (<out>.<rank>)
+        std::ofstream out(comm->getSize() > 1 ? outFile + "." + std::to_string(comm->getRank()) : outFile);
         out << std::setprecision(17);
         auto map = exportSolution->getMap();
         auto data = exportSolution->getData(0);
         for (size_t i = 0; i < data.size(); ++i) out << map->getGlobalElement((LO)i) << " " << data[i] << "\n";
 
-        bool boolExportSolution = true;
+        bool boolExportSolution = comm->getSize() == 1;     // (the facade's exporter writes one rank's piece)
         if (boolExportSolution) {
             Teuchos::RCP<ExporterParaView<SC, LO, GO, NO> > exPara(new ExporterParaView<SC, LO, GO, NO>());
             exPara->setup("solutionLaplace", domain->getMesh(), FEType);
@@ -127,4 +130,22 @@ int main(int argc, char* argv[]) {
         return 1;
     }
     return 0;
+}
+
+// ranks = processes under a launcher (RANK / WORLD_SIZE and FEDD_RENDEZVOUS in the environment, RCCL between the GPUs),
+// or, with --ranks-as-threads=N, N threads of this process sharing one GPU (functional runs of the N > 1 path)
+int main(int argc, char* argv[]) {
+    Teuchos::GlobalMPISession mpiSession(&argc, &argv);
+    int threads = 0;
+    for (int i = 1; i < argc; ++i)
+        if (std::strncmp(argv[i], "--ranks-as-threads=", 19) == 0) threads = std::atoi(argv[i] + 19);
+    if (threads > 1) {
+        try {
+            return Teuchos::runAsRanks(threads, [&](int) { return run(argc, argv); });
+        } catch (const std::exception& e) {
+            std::cerr << "exception: " << e.what() << std::endl;
+            return 1;
+        }
+    }
+    return run(argc, argv);
 }

@@ -83,7 +83,7 @@ def build_driver(verbose: bool = True, which: str = "laplace") -> str:
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd = [gxx, "-std=c++17", "-O2", "-I", host, src, "-o", out, "-L", LIBDIR, "-lfedd_hip",
+    cmd = [gxx, "-std=c++17", "-O2", "-pthread", "-I", host, src, "-o", out, "-L", LIBDIR, "-lfedd_hip",
            "-Wl,-rpath,$ORIGIN/../../feddlib_amd/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -3,15 +3,24 @@
 // FEDD_HAVE_TRILINOS and include the real headers instead: the facade only uses the subset below.
 // API subset mirrored: Teuchos::RCP / rcp / null / rcp_const_cast, Teuchos::ParameterList (get,
 // sublist, set, setParameters, isParameter, isSublist), Teuchos::getParametersFromXmlFile,
-// Teuchos::Comm<int> (getRank/getSize/barrier), Teuchos::ArrayRCP / ArrayView (pointer + size),
+// Teuchos::Comm<int> (getRank/getSize/barrier; several ranks: see CommBackend), Teuchos::GlobalMPISession,
+// Teuchos::DefaultComm<int>::getComm, Teuchos::ArrayRCP / ArrayView (pointer + size),
 // TEUCHOS_TEST_FOR_EXCEPTION, Teuchos::Time / TimeMonitor / StackedTimer (report with OutputOptions).
 #pragma once
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <ctime>
+#include <deque>
+#include <exception>
 #include <iostream>
 #include <fstream>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -74,16 +83,216 @@ private:
 template <class T>
 using ArrayRCP = ArrayView<T>;
 
+// ---- several ranks -------------------------------------------------------------------------------------------------
+// The facade needs little of a communicator itself (a barrier, an all-gather of a few bytes: the 128-byte RCCL id, the
+// halo request lists, norms): the data path of the solver is inside the library (RCCL, or its host-callback transport).
+// Two backends:
+//  * ThreadGroup: the ranks are threads of ONE process (Teuchos::runAsRanks); also carries the library's host-callback
+//    transport (point-to-point mailboxes).  For functional runs of the N > 1 path on a box with fewer GPUs than ranks.
+//  * FileRendezvous: the ranks are processes started by any launcher that exports RANK / WORLD_SIZE (torchrun), FEDD_RANK /
+//    FEDD_NRANKS or OMPI_COMM_WORLD_RANK / _SIZE; the few bytes travel through files in the directory FEDD_RENDEZVOUS
+//    (shared by the ranks, empty at start).  The solver's traffic goes over RCCL.
+// With a real Teuchos (MPI) the facade's Comm calls map onto Teuchos::gatherAll / barrier one to one.
+class CommBackend {
+public:
+    virtual ~CommBackend() {}
+    virtual bool inProcess() const = 0;
+    // out = the `bytes` of every rank, in rank order (every rank passes the same `bytes`)
+    virtual void allgather(int rank, const void* in, size_t bytes, std::vector<char>& out) = 0;
+    virtual void send(int src, int dst, const double* p, size_t n) = 0;
+    virtual void recv(int src, int dst, double* p, size_t n) = 0;
+};
+
+class ThreadGroup : public CommBackend {
+public:
+    explicit ThreadGroup(int world) : world_(world), slots_(world) {}
+    bool inProcess() const override { return true; }
+    void allgather(int rank, const void* in, size_t bytes, std::vector<char>& out) override {
+        std::unique_lock<std::mutex> lk(m_);
+        slots_[rank].assign((const char*)in, (const char*)in + bytes);
+        arrive(lk);                              // everyone has written
+        out.resize(bytes * world_);
+        for (int r = 0; r < world_; ++r) std::copy(slots_[r].begin(), slots_[r].end(), out.begin() + r * bytes);
+        arrive(lk);                              // everyone has read: the slots may be rewritten
+    }
+    void send(int src, int dst, const double* p, size_t n) override {
+        std::lock_guard<std::mutex> lk(m_);
+        box_[{src, dst}].emplace_back(p, p + n);
+        cv_.notify_all();
+    }
+    void recv(int src, int dst, double* p, size_t n) override {
+        std::unique_lock<std::mutex> lk(m_);
+        auto& q = box_[{src, dst}];
+        const bool ok = cv_.wait_for(lk, std::chrono::seconds(120), [&] { return !q.empty(); });
+        TEUCHOS_TEST_FOR_EXCEPTION(!ok, std::runtime_error, "ThreadGroup::recv " << dst << " <- " << src << " timed out");
+        TEUCHOS_TEST_FOR_EXCEPTION(q.front().size() != n, std::runtime_error, "ThreadGroup::recv: message size");
+        std::copy(q.front().begin(), q.front().end(), p);
+        q.pop_front();
+    }
+private:
+    void arrive(std::unique_lock<std::mutex>& lk) {      // reusable barrier (generation counter)
+        const long gen = gen_;
+        if (++count_ == world_) {
+            count_ = 0;
+            ++gen_;
+            cv_.notify_all();
+        } else {
+            const bool ok = cv_.wait_for(lk, std::chrono::seconds(120), [&] { return gen_ != gen; });
+            TEUCHOS_TEST_FOR_EXCEPTION(!ok, std::runtime_error, "ThreadGroup: a rank did not reach the collective");
+        }
+    }
+    int world_, count_ = 0;
+    long gen_ = 0;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<std::vector<char>> slots_;
+    std::map<std::pair<int, int>, std::deque<std::vector<double>>> box_;
+};
+
+class FileRendezvous : public CommBackend {
+public:
+    FileRendezvous(const std::string& dir, int world) : dir_(dir), world_(world) {}
+    bool inProcess() const override { return false; }
+    void allgather(int rank, const void* in, size_t bytes, std::vector<char>& out) override {
+        const long seq = seq_++;
+        const std::string mine = name(seq, rank);
+        {
+            std::ofstream f(mine + ".tmp", std::ios::binary);
+            f.write((const char*)in, (std::streamsize)bytes);
+            TEUCHOS_TEST_FOR_EXCEPTION(!f, std::runtime_error, "FileRendezvous: cannot write in " << dir_);
+        }
+        TEUCHOS_TEST_FOR_EXCEPTION(std::rename((mine + ".tmp").c_str(), mine.c_str()) != 0, std::runtime_error,
+                                   "FileRendezvous: rename in " << dir_);
+        out.resize(bytes * world_);
+        for (int r = 0; r < world_; ++r) {
+            const std::string fn = name(seq, r);
+            bool ok = false;
+            for (int tries = 0; tries < 12000 && !ok; ++tries) {      // 120 s
+                std::ifstream f(fn, std::ios::binary);
+                if (f && f.read(out.data() + r * bytes, (std::streamsize)bytes)) ok = true;
+                else std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+            TEUCHOS_TEST_FOR_EXCEPTION(!ok, std::runtime_error, "FileRendezvous: rank " << r << " did not arrive (" << fn << ")");
+        }
+        // everyone who wrote file seq has finished reading the files of seq - 1
+        if (seq > 0) std::remove(name(seq - 1, rank).c_str());
+    }
+    void send(int, int, const double*, size_t) override { TEUCHOS_TEST_FOR_EXCEPTION(true, std::logic_error, "FileRendezvous: no point-to-point (RCCL carries the data)"); }
+    void recv(int, int, double*, size_t) override { TEUCHOS_TEST_FOR_EXCEPTION(true, std::logic_error, "FileRendezvous: no point-to-point (RCCL carries the data)"); }
+private:
+    std::string name(long seq, int rank) const { return dir_ + "/fedd_" + std::to_string(seq) + "_" + std::to_string(rank) + ".bin"; }
+    std::string dir_;
+    int world_;
+    long seq_ = 0;
+};
+
 template <class Ordinal>
 class Comm {
 public:
-    Comm(int rank = 0, int size = 1) : rank_(rank), size_(size) {}
+    Comm(int rank = 0, int size = 1, std::shared_ptr<CommBackend> backend = nullptr) : rank_(rank), size_(size), backend_(backend) {
+        TEUCHOS_TEST_FOR_EXCEPTION(size > 1 && !backend, std::logic_error, "Teuchos::Comm: " << size << " ranks need a backend (Teuchos::DefaultComm / runAsRanks)");
+    }
     int getRank() const { return rank_; }
     int getSize() const { return size_; }
-    void barrier() const {}
+    void barrier() const {
+        if (size_ > 1) {
+            char c = 0;
+            std::vector<char> all;
+            backend_->allgather(rank_, &c, 1, all);
+        }
+    }
+    // the facade's collectives (Teuchos::gatherAll / reduceAll(REDUCE_SUM) / broadcast); sums in rank order: same bits everywhere
+    void gatherAll(const void* in, size_t bytes, std::vector<char>& out) const {
+        if (size_ > 1) backend_->allgather(rank_, in, bytes, out);
+        else out.assign((const char*)in, (const char*)in + bytes);
+    }
+    void sumAll(double* v, int n) const {
+        if (size_ == 1) return;
+        std::vector<char> all;
+        backend_->allgather(rank_, v, n * sizeof(double), all);
+        const double* a = (const double*)all.data();
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int r = 0; r < size_; ++r) s += a[(size_t)r * n + i];
+            v[i] = s;
+        }
+    }
+    void broadcast(int root, size_t bytes, void* buf) const {
+        if (size_ == 1) return;
+        std::vector<char> all;
+        backend_->allgather(rank_, buf, bytes, all);
+        std::copy(all.begin() + root * bytes, all.begin() + (root + 1) * bytes, (char*)buf);
+    }
+    CommBackend* backend() const { return backend_.get(); }
 private:
     int rank_, size_;
+    std::shared_ptr<CommBackend> backend_;
 };
+
+// Teuchos::GlobalMPISession / DefaultComm: the communicator of the calling rank -- the one set by runAsRanks for this
+// thread, else the one the launcher's environment describes (one rank when it describes none)
+class GlobalMPISession {
+public:
+    GlobalMPISession(int*, char***) {}
+};
+namespace detail {
+inline RCP<const Comm<int>>& threadComm() {
+    static thread_local RCP<const Comm<int>> c;
+    return c;
+}
+inline int envInt(const char* const* names, int dflt) {
+    for (; *names; ++names)
+        if (const char* v = std::getenv(*names)) return std::atoi(v);
+    return dflt;
+}
+}  // namespace detail
+template <class Ordinal>
+class DefaultComm {
+public:
+    static RCP<const Comm<Ordinal>> getComm() {
+        if (!detail::threadComm().is_null()) return detail::threadComm();
+        static RCP<const Comm<Ordinal>> process;
+        if (process.is_null()) {
+            static const char* const rk[] = {"FEDD_RANK", "RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", nullptr};
+            static const char* const sz[] = {"FEDD_NRANKS", "WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", nullptr};
+            const int rank = detail::envInt(rk, 0), size = detail::envInt(sz, 1);
+            std::shared_ptr<CommBackend> be;
+            if (size > 1) {
+                const char* dir = std::getenv("FEDD_RENDEZVOUS");
+                TEUCHOS_TEST_FOR_EXCEPTION(!dir, std::runtime_error, "Teuchos::DefaultComm: " << size << " ranks: set FEDD_RENDEZVOUS to an empty directory shared by the ranks");
+                be = std::make_shared<FileRendezvous>(dir, size);
+            }
+            process = rcp(new Comm<Ordinal>(rank, size, be));
+        }
+        return process;
+    }
+};
+
+// run `body(rank)` as `world` ranks = threads of this process; inside, DefaultComm<int>::getComm() is the rank's
+// communicator.  Returns the largest return value; an exception of any rank is rethrown after all have ended.
+template <class F>
+int runAsRanks(int world, F body) {
+    auto group = std::make_shared<ThreadGroup>(world);
+    std::vector<int> rc(world, 0);
+    std::vector<std::exception_ptr> err(world);
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r)
+        th.emplace_back([&, r] {
+            detail::threadComm() = rcp(new Comm<int>(r, world, group));
+            try {
+                rc[r] = body(r);
+            } catch (...) {
+                err[r] = std::current_exception();
+            }
+            detail::threadComm() = RCP<const Comm<int>>();
+        });
+    for (auto& t : th) t.join();
+    for (auto& e : err)
+        if (e) std::rethrow_exception(e);
+    int worst = 0;
+    for (int v : rc) worst = std::max(worst, v);
+    return worst;
+}
 
 class ParameterList {
 public:

@@ -59,8 +59,97 @@ inline void feddCheck(int rc, const char* what) {
 struct DeviceContext {
     fedd_ctx* ctx = nullptr;
     long generation = 0;      // bumped by every assembly into the context
+    Teuchos::RCP<const Teuchos::Comm<int> > comm;
     explicit DeviceContext(int device) { feddCheck(fedd_ctx_create(&ctx, device, nullptr, 0, 1), "fedd_ctx_create"); }
+    // One context per rank of the communicator (the reference: one MPI rank per subdomain block).  Ranks = processes:
+    // GPU = LOCAL_RANK (else rank), RCCL communicator from the 128-byte id that rank 0 makes and the communicator
+    // broadcasts.  Ranks = threads of one process (Teuchos::runAsRanks): one GPU, the library's host-callback transport.
+    explicit DeviceContext(const Teuchos::RCP<const Teuchos::Comm<int> >& c) : comm(c) {
+        const int rank = c->getRank(), size = c->getSize();
+        const char* lr = std::getenv("LOCAL_RANK");
+        if (size == 1) {
+            feddCheck(fedd_ctx_create(&ctx, lr ? std::atoi(lr) : 0, nullptr, 0, 1), "fedd_ctx_create");
+        } else if (c->backend()->inProcess()) {
+            feddCheck(fedd_ctx_create(&ctx, lr ? std::atoi(lr) : 0, nullptr, rank, size), "fedd_ctx_create");
+            feddCheck(fedd_comm_set_host_callbacks(ctx, &DeviceContext::exchangeCb, &DeviceContext::allreduceCb, this), "fedd_comm_set_host_callbacks");
+        } else {
+            unsigned char id[128] = {0};
+            if (rank == 0) feddCheck(fedd_nccl_unique_id(id), "fedd_nccl_unique_id");
+            c->broadcast(0, sizeof(id), id);
+            feddCheck(fedd_ctx_create(&ctx, lr ? std::atoi(lr) : rank, id, rank, size), "fedd_ctx_create");
+        }
+    }
+    // after fedd_mesh_set* and fedd_halo_set_owners: the exchange plan of the ghost imports
+    void finishHaloPlan() {
+        const int size = comm.is_null() ? 1 : comm->getSize();
+        if (size == 1) return;
+        if (!comm->backend()->inProcess()) {
+            feddCheck(fedd_halo_exchange_setup(ctx), "fedd_halo_exchange_setup");
+            return;
+        }
+        // transport-agnostic form: every rank learns what the others ask of it (an all-to-all of the gid lists, here
+        // through two all-gathers: counts, then the lists padded to the longest)
+        const int rank = comm->getRank();
+        std::vector<int64_t> cnt(size, 0);
+        feddCheck(fedd_halo_requests_sizes(ctx, cnt.data()), "fedd_halo_requests_sizes");
+        int64_t mine = 0;
+        for (int64_t v : cnt) mine += v;
+        std::vector<int64_t> gids((size_t)std::max<int64_t>(mine, 1));
+        feddCheck(fedd_halo_requests_get(ctx, gids.data()), "fedd_halo_requests_get");
+        std::vector<char> allc;
+        comm->gatherAll(cnt.data(), size * sizeof(int64_t), allc);
+        const int64_t* ac = (const int64_t*)allc.data();          // ac[p * size + q] = what rank p asks of rank q
+        int64_t longest = 1;
+        for (int p = 0; p < size; ++p) {
+            int64_t t = 0;
+            for (int q = 0; q < size; ++q) t += ac[(size_t)p * size + q];
+            longest = std::max(longest, t);
+        }
+        gids.resize((size_t)longest, 0);
+        std::vector<char> allg;
+        comm->gatherAll(gids.data(), (size_t)longest * sizeof(int64_t), allg);
+        const int64_t* ag = (const int64_t*)allg.data();
+        std::vector<int64_t> fromMe(size, 0), lists;
+        for (int p = 0; p < size; ++p) {
+            int64_t off = 0;
+            for (int q = 0; q < rank; ++q) off += ac[(size_t)p * size + q];
+            fromMe[p] = ac[(size_t)p * size + rank];
+            lists.insert(lists.end(), ag + (size_t)p * longest + off, ag + (size_t)p * longest + off + fromMe[p]);
+        }
+        if (lists.empty()) lists.push_back(0);
+        feddCheck(fedd_halo_requests_set(ctx, fromMe.data(), lists.data()), "fedd_halo_requests_set");
+    }
     ~DeviceContext() { if (ctx) fedd_ctx_destroy(ctx); }
+private:
+    static int exchangeCb(void* user, int n_peers, const int32_t* peers, const int64_t* send_ptr, const double* send_buf,
+                          const int64_t* recv_ptr, double* recv_buf, int dofs) {
+        DeviceContext* self = (DeviceContext*)user;
+        try {
+            const int rank = self->comm->getRank();
+            Teuchos::CommBackend* be = self->comm->backend();
+            for (int k = 0; k < n_peers; ++k)
+                if (send_ptr[k + 1] > send_ptr[k])
+                    be->send(rank, peers[k], send_buf + send_ptr[k] * dofs, (size_t)((send_ptr[k + 1] - send_ptr[k]) * dofs));
+            for (int k = 0; k < n_peers; ++k)
+                if (recv_ptr[k + 1] > recv_ptr[k])
+                    be->recv(peers[k], rank, recv_buf + recv_ptr[k] * dofs, (size_t)((recv_ptr[k + 1] - recv_ptr[k]) * dofs));
+            return 0;
+        } catch (const std::exception& e) {
+            std::cerr << "facade exchange callback: " << e.what() << std::endl;
+            return 1;
+        }
+    }
+    static int allreduceCb(void* user, double* buf, int n) {
+        DeviceContext* self = (DeviceContext*)user;
+        try {
+            self->comm->sumAll(buf, n);
+            return 0;
+        } catch (const std::exception& e) {
+            std::cerr << "facade allreduce callback: " << e.what() << std::endl;
+            return 1;
+        }
+    }
+public:
     DeviceContext(const DeviceContext&) = delete;
     DeviceContext& operator=(const DeviceContext&) = delete;
 };
@@ -71,8 +160,10 @@ class Map {
 public:
     typedef Teuchos::Comm<int> Comm_Type;
     typedef Teuchos::RCP<const Comm_Type> CommConstPtr_Type;
-    Map(const std::vector<GO>& gids, CommConstPtr_Type comm) : gids_(gids), comm_(comm) {
+    // nGlobal = number of global ids over all ranks (-1: this rank's largest id + 1, right for one rank)
+    Map(const std::vector<GO>& gids, CommConstPtr_Type comm, GO nGlobal = -1) : gids_(gids), comm_(comm) {
         for (size_t i = 0; i < gids_.size(); ++i) maxGid_ = std::max(maxGid_, gids_[i]);
+        if (nGlobal >= 0) maxGid_ = nGlobal - 1;
     }
     LO getNodeNumElements() const { return (LO)gids_.size(); }
     GO getGlobalNumElements() const { return maxGid_ + 1; }
@@ -92,7 +183,7 @@ public:
         std::vector<GO> g(gids_.size() * dofs);
         for (size_t i = 0; i < gids_.size(); ++i)
             for (UN d = 0; d < dofs; ++d) g[i * dofs + d] = dofs * gids_[i] + d;
-        return Teuchos::rcp(new Map(g, comm_));
+        return Teuchos::rcp(new Map(g, comm_, (GO)dofs * (maxGid_ + 1)));
     }
     const std::vector<GO>& gids() const { return gids_; }
 private:
@@ -118,7 +209,12 @@ public:
         for (size_t j = 0; j < data_.size(); ++j)
             for (size_t i = 0; i < data_[j].size(); ++i) data_[j][i] = alpha * A.data_[j][i] + beta * data_[j][i];
     }
-    SC norm2(UN j = 0) const { SC s = 0; for (SC v : data_.at(j)) s += v * v; return std::sqrt(s); }
+    SC norm2(UN j = 0) const {      // over all ranks (the map is a unique map: every entry counted once)
+        double s = 0;
+        for (SC v : data_.at(j)) s += v * v;
+        if (!map_->getComm().is_null()) map_->getComm()->sumAll(&s, 1);
+        return std::sqrt(s);
+    }
     std::vector<SC>& raw(UN j = 0) { return data_.at(j); }
     const std::vector<SC>& raw(UN j = 0) const { return data_.at(j); }
 private:
@@ -290,17 +386,37 @@ public:
         TEUCHOS_TEST_FOR_EXCEPTION(!(M >= 1), std::logic_error, "H/h is to small.");
         TEUCHOS_TEST_FOR_EXCEPTION(numProcsCoarseSolve != 0, std::logic_error, "Mpi Ranks Coarse is not supported.");
         dim_ = dim; FEType_ = FEType; n_ = N; m_ = M; flagsOption_ = flagsOption;
-        const int rank = comm_->getRank();
+        const int rank = comm_->getRank(), size = comm_->getSize();
+        int nblocks = 1;
+        for (int d = 0; d < dim; ++d) nblocks *= N;
+        TEUCHOS_TEST_FOR_EXCEPTION(nblocks != size, std::logic_error, "Domain::buildMesh: " << N << "^" << dim << " subdomain blocks need as many ranks, the communicator has " << size);
         int dec[3] = {N, N, N}, cel[3] = {M, M, M};
+        // Several ranks: the rank's block (the reference's repeated map) plus four layers of ghost elements, which
+        // complete the rows of the ghost nodes within three layers (row ghosts): the Schwarz boxes a rank boundary
+        // crosses are then built whole on both sides and the preconditioner does not depend on the split
+        const int ghosts = size > 1 ? 4 : 0;
         int64_t ne, nr, nu, ng;
-        feddCheck(fedd_mesh_structured_sizes(dim, dec, cel, rank, 0, &ne, &nr, &nu, &ng), "fedd_mesh_structured_sizes");
+        feddCheck(fedd_mesh_structured_sizes(dim, dec, cel, rank, ghosts, &ne, &nr, &nu, &ng), "fedd_mesh_structured_sizes");
         conn_.resize(ne * (dim + 1)); xyz_.resize(nr * dim); flagRep_.resize(nr); flagUni_.resize(nu);
-        std::vector<int64_t> grep(nr), guni(nu);
+        std::vector<int64_t> grep(nr), guni(nu), rowGhost;
+        std::vector<int32_t> rowGhostFlag;
         double org[3] = {0, 0, 0}, sz[3] = {length, dim == 2 ? height : width, height};
         for (size_t d = 0; d < coorRec.size() && d < 3; ++d) org[d] = coorRec[d];
-        feddCheck(fedd_mesh_structured_build(dim, dec, cel, rank, org, sz, flagsOption, 0, conn_.data(), xyz_.data(), grep.data(),
+        feddCheck(fedd_mesh_structured_build(dim, dec, cel, rank, org, sz, flagsOption, ghosts, conn_.data(), xyz_.data(), grep.data(),
                                              flagRep_.data(), guni.data(), flagUni_.data()), "fedd_mesh_structured_build");
-        finishMesh(grep, guni, dim + 1, ng);
+        if (ghosts >= 2) {
+            int64_t nrg = 0;
+            feddCheck(fedd_mesh_structured_row_ghosts(dim, dec, cel, rank, ghosts, org, sz, flagsOption, &nrg, nullptr, nullptr), "fedd_mesh_structured_row_ghosts");
+            rowGhost.resize((size_t)nrg); rowGhostFlag.resize((size_t)nrg);
+            if (nrg) feddCheck(fedd_mesh_structured_row_ghosts(dim, dec, cel, rank, ghosts, org, sz, flagsOption, &nrg, rowGhost.data(), rowGhostFlag.data()), "fedd_mesh_structured_row_ghosts");
+        }
+        finishMesh(grep, guni, dim + 1, ng, &rowGhost, &rowGhostFlag);
+        if (size > 1) {     // owner of every repeated node (lowest rank whose block holds it), then the import plan
+            std::vector<int32_t> owner(grep.size());
+            feddCheck(fedd_mesh_structured_owner(dim, dec, cel, (int64_t)grep.size(), grep.data(), owner.data()), "fedd_mesh_structured_owner");
+            feddCheck(fedd_halo_set_owners(dev_->ctx, (int64_t)grep.size(), grep.data(), owner.data()), "fedd_halo_set_owners");
+            dev_->finishHaloPlan();
+        }
     }
     // generic entry for externally built (e.g. unstructured, P2) meshes in the reference's data model
     void setMesh(int dim, std::string FEType, int nen, const std::vector<int32_t>& conn, const std::vector<double>& xyz,
@@ -313,8 +429,14 @@ public:
 
     // what MeshPartitioner::readAndPartition leaves in the domain on one rank (MeshPartitioner_def.hpp:224-530,
     // MeshUnstructured::readMeshSize / readMeshEntity): INRIA .mesh file, repeated = unique = identity numbering
+    // Several ranks: every rank reads the file (as in the reference), partitions the elements with the library's
+    // deterministic coordinate bisection (in place of METIS_PartMeshDual, :324) -- the same partition on every rank
+    // without communication -- and keeps its part plus two layers of ghost elements (row ghosts within one layer).
     void readMeshFile(const std::string& file, int dim, std::string FEType, int volumeID) {
-        TEUCHOS_TEST_FOR_EXCEPTION(comm_->getSize() > 1, std::logic_error, "Domain::readMeshFile: one rank in this build");
+        if (comm_->getSize() > 1) {
+            readAndPartitionMeshFile(file, dim, FEType, volumeID);
+            return;
+        }
         int64_t nv, ne, ns;
         feddCheck(fedd_mesh_read_sizes(file.c_str(), dim, &nv, &ne, &ns), "fedd_mesh_read_sizes");
         std::vector<double> xyz(nv * dim);
@@ -326,6 +448,28 @@ public:
         volumeID_ = volumeID;
         setMesh(dim, FEType, dim + 1, conn, xyz, gid, gid, vflag);
         flagRep_ = vflag;
+    }
+    void readAndPartitionMeshFile(const std::string& file, int dim, std::string FEType, int volumeID) {
+        TEUCHOS_TEST_FOR_EXCEPTION(FEType != "P1", std::logic_error, "Domain::readMeshFile on several ranks: P1 meshes");
+        const int rank = comm_->getRank(), size = comm_->getSize(), nen = dim + 1, layers = 2;
+        int64_t nv, ne, ns;
+        feddCheck(fedd_mesh_read_sizes(file.c_str(), dim, &nv, &ne, &ns), "fedd_mesh_read_sizes");
+        std::vector<double> xyz(nv * dim);
+        std::vector<int32_t> vflag(nv), conn(ne * nen), eflag(ne), surf(ns * dim), sflag(ns), part(ne);
+        feddCheck(fedd_mesh_read(file.c_str(), dim, xyz.data(), vflag.data(), conn.data(), eflag.data(), surf.data(), sflag.data()), "fedd_mesh_read");
+        feddCheck(fedd_mesh_partition(dim, nen, ne, conn.data(), nv, xyz.data(), size, part.data()), "fedd_mesh_partition");
+        int64_t nel, nr, nu, nrg;
+        feddCheck(fedd_mesh_partition_sizes(nen, ne, conn.data(), nv, part.data(), size, rank, layers, &nel, &nr, &nu, &nrg), "fedd_mesh_partition_sizes");
+        conn_.assign(nel * nen, 0); xyz_.assign(nr * dim, 0.); flagRep_.assign(nr, 0); flagUni_.assign(nu, 0);
+        std::vector<int64_t> grep(nr), guni(nu), rowGhost(nrg), egid(nel);
+        std::vector<int32_t> owner(nr), rowGhostFlag(nrg);
+        feddCheck(fedd_mesh_partition_extract(dim, nen, ne, conn.data(), nv, xyz.data(), vflag.data(), part.data(), size, rank, layers,
+                                              conn_.data(), xyz_.data(), grep.data(), flagRep_.data(), owner.data(), guni.data(), flagUni_.data(),
+                                              rowGhost.data(), rowGhostFlag.data(), egid.data()), "fedd_mesh_partition_extract");
+        dim_ = dim; FEType_ = FEType; volumeID_ = volumeID;
+        finishMesh(grep, guni, nen, nv, &rowGhost, &rowGhostFlag);
+        feddCheck(fedd_halo_set_owners(dev_->ctx, (int64_t)grep.size(), grep.data(), owner.data()), "fedd_halo_set_owners");
+        dev_->finishHaloPlan();
     }
     // Domain::buildP2ofP1Domain (Domain_def.hpp -> MeshUnstructured::buildP2ofP1MeshEdge, MeshUnstructured_def.hpp:129-410)
     void buildP2ofP1Domain(const Teuchos::RCP<Domain>& domainP1) {
@@ -380,13 +524,18 @@ public:
     int nodesPerElement() const { return nen_; }
     const std::vector<double>& xyzRepeated() const { return xyz_; }
     const std::vector<int32_t>& uniqueLocalOfRepeated() const { return uniOfRep_; }
+    // several ranks: nodes of other ranks whose rows this rank also builds (fedd_mesh_set_rows); their device node id is
+    // number of unique nodes + position here
+    const std::vector<int32_t>& rowGhostRepeatedIds() const { return rowGhostRep_; }
+    const std::vector<int32_t>& rowGhostFlags() const { return rowGhostFlag_; }
 
 private:
-    void finishMesh(const std::vector<int64_t>& grep, const std::vector<int64_t>& guni, int nen, int64_t nGlobal) {
+    void finishMesh(const std::vector<int64_t>& grep, const std::vector<int64_t>& guni, int nen, int64_t nGlobal,
+                    const std::vector<int64_t>* rowGhost = nullptr, const std::vector<int32_t>* rowGhostFlag = nullptr) {
         nen_ = nen;
         std::vector<GO> gr(grep.begin(), grep.end()), gu(guni.begin(), guni.end());
-        mapRepeated_ = Teuchos::rcp(new Map_Type(gr, comm_));
-        mapUnique_ = Teuchos::rcp(new Map_Type(gu, comm_));
+        mapRepeated_ = Teuchos::rcp(new Map_Type(gr, comm_, (GO)nGlobal));
+        mapUnique_ = Teuchos::rcp(new Map_Type(gu, comm_, (GO)nGlobal));
         // repeated-local id of every unique node (for getPointsUnique)
         uniOfRep_.assign(guni.size(), -1);
         std::vector<std::pair<int64_t, int32_t>> s(grep.size());
@@ -397,11 +546,24 @@ private:
             TEUCHOS_TEST_FOR_EXCEPTION(it == s.end() || it->first != guni[i], std::runtime_error, "unique node missing from repeated map");
             uniOfRep_[i] = it->second;
         }
-        (void)nGlobal;
-        const char* lr = std::getenv("LOCAL_RANK");
-        dev_ = Teuchos::rcp(new DeviceContext(lr ? std::atoi(lr) : 0));
-        feddCheck(fedd_mesh_set(dev_->ctx, dim_, nen_, (int64_t)(conn_.size() / nen_), conn_.data(), (int64_t)grep.size(), xyz_.data(),
-                                grep.data(), (int64_t)guni.size(), guni.data(), flagUni_.data()), "fedd_mesh_set");
+        dev_ = Teuchos::rcp(new DeviceContext(comm_));
+        rowGhostRep_.clear();
+        rowGhostFlag_.clear();
+        if (rowGhost) {     // their repeated-local ids (coordinates) and flags: the Dirichlet treatment covers their rows too
+            for (size_t k = 0; k < rowGhost->size(); ++k) {
+                auto it = std::lower_bound(s.begin(), s.end(), std::make_pair((*rowGhost)[k], (int32_t)-1));
+                TEUCHOS_TEST_FOR_EXCEPTION(it == s.end() || it->first != (*rowGhost)[k], std::runtime_error, "row ghost missing from repeated map");
+                rowGhostRep_.push_back(it->second);
+                rowGhostFlag_.push_back((*rowGhostFlag)[k]);
+            }
+        }
+        if (rowGhost && !rowGhost->empty())
+            feddCheck(fedd_mesh_set_rows(dev_->ctx, dim_, nen_, (int64_t)(conn_.size() / nen_), conn_.data(), (int64_t)grep.size(), xyz_.data(),
+                                         grep.data(), (int64_t)guni.size(), guni.data(), flagUni_.data(), (int64_t)rowGhost->size(),
+                                         rowGhost->data(), rowGhostFlag->data()), "fedd_mesh_set_rows");
+        else
+            feddCheck(fedd_mesh_set(dev_->ctx, dim_, nen_, (int64_t)(conn_.size() / nen_), conn_.data(), (int64_t)grep.size(), xyz_.data(),
+                                    grep.data(), (int64_t)guni.size(), guni.data(), flagUni_.data()), "fedd_mesh_set");
     }
     vec2D_dbl_ptr_Type points(const std::vector<double>& xyz, size_t n, const std::vector<int32_t>* idx) const {
         vec2D_dbl_ptr_Type p = Teuchos::rcp(new vec2D_dbl_Type(n, vec_dbl_Type(dim_, 0.)));
@@ -416,7 +578,7 @@ private:
     double length = 1., width = 1., height = 1.;
     int dim_ = 0, n_ = 0, m_ = 0, flagsOption_ = 0, nen_ = 0;
     std::string FEType_;
-    std::vector<int32_t> conn_, flagRep_, flagUni_, uniOfRep_, surf_, surfFlag_;
+    std::vector<int32_t> conn_, flagRep_, flagUni_, uniOfRep_, surf_, surfFlag_, rowGhostRep_, rowGhostFlag_;
     std::vector<double> xyz_;
     int volumeID_ = 10;
     int64_t nP1_ = 0;
@@ -577,13 +739,19 @@ public:
             std::vector<int32_t> nodes, mask;
             std::vector<double> values;
             vec_dbl_Type result(dofs, 0.), point(dim, 0.);
-            for (size_t i = 0; i < flags->size(); ++i) {
+            // owned nodes, then (several ranks) the row ghosts: their rows exist on this rank and get the same treatment
+            const auto& rgRep = dom->rowGhostRepeatedIds();
+            const auto& rgFlag = dom->rowGhostFlags();
+            const auto& xyzRep = dom->xyzRepeated();
+            const size_t nOwned = flags->size();
+            for (size_t i = 0; i < nOwned + rgRep.size(); ++i) {
                 int loc;
-                if (!findFlag((*flags)[i], (int)block, loc)) continue;
+                const int flag = i < nOwned ? (*flags)[i] : rgFlag[i - nOwned];
+                if (!findFlag(flag, (int)block, loc)) continue;
                 const std::string& ty = vecBCType_[loc];
                 if (ty.compare(0, 9, "Dirichlet") != 0) continue;
-                for (int d = 0; d < dim; ++d) point[d] = (*pts)[i][d];
-                for (int d = 0; d < dofs; ++d) result[d] = d < dim ? (*pts)[i][d] : 0.;   // :136-138
+                for (int d = 0; d < dim; ++d) point[d] = i < nOwned ? (*pts)[i][d] : xyzRep[(size_t)rgRep[i - nOwned] * dim + d];
+                for (int d = 0; d < dofs; ++d) result[d] = d < dim ? point[d] : 0.;   // :136-138
                 vecBC_func_[loc](point.data(), result.data(), t, vecBC_Parameters_[loc].data());
                 nodes.push_back((int32_t)i);
                 for (int d = 0; d < dofs; ++d) {

@@ -79,6 +79,56 @@ def test_3d_tight_tolerance_matches_oracle(driver, tmp_path):
     assert rel <= 1e-13
 
 
+@pytest.mark.parametrize("dim,ranks,hh", [(3, 8, 5), (2, 4, 12)])
+def test_driver_on_several_ranks(driver, tmp_path, dim, ranks, hh):
+    """The reference runs this driver as `mpirun -np N` with one rank per subdomain block (laplace/main.cpp:75-109).  Here
+    the N ranks are threads of the driver on one GPU (Teuchos::runAsRanks, the facade's ThreadGroup communicator and the
+    library's host-callback transport); with processes under a launcher the same facade code takes RCCL.  Every rank
+    writes the entries of its unique map; together they are the one-rank solution."""
+    prob = tmp_path / "p.xml"
+    txt = open(os.path.join(XML, "parametersProblem.xml")).read() \
+        .replace('name="Dimension" type="int" value="2"', 'name="Dimension" type="int" value="%d"' % dim) \
+        .replace('name="H/h" type="int" value="10"', 'name="H/h" type="int" value="%d"' % hh)
+    prob.write_text(txt)
+    sol = tmp_path / "s.xml"
+    sol.write_text(open(os.path.join(XML, "parametersSolver.xml")).read()
+                   .replace('value="1e-8"', 'value="1e-12"').replace('"Maximum Iterations" type="int" value="100"',
+                                                                     '"Maximum Iterations" type="int" value="400"'))
+    prec = tmp_path / "c.xml"
+    prec.write_text(open(os.path.join(XML, "parametersPrec.xml")).read()
+                    .replace('name="Combine Values in Overlap" type="string" value="Averaging"',
+                             'name="Combine Values in Overlap" type="string" value="Restricted"'))
+    out = tmp_path / "sol.txt"
+    r = subprocess.run([driver, "--problemfile=%s" % prob, "--precfile=%s" % prec, "--solverfile=%s" % sol, "--out=%s" % out,
+                        "--ranks-as-threads=%d" % ranks], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    mt = re.search(r"iterations (\d+) relres (\S+)", r.stdout)
+    assert mt, r.stdout
+    its, rel = int(mt.group(1)), float(mt.group(2))
+    n = round(ranks ** (1.0 / dim))
+    m = fo.build_mesh_structured(dim, 1, n * hh)            # the same global grid on one rank
+    A_bc, rhs_bc, _, _, _ = fo.laplace_problem(m)
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    x = np.full(xd.shape[0], np.nan)
+    seen = np.zeros(xd.shape[0], dtype=int)
+    for rank in range(ranks):
+        part = np.loadtxt(str(out) + ".%d" % rank, ndmin=2)
+        gid = part[:, 0].astype(int)
+        x[gid] = part[:, 1]
+        seen[gid] += 1
+    assert (seen == 1).all()                                # the unique maps partition the global nodes
+    assert rel <= 1e-12
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+    # 3D: the four ghost layers hold every 27-node box that a rank boundary crosses, so the preconditioner does not depend
+    # on the split and the one-rank driver on the same grid takes the same number of iterations; the wider 2D boxes are
+    # cut at the rank boundaries (each rank inverts its part), which costs a few iterations
+    prob1 = tmp_path / "p1.xml"
+    prob1.write_text(txt.replace('name="H/h" type="int" value="%d"' % hh, 'name="H/h" type="int" value="%d"' % (n * hh)))
+    x1, its1, rel1, _ = run_driver(driver, tmp_path, prob1, prec, sol)
+    assert (abs(its - its1) <= 2) if dim == 3 else (its1 - 2 <= its <= its1 + 12), (its, its1)
+    np.testing.assert_allclose(x, x1, rtol=0, atol=1e-9 * np.abs(xd).max())
+
+
 LINELAS_XML = os.path.join(ROOT, "tests", "golden", "linelas_xml")
 
 
