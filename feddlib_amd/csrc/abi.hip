@@ -138,6 +138,9 @@ extern "C" void fedd_ctx_destroy(fedd_ctx* c) {
         }
         for (auto& b : c->d_scan) b.release();
         if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+        if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+        if (c->stream2) (void)hipStreamDestroy(c->stream2);
         (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -683,6 +686,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
         c->gdsw_tol = value;
     } else if (k == "schwarz_dedupe") c->sw_dedupe = (int)value;
     else if (k == "apply_span") c->apply_span = (int)value;
+    else if (k == "halo_overlap") { c->halo_overlap = (int)value; c->have_schwarz = false; }
     else if (k == "schwarz_big") c->sw_big = (int)value;
     else if (k == "schwarz_big_target") c->sw_big_target = (int)value;
     else if (k == "asm_kind") c->asm_kind = (int)value;

@@ -214,6 +214,10 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_inv;                 // per subdomain [n_i][rp_i] column-major slab
     fedd::DevBuf<double> d_mult;                // [n_cols] multiplicity (averaging)
     bool have_schwarz = false;
+    int halo_overlap = 0;                       // several ranks: interior subdomains first, ghost import of r on a second stream meanwhile
+    hipStream_t stream2 = nullptr;              // (created on first use)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int64_t sw_nint = -1;                       // subdomains without ghost dofs at the front of d_sw_order (-1: not split)
     int apply_span = 0;                         // grouped apply: subdomains per workgroup (0 = 64)
     int sw_dedupe = 1;                          // option "schwarz_dedupe": subdomains with the same local matrix share one slab
     int64_t sw_nrep = 0;                        // distinct local matrices (= slabs) of the last setup

@@ -391,12 +391,29 @@ __global__ void k_iota(int32_t* __restrict__ v, int32_t n) {
     if (i < n) v[i] = i;
 }
 
+// subdomains that hold a dof of another rank (index >= n_owned in the column space) wait for the ghost import of r; the
+// others can be applied while it is in flight (option "halo_overlap"): sort key = representative, +2^30 for the former
+__global__ void k_order_key(const int32_t* __restrict__ sub_n, const int32_t* __restrict__ sub_dofs, const int32_t* __restrict__ rep,
+                            int32_t nsub, int32_t n_owned, int split, int32_t* __restrict__ key, int32_t* __restrict__ n_int) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nsub) return;
+    int32_t k = rep ? rep[b] : b;
+    if (split) {
+        bool ghost = false;
+        const int n = sub_n[b];
+        for (int i = 0; i < n; ++i) ghost |= sub_dofs[(int64_t)b * NMAX + i] >= n_owned;
+        if (ghost) k += 1 << 30;
+        else atomicAdd(n_int, 1);
+    }
+    key[b] = k;
+}
+
 __global__ void k_pack_order(const int32_t* __restrict__ ord, const int32_t* __restrict__ rep, const int32_t* __restrict__ sub_n,
                              const int32_t* __restrict__ sub_nown, int32_t n, int4* __restrict__ rec) {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t sidx = ord[i];
-    rec[i] = make_int4(sidx, rep[sidx], sub_n[sidx], sub_nown[sidx]);
+    rec[i] = make_int4(sidx, rep ? rep[sidx] : sidx, sub_n[sidx], sub_nown[sidx]);
 }
 
 __global__ void k_fp_share(const int32_t* __restrict__ rep, int32_t nsub, int64_t* __restrict__ inv_ptr) {
@@ -621,11 +638,12 @@ __global__ __launch_bounds__(256) void k_apply(const int32_t* __restrict__ sub_n
                                                const int32_t* __restrict__ sub_dofs,
                                                const int64_t* __restrict__ inv_ptr,
                                                const double* __restrict__ inv, const double* __restrict__ r,
-                                               double* __restrict__ z) {
+                                               double* __restrict__ z, const int4* __restrict__ perm, int32_t p0) {
     __shared__ double rsub[NMAX];
     __shared__ double part[256];
     __shared__ int32_t sdof[NMAX];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // perm: the workgroups walk places p0 ... of the setup's order records (interior-first split), else subdomain = workgroup
+    const int b = perm ? perm[p0 + (int32_t)blockIdx.x].x : (int)blockIdx.x, tid = threadIdx.x;
     const int n = sub_n[b];
     const int nrow = RESTRICTED ? sub_nown[b] : n;
     const int rp = slab_ld(nrow);
@@ -682,7 +700,7 @@ __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ 
                                                     const int32_t* __restrict__ sub_dofs,
                                                     const int64_t* __restrict__ inv_ptr,
                                                     const double* __restrict__ inv, const double* __restrict__ r,
-                                                    double* __restrict__ z, int span) {
+                                                    double* __restrict__ z, int span, const int4* __restrict__ perm, int32_t p0) {
     constexpr int PS = COMPACT ? 152 : 256;          // partial-sum slots
     __shared__ double shbuf[COMPACT ? 152 : NMAX + 256];
     double* const rsub = shbuf;
@@ -692,7 +710,8 @@ __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ 
     // bijective XCD remap (workgroups i and i + 8 share an XCD and its L2): XCD k takes a contiguous
     // eighth of the subdomains, so the part of r that neighbouring subdomains gather stays in one L2
     const int nb_ = gridDim.x, q_ = nb_ >> 3, rem_ = nb_ & 7, xcd_ = blockIdx.x & 7, within_ = blockIdx.x >> 3;
-    const int b = (xcd_ < rem_ ? xcd_ * (q_ + 1) : rem_ * (q_ + 1) + (xcd_ - rem_) * q_) + within_;
+    const int place = (xcd_ < rem_ ? xcd_ * (q_ + 1) : rem_ * (q_ + 1) + (xcd_ - rem_) * q_) + within_;
+    const int b = perm ? perm[p0 + place].x : place;      // (perm: places of the setup's order records, interior-first split)
     const int n = sub_n[b], nrow = sub_nown[b];
     const int total = n * nrow;
     const double* __restrict__ slab = inv + inv_ptr[b];
@@ -1193,28 +1212,46 @@ int schwarz_setup(fedd_ctx* c) {
         hipLaunchKernelGGL(k_fp_resolve, gs, blk, 0, c->stream, (const int32_t*)slot_of, (const int32_t*)tmin,
                            (const int32_t*)c->d_sub_n.p, (int32_t)nsub, rep, n_inv, n_rep);
         sub_n_inv = n_inv;
-        // the apply walks the subdomains sorted by representative (stable: lattice order within one)
-        {
-            FEDD_TRY(c->d_sw_order.ensure((size_t)(8 * nsub + 4)));
-            int32_t* ord = c->d_sw_order.p;
-            int32_t* keys_out = ord + nsub;
-            int32_t* iota = ord + 2 * nsub;
-            hipLaunchKernelGGL(k_iota, gs, blk, 0, c->stream, iota, (int32_t)nsub);
-            size_t tmp_bytes = 0;
-            FEDD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const int32_t*)rep, keys_out, (const int32_t*)iota, ord,
-                                                        (int)nsub, 0, 32, c->stream));
-            FEDD_TRY(c->d_dense_ws.ensure((tmp_bytes + sizeof(double) - 1) / sizeof(double)));
-            FEDD_HIP(hipcub::DeviceRadixSort::SortPairs((void*)c->d_dense_ws.p, tmp_bytes, (const int32_t*)rep, keys_out,
-                                                        (const int32_t*)iota, ord, (int)nsub, 0, 32, c->stream));
-            // records (subdomain, representative, columns, owned rows) in that order: one 16-byte load per place
-            hipLaunchKernelGGL(k_pack_order, gs, blk, 0, c->stream, (const int32_t*)ord, (const int32_t*)rep,
-                               (const int32_t*)c->d_sub_n.p, (const int32_t*)c->d_sub_nown.p, (int32_t)nsub, (int4*)(ord + 4 * nsub));
-            c->sw_order_off = 4 * (int64_t)nsub;
-        }
         int32_t h_nrep = 0;
         FEDD_HIP(hipMemcpyAsync(&h_nrep, n_rep, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         FEDD_HIP(hipStreamSynchronize(c->stream));
         c->sw_nrep = h_nrep;
+    }
+    // ---- the order the apply walks the subdomains in: sorted by representative (stable: lattice order within one); with
+    // several ranks and option "halo_overlap" the subdomains without ghost dofs first ----
+    c->sw_nint = -1;
+    {
+        const bool split = c->halo_overlap && restricted && (c->n_cols != c->n_rows || !c->halo.peers.empty());
+        if (c->sw_dedupe || split) {
+            const dim3 gs((unsigned)((nsub + 255) / 256));
+            const int32_t* rep = c->sw_dedupe ? c->d_sw_rep.p : nullptr;
+            FEDD_TRY(c->d_sw_order.ensure((size_t)(8 * nsub + 8)));
+            int32_t* ord = c->d_sw_order.p;
+            int32_t* keys_out = ord + nsub;
+            int32_t* iota = ord + 2 * nsub;
+            int32_t* keys_in = ord + 3 * nsub;      // (the records overwrite this part afterwards)
+            int32_t* n_int = ord + 8 * nsub + 4;
+            FEDD_HIP(hipMemsetAsync(n_int, 0, sizeof(int32_t), c->stream));
+            hipLaunchKernelGGL(k_iota, gs, blk, 0, c->stream, iota, (int32_t)nsub);
+            hipLaunchKernelGGL(k_order_key, gs, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p, (const int32_t*)c->d_sub_dofs.p, rep,
+                               (int32_t)nsub, (int32_t)n_rows, split ? 1 : 0, keys_in, n_int);
+            size_t tmp_bytes = 0;
+            FEDD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const int32_t*)keys_in, keys_out, (const int32_t*)iota, ord,
+                                                        (int)nsub, 0, 32, c->stream));
+            FEDD_TRY(c->d_dense_ws.ensure((tmp_bytes + sizeof(double) - 1) / sizeof(double)));
+            FEDD_HIP(hipcub::DeviceRadixSort::SortPairs((void*)c->d_dense_ws.p, tmp_bytes, (const int32_t*)keys_in, keys_out,
+                                                        (const int32_t*)iota, ord, (int)nsub, 0, 32, c->stream));
+            // records (subdomain, representative, columns, owned rows) in that order: one 16-byte load per place
+            hipLaunchKernelGGL(k_pack_order, gs, blk, 0, c->stream, (const int32_t*)ord, rep, (const int32_t*)c->d_sub_n.p,
+                               (const int32_t*)c->d_sub_nown.p, (int32_t)nsub, (int4*)(ord + 4 * nsub));
+            c->sw_order_off = 4 * (int64_t)nsub;
+            if (split) {
+                int32_t h = 0;
+                FEDD_HIP(hipMemcpyAsync(&h, n_int, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+                FEDD_HIP(hipStreamSynchronize(c->stream));
+                c->sw_nint = h;
+            }
+        }
     }
     // ---- slab offsets ----
     FEDD_TRY(c->d_inv_ptr.ensure((size_t)nsub + 1));
@@ -1303,61 +1340,98 @@ int schwarz_setup(fedd_ctx* c) {
 int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool r_has_tail) {
     if (c->sw_big_active) return schwarz_apply_big(c, d_r_owned, d_z_owned, r_has_tail);
     const double* r = d_r_owned;
-    if (c->n_cols != c->n_rows || !c->halo.peers.empty()) {   // also a rank that only sends takes part
+    const bool need_halo = c->n_cols != c->n_rows || !c->halo.peers.empty();   // also a rank that only sends takes part
+    // option "halo_overlap": the subdomains without ghost dofs (the first sw_nint places of the order records) are applied
+    // while the ghost entries of r travel on a second stream; the others follow when they have arrived
+    const bool overlap = need_halo && c->halo_overlap && c->sw_combine == FEDD_COMBINE_RESTRICTED && c->sw_nint > 0;
+    double* rbuf = nullptr;
+    if (need_halo) {
         if (r_has_tail) {   // the caller's buffer takes the ghost values behind its owned entries
-            FEDD_TRY(halo_import(c, const_cast<double*>(d_r_owned), c->dofs));
+            rbuf = const_cast<double*>(d_r_owned);
         } else {
             FEDD_HIP(hipMemcpyAsync(c->d_xcol.p, d_r_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-            FEDD_TRY(halo_import(c, c->d_xcol.p, c->dofs));
+            rbuf = c->d_xcol.p;
             r = c->d_xcol.p;
         }
+        if (!overlap) FEDD_TRY(halo_import(c, rbuf, c->dofs));
     }
-    const dim3 grid((unsigned)c->sw_nsub), blk(256);
+    const dim3 blk(256);
     if (c->sw_combine == FEDD_COMBINE_RESTRICTED) {
         // flat streaming kernel while the product park of the largest slab fits 48 KB of LDS
         const size_t park = (((size_t)c->sw_max_size * (size_t)c->sw_max_own + 1) & ~(size_t)1) * sizeof(double);
-        ScopedTimer t(c, FEDD_T_SCHWARZ_APPLY);
         // most subdomains share their inverse (schwarz_dedupe found few distinct local matrices): matrix-core kernel
         // (a few thousand subdomains: their slabs stay in the caches and the flat kernel's shorter dependency chain wins)
         const bool shared = c->sw_dedupe && c->sw_nrep * 4 <= c->sw_nsub && c->sw_max_own <= 96 && c->apply_kind != 2 && c->apply_kind != 1 &&
                             (c->sw_nsub >= 4096 || c->apply_kind == 4);
-        if (shared) {
-            // ranges of whole 64-place chunks (measured on the 214^3 grid, 389017 subdomains: 64: 195 us, 128: 187, 256: 191, 512: 233)
-            int span = c->apply_span > 0 ? c->apply_span : (c->sw_nsub >= 256 * 1024 ? 128 : 64);
-            span = std::max(64, (span + 63) / 64 * 64);
-            const int nwg = (int)((c->sw_nsub + span - 1) / span);
+        const int4* records = c->d_sw_order.p ? (const int4*)(c->d_sw_order.p + c->sw_order_off) : nullptr;
+        // places [p0, p0 + count) of the order records (all subdomains: p0 = 0, count = sw_nsub)
+        auto launch_range = [&](int64_t p0, int64_t count, bool permuted) {
+            if (count <= 0) return;
+            if (shared) {
+                // ranges of whole 64-place chunks (measured on the 214^3 grid, 389017 subdomains: 64: 195 us, 128: 187, 256: 191, 512: 233)
+                int span = c->apply_span > 0 ? c->apply_span : (count >= 256 * 1024 ? 128 : 64);
+                span = std::max(64, (span + 63) / 64 * 64);
+                const int nwg = (int)((count + span - 1) / span);
 #define APPLY_MFMA(RT, KW)                                                                                                   \
-    hipLaunchKernelGGL((k_apply_mfma<RT, KW>), dim3((unsigned)nwg), blk, 0, c->stream, (const int4*)(c->d_sw_order.p + c->sw_order_off),          \
+    hipLaunchKernelGGL((k_apply_mfma<RT, KW>), dim3((unsigned)nwg), blk, 0, c->stream, records + p0,                          \
                        (const int32_t*)c->d_sub_dofs.p, (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r,         \
-                       d_z_owned, (int32_t)c->sw_nsub, span)
-            const bool narrow = c->sw_max_size <= 160;
-            if (c->sw_max_own <= 32) {
-                if (narrow) APPLY_MFMA(2, 10);
-                else APPLY_MFMA(2, 16);
-            } else if (c->sw_max_own <= 64) {
-                if (narrow) APPLY_MFMA(4, 10);
-                else APPLY_MFMA(4, 16);
-            } else {
-                APPLY_MFMA(6, 16);
-            }
+                       d_z_owned, (int32_t)count, span)
+                const bool narrow = c->sw_max_size <= 160;
+                if (c->sw_max_own <= 32) {
+                    if (narrow) APPLY_MFMA(2, 10);
+                    else APPLY_MFMA(2, 16);
+                } else if (c->sw_max_own <= 64) {
+                    if (narrow) APPLY_MFMA(4, 10);
+                    else APPLY_MFMA(4, 16);
+                } else {
+                    APPLY_MFMA(6, 16);
+                }
 #undef APPLY_MFMA
-        } else
-        if ((c->apply_kind == 0 || c->apply_kind == 2) && park <= 48 * 1024)   // 2 = flat without the compact LDS layout (A/B)
-            if (c->sw_max_size <= 128 && c->apply_kind != 2)
-                hipLaunchKernelGGL(k_apply_flat<true>, grid, blk, park, c->stream, (const int32_t*)c->d_sub_n.p,
+                return;
+            }
+            const dim3 grid((unsigned)count);
+            const int4* perm = permuted ? records : nullptr;
+            if ((c->apply_kind == 0 || c->apply_kind == 2 || c->apply_kind == 4) && park <= 48 * 1024) {   // 2 = flat without the compact LDS layout (A/B)
+                if (c->sw_max_size <= 128 && c->apply_kind != 2)
+                    hipLaunchKernelGGL(k_apply_flat<true>, grid, blk, park, c->stream, (const int32_t*)c->d_sub_n.p,
+                                       (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
+                                       (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned,
+                                       (c->sw_max_size + 63) & ~63, perm, (int32_t)p0);
+                else
+                    hipLaunchKernelGGL(k_apply_flat<false>, grid, blk, park, c->stream, (const int32_t*)c->d_sub_n.p,
+                                       (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
+                                       (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned,
+                                       (c->sw_max_size + 63) & ~63, perm, (int32_t)p0);
+            } else {
+                hipLaunchKernelGGL(k_apply<true>, grid, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
                                    (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
-                                   (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned,
-                                   (c->sw_max_size + 63) & ~63);
-            else
-                hipLaunchKernelGGL(k_apply_flat<false>, grid, blk, park, c->stream, (const int32_t*)c->d_sub_n.p,
-                                   (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
-                                   (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned,
-                                   (c->sw_max_size + 63) & ~63);
-        else
-            hipLaunchKernelGGL(k_apply<true>, grid, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
-                               (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
-                               (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned);
-        t.stop();
+                                   (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned, perm, (int32_t)p0);
+            }
+        };
+        if (!overlap) {
+            ScopedTimer t(c, FEDD_T_SCHWARZ_APPLY);
+            launch_range(0, c->sw_nsub, false);
+            t.stop();
+        } else {
+            if (!c->stream2) {
+                FEDD_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+                FEDD_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                FEDD_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            hipStream_t main_stream = c->stream;
+            FEDD_HIP(hipEventRecord(c->ev_fork, main_stream));       // the owned part of r is complete here
+            FEDD_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            ScopedTimer t(c, FEDD_T_SCHWARZ_APPLY);                  // (includes whatever of the import stays exposed)
+            launch_range(0, c->sw_nint, true);
+            c->stream = c->stream2;                                  // the import -- pack, send / receive, unpack -- on stream 2
+            const int rc = halo_import(c, rbuf, c->dofs);
+            c->stream = main_stream;
+            if (rc) return rc;
+            FEDD_HIP(hipEventRecord(c->ev_join, c->stream2));
+            FEDD_HIP(hipStreamWaitEvent(main_stream, c->ev_join, 0));
+            launch_range(c->sw_nint, c->sw_nsub - c->sw_nint, true);
+            t.stop();
+        }
     } else {
         // Several ranks: what a rank's subdomains contribute to its ghost dofs is dropped (their rows
         // are not stored here, so those entries of the local solutions are not Schwarz corrections),
@@ -1366,9 +1440,9 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
         FEDD_HIP(hipMemsetAsync(z, 0, (size_t)c->n_cols * sizeof(double), c->stream));
         {
             ScopedTimer t(c, FEDD_T_SCHWARZ_APPLY);
-            hipLaunchKernelGGL(k_apply<false>, grid, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
+            hipLaunchKernelGGL(k_apply<false>, dim3((unsigned)c->sw_nsub), blk, 0, c->stream, (const int32_t*)c->d_sub_n.p,
                                (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
-                               (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, z);
+                               (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, z, (const int4*)nullptr, 0);
             t.stop();
         }
         if (c->sw_combine == FEDD_COMBINE_AVERAGING)

@@ -325,6 +325,9 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
  * threshold, FE_def.hpp:719-721), which changes y by less than the rounding error of the row sum;
  * "schwarz_dedupe" 1 (default) = subdomains with the same local matrix share one inverse (see fedd_schwarz_unique), 0 = every
  * subdomain is inverted and stored on its own;
+ * "halo_overlap" 1 = several ranks, restricted combine: the subdomains that hold no dof of another rank are applied while the
+ * ghost entries of r are imported on a second stream, the others after the import (same operator bit for bit); 0 (default) =
+ * import, then all subdomains.  An A/B switch for multi-GPU runs: on one GPU there is nothing to hide;
  * "whole_boxes" 1 (default) = with row ghosts, a box that a rank boundary crosses is built whole (with its full
  * overlap) on every rank that owns a part of it wherever the stored rows reach, 0 = each rank takes its part. */
 int fedd_set_option(fedd_ctx* ctx, const char* key, double value);

@@ -650,3 +650,65 @@ def test_rccl_call_shapes_on_one_rank(fedd_lib):
         assert c.rccl_selftest(100000) == 0.0
     finally:
         c.close()
+
+
+def _thread_rank_overlap(capi, group, rank, dec, M, out, errs):
+    try:
+        world = group.world
+        m = capi.structured_mesh(3, dec, [M] * 3, rank, ghosts=4)
+        c = capi.Context(device=0, rank=rank, nranks=world, nccl_id=None)
+        c.mesh_set_dict(m)
+        c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, [M] * 3, m["gid_rep"]))
+        c.comm_set_thread_group(group)
+        c.pattern_build(1, capi.BLOCK_SCALAR)
+        c.assemble(capi.FORM_LAPLACE)
+        c.assemble_rhs([1.0])
+        c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+        rg = np.random.default_rng(5).standard_normal(m["n_global"])
+        res = {}
+        for dedupe, kind in ((1, 4), (1, 0), (0, 0)):          # matrix-core kernel, flat kernel on shared slabs, flat kernel
+            for ov in (0, 1):
+                c.set_option("schwarz_dedupe", dedupe)
+                c.set_option("apply_kind", kind)
+                c.set_option("halo_overlap", ov)
+                c.schwarz_set_target(27, 1.0)
+                c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+                z = c.schwarz_apply(rg[m["gid_uni"]])
+                x, its, rel = c.gmres(None, rtol=1e-12, max_it=400, restart=100, use_prec=True)
+                res[(dedupe, kind, ov)] = (z, x, its)
+        out[rank] = dict(gu=m["gid_uni"], res=res)
+        c.close()
+    except Exception as e:      # pragma: no cover
+        import traceback
+        errs.append("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+        try:
+            group._barrier.abort()
+        except Exception:
+            pass
+
+
+def test_interior_first_order_with_the_ghost_import_on_a_second_stream(fedd_lib):
+    """Option halo_overlap: the subdomains without ghost dofs are applied while the ghost entries of r are imported on a
+    second stream, the others afterwards.  Every entry of z is still produced by one subdomain with the same arithmetic:
+    the operator is the same bit for bit, whichever apply kernel runs, and so are the GMRES iterates."""
+    import threading
+    dec, M = (1, 2, 2), 8
+    group = fedd_lib.ThreadGroup(4)
+    out, errs = [None] * 4, []
+    th = [threading.Thread(target=_thread_rank_overlap, args=(fedd_lib, group, r, dec, M, out, errs)) for r in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errs, "\n".join(errs)
+    for o in out:
+        assert o is not None
+        for dedupe, kind in ((1, 4), (1, 0), (0, 0)):
+            z0, x0, its0 = o["res"][(dedupe, kind, 0)]
+            z1, x1, its1 = o["res"][(dedupe, kind, 1)]
+            assert np.array_equal(z0, z1), (dedupe, kind)
+            assert its0 == its1 and np.array_equal(x0, x1), (dedupe, kind)
+        # ... and the three kernels agree with each other to rounding
+        za, zb = o["res"][(1, 4, 1)][0], o["res"][(0, 0, 1)][0]
+        np.testing.assert_allclose(za, zb, rtol=0, atol=1e-11 * np.abs(zb).max())
+

@@ -308,3 +308,33 @@ def test_mesh_set_rows_rejects_inconsistent_row_ghost_lists():
     with pytest.raises(capi.FeddError, match="not listed as a row ghost"):
         c.mesh_set(3, m["conn"], m["xyz"], m["gid_rep"], m["gid_uni"], m["flag_uni"], rg[1:], rf[1:])
     c.close()
+
+
+def test_facade_communicator_backends(tmp_path):
+    """The facade's two ways to be several ranks (Teuchos_shim.hpp): threads of one process, and launcher processes that
+    pass the RCCL id and a few scalars through files.  CPU only: broadcast, sums in rank order, gather, barrier, ring."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    assert gxx
+    exe = tmp_path / "comm_backends"
+    src = os.path.join(ROOT, "tests", "cpp", "comm_backends.cpp")
+    subprocess.run([gxx, "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "feddlib_amd", "host"), src, "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe), "--threads=5"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.count(" bad 0") == 5, r.stdout + r.stderr
+    rdv = tmp_path / "rdv"
+    rdv.mkdir()
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", FEDD_RENDEZVOUS=str(rdv))
+        procs.append(subprocess.Popen([str(exe)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for rank, o in enumerate(outs):
+        assert "rank %d of 3 bad 0" % rank in o, outs
+    assert len(list(rdv.iterdir())) <= 6            # the rendezvous files are recycled, not accumulated
+    # one rank needs no backend and no environment
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "FEDD_RANK", "FEDD_NRANKS")})
+    assert r.returncode == 0 and "rank 0 of 1 bad 0" in r.stdout
+
