@@ -634,7 +634,12 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
     // launch shape of k_multidot2: 2048 rows per workgroup, one grid row per group of 8 columns.
     // Measured alternatives on cfg 2 (ms per step): 1024 rows 43.9, column groups looped inside one
     // grid row 46.4 (2048 rows) / 44.5 (1024 rows), 2 or 4 grid rows 42.7-44.6; this one 43.1.
-    const int md2_gy = 1024, md2_nch = 4;
+    // grid rows of k_multidot2 = column groups in flight per row block: every workgroup reads its rows of u and B u once
+    // and keeps them across its column groups, so fewer grid rows = fewer re-reads of those two vectors (PMC: 1.24x the
+    // algorithmic bytes with one group per workgroup at 214^3); enough of them to fill the GPU when the vectors are short
+    const int md2_nch = 4;
+    const int64_t nblkd_ = (n + 512 * md2_nch - 1) / (512 * md2_nch);
+    const int md2_gy = c->md2_gy > 0 ? c->md2_gy : (int)std::max<int64_t>(1, (2048 + nblkd_ - 1) / nblkd_);
     const int nblkd = (int)((n + 512 * md2_nch - 1) / (512 * md2_nch));
     bool converged = false;
     while (!converged && its < max_it) {
