@@ -32,7 +32,7 @@ static int run(int argc, char* argv[]) {
     std::string xmlProblemFile = "parametersProblem.xml", xmlPrecFile = "parametersPrec.xml", xmlSolverFile = "parametersSolver.xml";
     std::string outFile = "solutionLaplace.txt";
     double length = 4.;
-    bool vL = false;
+    bool vL = false, userPrec = false;
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);
         auto val = [&](const char* key, std::string& dst) {
@@ -45,6 +45,7 @@ static int run(int argc, char* argv[]) {
         if (val("length", tmp)) { length = std::atof(tmp.c_str()); continue; }
         if (a == "--vectorLaplace") { vL = true; continue; }
         if (val("ranks-as-threads", tmp)) continue;     // handled by main
+        if (a == "--user-preconditioner") { userPrec = true; continue; }
         std::cerr << "unknown option " << a << std::endl;
         return 2;
     }
@@ -103,6 +104,15 @@ static int run(int argc, char* argv[]) {
             laplace.initializeProblem();
             laplace.assemble();
             laplace.setBoundaries();
+            if (userPrec) {
+                // the iterative solver stays on the host and gets the GPU's Schwarz preconditioner as
+                // a PreconditionerOperator (Problem::setPreconditionerThyraFromLinOp, Problem_def.hpp:397-399)
+                auto& fr = parameterListAll->sublist("ThyraPreconditioner").sublist("Preconditioner Types").sublist("FROSch");
+                std::string combine = fr.sublist("AlgebraicOverlappingOperator").get("Combine Values in Overlap", "Restricted");
+                Teuchos::RCP<PreconditionerOperator<SC, LO, GO, NO> > op(
+                    new DeviceSchwarzOperator<SC, LO, GO, NO>(domain->device(), fr.get("Overlap", 1), combine, fr.get("TwoLevel", false)));
+                laplace.setPreconditionerThyraFromLinOp(op);
+            }
             its = laplace.solve();
         }
         if (comm->getRank() == 0) std::cout << "iterations " << its << " relres " << laplace.getLastRelativeResidual() << std::endl;

@@ -824,6 +824,47 @@ private:
 template <class SC, class LO, class GO, class NO>
 class Problem;
 
+// PreconditionerOperator (feddlib/problems/Solver/PreconditionerOperator_decl.hpp:24-125): the reference's base class for a
+// preconditioner that the user hands to the iterative solver through Problem::setPreconditionerThyraFromLinOp
+// (Problem_def.hpp:397-399, Preconditioner_def.hpp:96-102) -- there a Thyra::LinearOpBase with a pure applyImpl, here the
+// same contract on the facade's MultiVector:  Y = alpha * M^-1 X + beta * Y  on the entries of the unique map.
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class PreconditionerOperator {
+public:
+    typedef MultiVector<SC, LO, GO, NO> MultiVector_Type;
+    virtual ~PreconditionerOperator() {}
+    void apply(const MultiVector_Type& X, MultiVector_Type& Y, SC alpha = 1., SC beta = 0.) const { applyImpl(X, Y, alpha, beta); }
+    virtual std::string description() const { return "FEDD::PreconditionerOperator"; }
+protected:
+    virtual void applyImpl(const MultiVector_Type& X, MultiVector_Type& Y, const SC alpha, const SC beta) const = 0;
+};
+
+// the library's Schwarz preconditioner behind that interface.  Every application crosses the host
+// boundary (fedd_schwarz_apply takes and returns host vectors); the resident path is LinearSolver's default.
+template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
+class DeviceSchwarzOperator : public PreconditionerOperator<SC, LO, GO, NO> {
+public:
+    typedef MultiVector<SC, LO, GO, NO> MultiVector_Type;
+    // the matrix resident in `dev` must be final (assembled, boundary conditions set); parameters as in parametersPrec.xml
+    DeviceSchwarzOperator(const DeviceContextPtr& dev, int overlap = 1, const std::string& combine = "Restricted", bool twoLevel = false,
+                          int coarseKind = FEDD_COARSE_GDSW)
+        : dev_(dev) {
+        const int cmb = combine == "Averaging" ? FEDD_COMBINE_AVERAGING : (combine == "Full" ? FEDD_COMBINE_FULL : FEDD_COMBINE_RESTRICTED);
+        feddCheck(fedd_schwarz_setup(dev_->ctx, overlap, cmb, twoLevel ? 1 : 0, twoLevel ? coarseKind : 0), "fedd_schwarz_setup");
+    }
+    std::string description() const override { return "FEDD::DeviceSchwarzOperator (overlapping Schwarz on the GPU)"; }
+protected:
+    void applyImpl(const MultiVector_Type& X, MultiVector_Type& Y, const SC alpha, const SC beta) const override {
+        z_.resize(X.raw().size());
+        feddCheck(fedd_schwarz_apply(dev_->ctx, X.raw().data(), z_.data()), "fedd_schwarz_apply");
+        auto& y = Y.raw();
+        for (size_t i = 0; i < y.size(); ++i) y[i] = alpha * z_[i] + (beta == 0. ? 0. : beta * y[i]);
+    }
+private:
+    DeviceContextPtr dev_;
+    mutable std::vector<SC> z_;
+};
+
 // LinearSolver::solve -> solveMonolithic (LinearSolver_def.hpp:23-135): GMRES + one-level Schwarz on
 // the device, configured from the same ParameterList entries the reference hands to Stratimikos.
 template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
@@ -834,6 +875,87 @@ public:
     typedef Teuchos::RCP<BlockMultiVector_Type> BlockMultiVectorPtr_Type;
     int solve(Problem_Type* problem, BlockMultiVectorPtr_Type rhs, std::string type = "Monolithic");
     double lastRelativeResidual = 0.;
+private:
+    typedef MultiVector<SC, LO, GO, NO> MV;
+    static double dot(const MV& a, const MV& b) {
+        double s = 0.;
+        const auto& x = a.raw();
+        const auto& y = b.raw();
+        for (size_t i = 0; i < x.size(); ++i) s += x[i] * y[i];
+        if (!a.getMap()->getComm().is_null()) a.getMap()->getComm()->sumAll(&s, 1);
+        return s;
+    }
+    static int hostGmres(Matrix<SC, LO, GO, NO>& A, const PreconditionerOperator<SC, LO, GO, NO>& M, const MV& b, MV& x, double tol,
+                         int maxIt, int m, double& rel) {
+        auto map = b.getMap();
+        const double bnorm = b.norm2();
+        x.putScalar(0.);
+        rel = 0.;
+        if (bnorm == 0.) return 0;
+        MV r(map), z(map), w(map);
+        r.update(1., b, 0.);
+        double beta = bnorm;
+        int its = 0;
+        while (its < maxIt) {
+            std::vector<MV> V;
+            V.reserve((size_t)m + 1);
+            V.emplace_back(map);
+            V[0].update(1. / beta, r, 0.);
+            std::vector<std::vector<double>> H((size_t)m, std::vector<double>((size_t)m + 1, 0.));
+            std::vector<double> cs((size_t)m, 0.), sn((size_t)m, 0.), g((size_t)m + 1, 0.);
+            g[0] = beta;
+            int k = 0;
+            for (; k < m && its < maxIt; ++k) {
+                M.apply(V[k], z);
+                A.apply(z, w);
+                for (int pass = 0; pass < 2; ++pass) {       // classical Gram-Schmidt, twice
+                    std::vector<double> h((size_t)k + 1);
+                    for (int i = 0; i <= k; ++i) h[i] = dot(V[i], w);
+                    for (int i = 0; i <= k; ++i) {
+                        w.update(-h[i], V[i], 1.);
+                        H[k][i] += h[i];
+                    }
+                }
+                const double hn = w.norm2();
+                H[k][k + 1] = hn;
+                for (int i = 0; i < k; ++i) {
+                    const double t = cs[i] * H[k][i] + sn[i] * H[k][i + 1];
+                    H[k][i + 1] = -sn[i] * H[k][i] + cs[i] * H[k][i + 1];
+                    H[k][i] = t;
+                }
+                const double d = std::hypot(H[k][k], H[k][k + 1]);
+                cs[k] = H[k][k] / d;
+                sn[k] = H[k][k + 1] / d;
+                H[k][k] = d;
+                H[k][k + 1] = 0.;
+                g[k + 1] = -sn[k] * g[k];
+                g[k] = cs[k] * g[k];
+                ++its;
+                rel = std::fabs(g[k + 1]) / bnorm;
+                if (rel <= tol || hn == 0.) { ++k; break; }
+                V.emplace_back(map);
+                V[k + 1].update(1. / hn, w, 0.);
+            }
+            std::vector<double> y((size_t)k, 0.);
+            for (int i = k - 1; i >= 0; --i) {
+                double sum = g[i];
+                for (int j = i + 1; j < k; ++j) sum -= H[j][i] * y[j];
+                y[i] = sum / H[i][i];
+            }
+            w.putScalar(0.);
+            for (int i = 0; i < k; ++i) w.update(y[i], V[i], 1.);
+            M.apply(w, z);
+            x.update(1., z, 1.);
+            if (rel <= tol) break;
+            A.apply(x, w);
+            r.update(1., b, 0.);
+            r.update(-1., w, 1.);
+            beta = r.norm2();
+            rel = beta / bnorm;
+            if (rel <= tol) break;
+        }
+        return its;
+    }
 };
 
 template <class SC = default_sc, class LO = default_lo, class GO = default_go, class NO = default_no>
@@ -904,6 +1026,11 @@ public:
         if (verbose_) std::cout << " done. -- " << its << " iterations, relative residual " << lastRelativeResidual_ << std::endl;
         return its;
     }
+    // Problem::setPreconditionerThyraFromLinOp (Problem_def.hpp:397-399): a user-supplied preconditioner; the solve then
+    // runs the host-side GMRES below (the stand-in for Belos in this build) on Matrix::apply and this operator
+    typedef PreconditionerOperator<SC, LO, GO, NO> PrecOp_Type;
+    void setPreconditionerThyraFromLinOp(const Teuchos::RCP<PrecOp_Type>& op) { userPrec_ = op; }
+    Teuchos::RCP<PrecOp_Type> getUserPreconditioner() const { return userPrec_; }
     void addBoundaries(const BCConstPtr_Type& bcFactory) { bcFactory_ = bcFactory; }
     void setBoundaries(double time = .0) const {                      // Problem_def.hpp:298-304
         TEUCHOS_TEST_FOR_EXCEPTION(bcFactory_.is_null(), std::runtime_error, "No boundary conditions added.");
@@ -957,6 +1084,7 @@ protected:
     std::vector<RhsFunc_Type> rhsFuncVec_;
     vec_dbl_Type parasSourceFunc_;
     double lastRelativeResidual_ = 0.;
+    Teuchos::RCP<PrecOp_Type> userPrec_;
 };
 
 template <class SC, class LO, class GO, class NO>
@@ -1009,6 +1137,16 @@ int LinearSolver<SC, LO, GO, NO>::solve(Problem_Type* problem, BlockMultiVectorP
     auto x = problem->getSolution();
     int its = 0;
     double rel = 0.;
+    if (!problem->getUserPreconditioner().is_null()) {
+        // INTEGRATION.md 3(b), "keep the iterative solver, plug in operator and preconditioner": right-preconditioned
+        // GMRES(m) on the host -- what Belos' Block GMRES does with Thyra operators (LinearSolver_def.hpp:72-135), two-pass
+        // classical Gram-Schmidt like its ICGS manager -- with A = Matrix::apply (fedd_spmv) and M^-1 = the user's operator
+        TEUCHOS_TEST_FOR_EXCEPTION(blocks, std::logic_error, "user preconditioner operators: single-block systems in this build");
+        its = hostGmres(*system->getBlock(0, 0), *problem->getUserPreconditioner(), *b->getBlock(0), *x->getBlockNonConst(0), tol, maxIt,
+                        numBlocks, rel);
+        lastRelativeResidual = rel;
+        return its;
+    }
     if (!blocks) {
         feddCheck(fedd_gmres(ctx, b->getBlock(0)->raw().data(), x->getBlockNonConst(0)->raw().data(), tol, maxIt, numBlocks,
                              usePrec ? 1 : 0, &its, &rel), "fedd_gmres");

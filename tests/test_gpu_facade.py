@@ -79,6 +79,38 @@ def test_3d_tight_tolerance_matches_oracle(driver, tmp_path):
     assert rel <= 1e-13
 
 
+def test_user_preconditioner_operator_path(driver, tmp_path):
+    """the iterative solver stays outside the library (here the facade's host GMRES, the stand-in for
+    Belos) and takes the GPU's Schwarz preconditioner as a PreconditionerOperator through
+    Problem::setPreconditionerThyraFromLinOp, the matrix as Matrix::apply (fedd_spmv).  Same Krylov method, same
+    operator: the iteration count and the solution agree with the resident path."""
+    prob = tmp_path / "p.xml"
+    prob.write_text(open(os.path.join(XML, "parametersProblem.xml")).read()
+                    .replace('name="Dimension" type="int" value="2"', 'name="Dimension" type="int" value="3"')
+                    .replace('name="H/h" type="int" value="10"', 'name="H/h" type="int" value="8"'))
+    sol = tmp_path / "s.xml"
+    sol.write_text(open(os.path.join(XML, "parametersSolver.xml")).read()
+                   .replace('value="1e-8"', 'value="1e-12"').replace('"Maximum Iterations" type="int" value="100"',
+                                                                     '"Maximum Iterations" type="int" value="400"'))
+    prec = tmp_path / "c.xml"
+    prec.write_text(open(os.path.join(XML, "parametersPrec.xml")).read()
+                    .replace('name="Combine Values in Overlap" type="string" value="Averaging"',
+                             'name="Combine Values in Overlap" type="string" value="Restricted"'))
+    x0, its0, rel0, _ = run_driver(driver, tmp_path, prob, prec, sol)
+    out = tmp_path / "solb.txt"
+    r = subprocess.run([driver, "--problemfile=%s" % prob, "--precfile=%s" % prec, "--solverfile=%s" % sol, "--out=%s" % out,
+                        "--user-preconditioner"], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    mt = re.search(r"iterations (\d+) relres (\S+)", r.stdout)
+    assert mt, r.stdout
+    its, rel = int(mt.group(1)), float(mt.group(2))
+    part = np.loadtxt(out)
+    x = np.zeros(x0.shape[0])
+    x[part[:, 0].astype(int)] = part[:, 1]
+    assert rel <= 1e-12 and abs(its - its0) <= 1, (its, its0)
+    np.testing.assert_allclose(x, x0, rtol=0, atol=1e-10 * np.abs(x0).max())
+
+
 @pytest.mark.parametrize("dim,ranks,hh", [(3, 8, 5), (2, 4, 12)])
 def test_driver_on_several_ranks(driver, tmp_path, dim, ranks, hh):
     """The reference runs this driver as `mpirun -np N` with one rank per subdomain block (laplace/main.cpp:75-109).  Here
