@@ -189,10 +189,12 @@ __global__ __launch_bounds__(256) void k_sub_dofs(const int32_t* __restrict__ bi
         for (int layer = 0; layer < overlap; ++layer) {
             // sources: the box (layer 0) or everything collected so far (later layers)
             const int nsrc = layer == 0 ? n_own + nf : s_prev;
-            for (int k = tid; k < nsrc; k += 256) {
+            // 16 lanes per source row: consecutive lanes read consecutive entries of its CSR row
+            for (int k = tid >> 4; k < nsrc; k += 16) {
                 const int32_t src = layer == 0 ? (k < n_own ? bin_nodes[nb + k] : fbin_nodes[fb + k - n_own]) : lst[k];
                 if (src >= n_stored) continue;
-                for (int32_t p = rowptr[src]; p < rowptr[src + 1]; ++p) {
+                const int32_t p_end = rowptr[src + 1];
+                for (int32_t p = rowptr[src] + (tid & 15); p < p_end; p += 16) {
                     const int32_t col = colind[p];
                     if (col < n_rows && node_bin[col] == b) continue;
                     if (!ghost_overlap && col >= n_rows) continue;  // another rank's dof: its row is not stored here
@@ -260,11 +262,16 @@ __device__ __forceinline__ int bsearch_i32(const int32_t* a, int n, int32_t v);
 // L2 instead of streaming 8 GB (k_apply_mfma below): the one-level step at 214^3 cells drops from 564 to 341 ms.
 __global__ void k_row_absmax(const int32_t* __restrict__ rowptr, const double* __restrict__ val, int32_t n_rows,
                              double* __restrict__ rmax) {
-    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
+    // 16 lanes per row: consecutive lanes read consecutive entries (a lane per row made every load touch 64 lines)
+    const int32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int e = threadIdx.x & 15;
     double m = 0.0;
-    for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) m = fmax(m, fabs(val[p]));
-    rmax[r] = m;
+    if (r < n_rows) {
+        const int32_t p_end = rowptr[r + 1];
+        for (int32_t p = rowptr[r] + e; p < p_end; p += 16) m = fmax(m, fabs(val[p]));
+    }
+    for (int off = 8; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 16));
+    if (r < n_rows && e == 0) rmax[r] = m;
 }
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
@@ -276,35 +283,54 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-// one wave per subdomain: lanes over the local rows, each walks its CSR row
+// one wave per subdomain: 16 lanes per local row (four rows at a time), the lanes of a group read consecutive entries of the
+// CSR row (with a lane per row every load instruction touched 64 different cache lines: address-bound, 10.7 ms at cfg 3)
 template <int NM>
 __global__ __launch_bounds__(64) void k_sub_fingerprint(const int32_t* __restrict__ sub_n, const int32_t* __restrict__ sub_nown,
                                                         const int32_t* __restrict__ sub_dofs, const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ colind, const double* __restrict__ val,
                                                         const double* __restrict__ rmax, int32_t n_stored, int32_t p_off,
                                                         uint64_t* __restrict__ fp) {
+    // global dof -> local index through a small open-addressing table in LDS (one or two probes per matrix entry; the two
+    // binary searches of the first version -- 14 dependent LDS reads per entry -- were most of the kernel's 10.7 ms at cfg 3)
+    constexpr int HS = 2 * NM;
     __shared__ int32_t sdof[NM];
+    __shared__ int32_t hkey[HS], hval[HS];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = sub_n[b], no = sub_nown[b];
+    for (int k = lane; k < HS; k += 64) hkey[k] = -1;
     for (int k = lane; k < n; k += 64) sdof[k] = sub_dofs[(int64_t)b * NM + k];
     __syncthreads();
+    for (int k = lane; k < n; k += 64) {
+        const int32_t g = sdof[k];
+        unsigned slot = ((unsigned)g * 2654435761u) >> (32 - 9);
+        static_assert(HS == 512, "hash shift assumes 512 slots");
+        while (atomicCAS(&hkey[slot], -1, g) != -1) slot = (slot + 1) & (HS - 1);   // (dofs of a subdomain are distinct)
+        hval[slot] = k;
+    }
+    __syncthreads();
     uint64_t h1 = 0, h2 = 0;
-    for (int i = lane; i < n; i += 64) {
+    const int grp = lane >> 4, e = lane & 15;
+    for (int i = grp; i < n; i += 4) {
         const int32_t g = sdof[i];
         if (g >= n_stored) {   // ghost row without a stored row: identity
-            h1 += mix64(((uint64_t)i << 32) ^ 0x9e3779b97f4a7c15ull);
-            h2 += mix64(((uint64_t)i << 20) ^ 0xd1b54a32d192ed03ull);
+            if (e == 0) {
+                h1 += mix64(((uint64_t)i << 32) ^ 0x9e3779b97f4a7c15ull);
+                h2 += mix64(((uint64_t)i << 20) ^ 0xd1b54a32d192ed03ull);
+            }
             continue;
         }
         const double scale = rmax[g] > 0.0 ? 17592186044416.0 / rmax[g] : 0.0;   // 2^44 / row max
         // pressure rows of a merged system are pivoted after the velocities: part of the matrix' identity
         const uint64_t tag = g >= p_off ? 0x5851f42d4c957f2dull : 0ull;
-        for (int32_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
+        const int32_t p_end = rowptr[g + 1];
+        for (int32_t p = rowptr[g] + e; p < p_end; p += 16) {
             const int32_t col = colind[p];
-            int cidx = bsearch_i32(sdof, no, col);
-            if (cidx < 0) {
-                cidx = bsearch_i32(sdof + no, n - no, col);
-                if (cidx >= 0) cidx += no;
+            int cidx = -1;
+            for (unsigned slot = ((unsigned)col * 2654435761u) >> (32 - 9);; slot = (slot + 1) & (HS - 1)) {
+                const int32_t kk = hkey[slot];
+                if (kk == col) cidx = hval[slot];
+                if (kk == col || kk == -1) break;
             }
             if (cidx < 0) continue;
             const int64_t q = (int64_t)llrint(val[p] * scale);
@@ -1190,7 +1216,7 @@ int schwarz_setup(fedd_ctx* c) {
     if (c->sw_dedupe) {
         const dim3 gs((unsigned)((nsub + 255) / 256));
         FEDD_TRY(c->d_sw_rmax.ensure((size_t)n_stored));
-        hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)((n_stored + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_rowptr.p,
+        hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)((n_stored + 15) / 16)), blk, 0, c->stream, (const int32_t*)c->d_rowptr.p,
                            (const double*)c->d_val.p, n_stored, c->d_sw_rmax.p);
         const int64_t tsize = 2 * nsub + 64;
         FEDD_TRY(c->d_sw_fp.ensure((size_t)(2 * nsub + 2 * tsize)));
