@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -49,7 +50,9 @@ def parse():
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--restart", type=int, default=100)
     ap.add_argument("--max-it", type=int, default=2000)
-    ap.add_argument("--target", type=int, default=27, help="nodes per Schwarz subdomain")
+    # 64-node boxes: the fastest one-level decomposition on this grid since the local inverses are shared
+    # (profiles/r02_one_level_sweep_214_shared.txt: 248 ms against 312 ms for 27-node boxes; 145 against 178 iterations)
+    ap.add_argument("--target", type=int, default=64, help="nodes per Schwarz subdomain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-level", action="store_true", help="skip the extra two-level measurement")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
@@ -83,12 +86,12 @@ def _cycle_cols(its, restart):
     return full * restart * (restart + 1) // 2 + rest * (rest + 1) // 2
 
 
-def _recorded_full_cpu_run(full_cells):
+def _recorded_full_cpu_run(full_cells, target):
     """the full-grid CPU run of this round (bench.py --cpu-full on a GPU box, committed as profiles/cpu_full.json): the
     measured partner of the extrapolated figure, quoted when it is of the same grid"""
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "cpu_full.json")))
-        if pj.get("cells") == full_cells:
+        if pj.get("cells") == full_cells and pj.get("target", 27) == target:
             cb = pj["cpu_baseline"]
             return {"value": cb["value"], "seconds": cb["seconds"], "cores": cb["cores"], "sample": cb["sample"],
                     "source": "profiles/cpu_full.json (" + pj.get("command", "") + ")"}
@@ -140,7 +143,7 @@ def cpu_baseline(a, full_cells, gpu_its, full=False):
                       "recorded under profiles/ (bench.py --cpu-full)"
                       % (M, r["dofs"], desc, r["seconds"], r["dofs"] / r["seconds"], full_cells, scale, gpu_its, r["its"],
                          cols_f, cols_s, a.restart, t_full, a.target),
-            "seconds": t_full, "extrapolated": True, "full_grid_measured": _recorded_full_cpu_run(full_cells),
+            "seconds": t_full, "extrapolated": True, "full_grid_measured": _recorded_full_cpu_run(full_cells, a.target),
             "sample_measured": {"cells": M, "dofs": r["dofs"], "seconds": r["seconds"], "value": r["dofs"] / r["seconds"],
                                 "gmres_iterations": r["its"]}}
 
@@ -291,10 +294,12 @@ def main():
         return {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kern.items()}
 
     t0 = time.perf_counter()
-    # N > 1: four ghost-element layers, so that the rows of the ghost nodes within three layers are complete on
-    # the rank (fedd_mesh_set_rows): every Schwarz box that a rank boundary crosses (3 node planes + 1 of overlap)
-    # is then built whole on both sides and the preconditioner is the one-rank preconditioner at any N
-    m = capi.structured_mesh(3, dec, cells, rank, size=dom, ghosts=4 if N > 1 else 0)
+    # N > 1: as many ghost-element layers as a Schwarz box is wide plus one of overlap (27-node boxes: 3 + 1, 64-node
+    # boxes: 4 + 1), so that the rows of the ghost nodes within one layer less are complete on the rank
+    # (fedd_mesh_set_rows): every box that a rank boundary crosses is then built whole on both sides and the
+    # preconditioner is the one-rank preconditioner at any N
+    ghost_layers = int(math.ceil(round(a.target ** (1.0 / 3.0), 6))) + 1
+    m = capi.structured_mesh(3, dec, cells, rank, size=dom, ghosts=ghost_layers if N > 1 else 0)
     t_mesh = time.perf_counter() - t0
     c = capi.Context(device=dev, rank=rank, nranks=N, nccl_id=nccl_id)
     for kv in filter(None, os.environ.get("FEDD_OPTIONS", "").split(",")):   # development: key=value,...

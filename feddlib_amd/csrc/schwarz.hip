@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ 
 typedef double ap_d4 __attribute__((ext_vector_type(4)));
 constexpr int AM_MB = 16;
 template <int RT, int KW>   // owned rows <= 16 RT, columns <= 16 KW
-__global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : 1) void k_apply_mfma(const int4* __restrict__ order, const int32_t* __restrict__ sub_dofs,
+__global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <= 12) ? 2 : 1)) void k_apply_mfma(const int4* __restrict__ order, const int32_t* __restrict__ sub_dofs,
                                                     const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
                                                     const double* __restrict__ r, double* __restrict__ z, int32_t nsub, int span) {
     constexpr int S = 16 * KW + 2;              // row stride of the id lists in LDS: fragment reads hit 32 distinct banks
@@ -1402,12 +1402,14 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
     hipLaunchKernelGGL((k_apply_mfma<RT, KW>), dim3((unsigned)nwg), blk, 0, c->stream, records + p0,                          \
                        (const int32_t*)c->d_sub_dofs.p, (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r,         \
                        d_z_owned, (int32_t)count, span)
-                const bool narrow = c->sw_max_size <= 160;
+                // (row tiles, column steps per wave) by the largest subdomain: fewer steps = fewer registers = more waves
+                const int64_t mx = c->sw_max_size;
                 if (c->sw_max_own <= 32) {
-                    if (narrow) APPLY_MFMA(2, 10);
+                    if (mx <= 160) APPLY_MFMA(2, 10);
                     else APPLY_MFMA(2, 16);
                 } else if (c->sw_max_own <= 64) {
-                    if (narrow) APPLY_MFMA(4, 10);
+                    if (mx <= 160) APPLY_MFMA(4, 10);
+                    else if (mx <= 192) APPLY_MFMA(4, 12);
                     else APPLY_MFMA(4, 16);
                 } else {
                     APPLY_MFMA(6, 16);

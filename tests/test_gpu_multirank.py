@@ -397,6 +397,8 @@ def test_row_ghosts_make_the_two_rank_schwarz_apply_equal_to_the_one_rank_apply(
 
 @pytest.mark.parametrize("G,dec,target,layers,problem", [(12, (2, 2, 2), 27, 4, "laplace"), (16, (1, 2, 2), 27, 4, "laplace"),
                                                          (12, (2, 2, 2), 8, 3, "laplace"), (30, (3, 2), 16, 5, "laplace"),
+                                                         (24, (2, 2, 2), 64, 5, "laplace"),       # bench.py's boxes: 4 planes + 1
+
                                                          (8, (1, 2, 2), 0, 4, "linelas")])
 def test_whole_boxes_make_the_preconditioner_independent_of_the_number_of_ranks(fedd_lib, G, dec, target, layers, problem):
     """With enough ghost layers (boxes of 3 node planes + 1 of overlap: 4 element layers; 2-plane boxes: 3) every

@@ -1,5 +1,5 @@
 """One-level Schwarz on the headline grid: overlap x box size against ms per assemble + solve step.
-usage: sweep_one_level.py [cells per direction] ; writes one line per configuration"""
+usage: sweep_one_level.py [cells per direction] [overlap:box:big,...] ; writes one line per configuration"""
 import os
 import sys
 import time
@@ -28,7 +28,10 @@ def step(overlap, target, big):
     return c.gmres(None, rtol=1e-8, max_it=2000, restart=100, use_prec=True, want_x=False)
 
 
-for overlap, target, big in ((1, 27, 0), (1, 8, 0), (1, 64, 0), (2, 8, 0), (2, 27, 0), (1, 125, 1), (1, 343, 1), (2, 125, 1)):
+CONFIGS = ((1, 27, 0), (1, 8, 0), (1, 64, 0), (2, 8, 0), (2, 27, 0), (1, 125, 1), (1, 343, 1), (2, 125, 1))
+if len(sys.argv) > 2:       # "overlap:box:big,..." picks other configurations
+    CONFIGS = tuple(tuple(int(v) for v in t.split(":")) for t in sys.argv[2].split(","))
+for overlap, target, big in CONFIGS:
     try:
         step(overlap, target, big)                  # warm-up (allocations)
         c.sync()
