@@ -22,10 +22,14 @@ z0 = None
 c.timing_enable(True)
 for rep in range(2):
     for cfg in configs:
+        target = 27
         for kv in cfg.split(","):
             k, v = kv.split("=")
-            c.set_option(k, float(v))
-        c.schwarz_set_target(27, 1.0)
+            if k == "target":       # (not a library option: nodes per box)
+                target = int(v)
+            else:
+                c.set_option(k, float(v))
+        c.schwarz_set_target(target, 1.0)
         c.timing_reset()
         c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
         c.sync()
