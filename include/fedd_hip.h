@@ -308,8 +308,12 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
 /* tuning knobs (A/B tests), 0 is the default of each: "spmv_kind" 0 = CSR-window (CSR-stream when a row has more than 256 entries), 1 = row-per-lane-group, 2 = CSR-stream;
  * "asm_kind" 0 = pair-parallel assembly (slot-addressed accumulation for the block forms -- elasticity, B / B^T --, slot sweep for
  * the scalar forms), 1 = lane-per-row gather, 2 = slot sweep always, 3 = slot-addressed always; "asm_u" pairs per lane whose
- * loads are in flight together in the slot-addressed kernel (P1; default 1); "asm_dbg" ablation switches (development); "apply_kind" 0 = flat streaming Schwarz
- * apply, 1 = strided, 2 = flat without the compact LDS layout; "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
+ * loads are in flight together in the slot-addressed kernel (P1; default 1); "asm_dbg" ablation switches (development); "apply_kind" 0 = restricted Schwarz
+ * apply by the setup's outcome (batched matrix-core kernel when at most a quarter of at least 4096 subdomains have distinct
+ * local matrices, else the flat streaming kernel), 1 = strided, 2 = flat without the compact LDS layout, 4 = matrix-core
+ * kernel whenever the inverses are shared (any number of subdomains); "apply_span" places per workgroup of that kernel
+ * (multiples of 64; 0 = 64 / 128 by the number of subdomains); "md2_gy" column groups in flight per row block of the
+ * Gram-Schmidt dot sweep (0 = by vector length); "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
  * matrix cores, 2 = scalar-pivot without dropping rows;
  * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes;
  * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank;

@@ -1,5 +1,5 @@
 """Tolerance of GDSW's interior extension solves against setup time and outer iteration count (cfg 5's share: 3D P1 linear
-elasticity, steadyLinElas_Perf parameters).  usage: gdsw_tol_sweep.py [cells] [kind 2=GDSW 3=RGDSW] [tol,tol,...]"""
+elasticity, steadyLinElas_Perf parameters).  usage: gdsw_tol_sweep.py [cells] [kind 2=GDSW 3=RGDSW] [tol,tol,...] [coarse cells]"""
 import os
 import sys
 import time
@@ -10,6 +10,7 @@ from feddlib_amd import capi  # noqa: E402
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 tols = [float(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1e-10, 1e-6, 1e-4, 1e-3]
+cells = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0        # coarse lattice cells (0 = library default)
 m = capi.structured_mesh(3, 1, M)
 c = capi.Context(device=0)
 c.mesh_set_dict(m)
@@ -23,6 +24,7 @@ c.schwarz_set_target(8, 1.0)
 c.timing_enable(True)
 for tol in tols:
     c.set_option("gdsw_tol", tol)
+    c.schwarz_set_coarse(cells)
     c.timing_reset()
     c.sync()
     t0 = time.perf_counter()
