@@ -13,6 +13,7 @@
 #include "feddlib/core/FE/Domain.hpp"
 #include "feddlib/core/General/BCBuilder.hpp"
 #include "feddlib/core/General/ExporterParaView.hpp"
+#include "feddlib/core/Mesh/MeshPartitioner.hpp"
 #include "feddlib/problems/specific/Laplace.hpp"
 
 void zeroBC(double* x, double* res, double t, const double* parameters) { res[0] = 0.; }
@@ -67,9 +68,19 @@ static int run(int argc, char* argv[]) {
         int size = comm->getSize() - numProcsCoarseSolve;
 
         Teuchos::RCP<Domain<SC, LO, GO, NO> > domain;
-        TEUCHOS_TEST_FOR_EXCEPTION(meshType != "structured", std::logic_error, "this driver builds structured meshes");
+        TEUCHOS_TEST_FOR_EXCEPTION(meshType != "structured" && meshType != "unstructured", std::logic_error,
+                                   "this driver builds 'structured' meshes and reads 'unstructured' ones");
         int n;
-        if (dim == 2) {
+        if (meshType == "unstructured") {       // laplace/main.cpp:155-175: read, partition over the ranks, P1
+            Teuchos::RCP<Domain<SC, LO, GO, NO> > domainP1(new Domain<SC, LO, GO, NO>(comm, dim));
+            MeshPartitioner<SC, LO, GO, NO>::DomainPtrArray_Type domainP1Array(1);
+            domainP1Array[0] = domainP1;
+            ParameterListPtr_Type pListPartitioner(new Teuchos::ParameterList(parameterListAll->sublist("Mesh Partitioner")));
+            MeshPartitioner<SC, LO, GO, NO> partitionerP1(domainP1Array, pListPartitioner, "P1", dim);
+            partitionerP1.readAndPartition();
+            TEUCHOS_TEST_FOR_EXCEPTION(FEType != "P1", std::logic_error, "unstructured meshes: P1 in this driver");
+            domain = domainP1;
+        } else if (dim == 2) {
             n = (int)(std::pow(size, 1 / 2.) + 100. * 2.220446049250313e-16);
             std::vector<double> x(2);
             x[0] = 0.0; x[1] = 0.0;

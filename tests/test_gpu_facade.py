@@ -161,6 +161,50 @@ def test_driver_on_several_ranks(driver, tmp_path, dim, ranks, hh):
     np.testing.assert_allclose(x, x1, rtol=0, atol=1e-9 * np.abs(xd).max())
 
 
+@pytest.mark.parametrize("ranks", [1, 3])
+def test_driver_reads_and_partitions_an_unstructured_mesh(driver, tmp_path, ranks):
+    """"Mesh Type" = unstructured (laplace/main.cpp:155-175): MeshPartitioner::readAndPartition on the reference's own
+    cylinder mesh; on several ranks every rank reads the file, the library's deterministic bisection splits the elements
+    and each rank keeps its part with ghost layers.  The pieces of the solution together are the one-rank oracle solution."""
+    mesh = os.path.join(ROOT, "tests", "golden", "DFG3DCylinder_1k.mesh")
+    prob = tmp_path / "p.xml"
+    prob.write_text(open(os.path.join(XML, "parametersProblem.xml")).read()
+                    .replace('name="Dimension" type="int" value="2"', 'name="Dimension" type="int" value="3"')
+                    .replace('name="Mesh Type" type="string" value="structured"', 'name="Mesh Type" type="string" value="unstructured"')
+                    .replace('name="Mesh 1 Name" type="string" value="square.mesh"', 'name="Mesh 1 Name" type="string" value="%s"' % mesh))
+    sol = tmp_path / "s.xml"
+    sol.write_text(open(os.path.join(XML, "parametersSolver.xml")).read()
+                   .replace('value="1e-8"', 'value="1e-12"').replace('"Maximum Iterations" type="int" value="100"',
+                                                                     '"Maximum Iterations" type="int" value="600"'))
+    prec = tmp_path / "c.xml"
+    prec.write_text(open(os.path.join(XML, "parametersPrec.xml")).read()
+                    .replace('name="Combine Values in Overlap" type="string" value="Averaging"',
+                             'name="Combine Values in Overlap" type="string" value="Restricted"'))
+    out = tmp_path / "sol.txt"
+    cmd = [driver, "--problemfile=%s" % prob, "--precfile=%s" % prec, "--solverfile=%s" % sol, "--out=%s" % out]
+    if ranks > 1:
+        cmd.append("--ranks-as-threads=%d" % ranks)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    mt = re.search(r"iterations (\d+) relres (\S+)", r.stdout)
+    assert mt and float(mt.group(2)) <= 1e-12, r.stdout
+    import feddlib_amd.capi as capi
+    m = capi.read_mesh(mesh, 3)
+    from test_gpu_parity import oracle_mesh
+    A_bc, rhs_bc, _, _, _ = fo.laplace_problem(oracle_mesh(m), bc_flags=(1, 2, 3))
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    x = np.full(xd.shape[0], np.nan)
+    files = [str(out)] if ranks == 1 else [str(out) + ".%d" % k for k in range(ranks)]
+    seen = np.zeros(xd.shape[0], dtype=int)
+    for f in files:
+        part = np.loadtxt(f, ndmin=2)
+        gid = part[:, 0].astype(int)
+        x[gid] = part[:, 1]
+        seen[gid] += 1
+    assert (seen == 1).all()
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+
+
 LINELAS_XML = os.path.join(ROOT, "tests", "golden", "linelas_xml")
 
 
