@@ -687,6 +687,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     } else if (k == "schwarz_dedupe") c->sw_dedupe = (int)value;
     else if (k == "apply_span") c->apply_span = (int)value;
     else if (k == "md2_gy") c->md2_gy = (int)value;
+    else if (k == "md2_nch") c->md2_nch = (int)value;
     else if (k == "halo_overlap") { c->halo_overlap = (int)value; c->have_schwarz = false; }
     else if (k == "schwarz_big") c->sw_big = (int)value;
     else if (k == "schwarz_big_target") c->sw_big_target = (int)value;

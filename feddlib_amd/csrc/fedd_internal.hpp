@@ -214,6 +214,7 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_inv;                 // per subdomain [n_i][rp_i] column-major slab
     fedd::DevBuf<double> d_mult;                // [n_cols] multiplicity (averaging)
     bool have_schwarz = false;
+    int md2_nch = 4;                            // k_multidot2: 512-row chunks per workgroup (2 or 4)
     int md2_gy = 0;                             // k_multidot2: column groups in flight per row block (0 = by vector length)
     int halo_overlap = 0;                       // several ranks: interior subdomains first, ghost import of r on a second stream meanwhile
     hipStream_t stream2 = nullptr;              // (created on first use)

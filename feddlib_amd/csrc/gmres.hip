@@ -637,7 +637,7 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
     // grid rows of k_multidot2 = column groups in flight per row block: every workgroup reads its rows of u and B u once
     // and keeps them across its column groups, so fewer grid rows = fewer re-reads of those two vectors (PMC: 1.24x the
     // algorithmic bytes with one group per workgroup at 214^3); enough of them to fill the GPU when the vectors are short
-    const int md2_nch = 4;
+    const int md2_nch = c->md2_nch == 2 ? 2 : 4;
     const int64_t nblkd_ = (n + 512 * md2_nch - 1) / (512 * md2_nch);
     const int md2_gy = c->md2_gy > 0 ? c->md2_gy : (int)std::max<int64_t>(1, (2048 + nblkd_ - 1) / nblkd_);
     const int nblkd = (int)((n + 512 * md2_nch - 1) / (512 * md2_nch));
