@@ -258,11 +258,18 @@ def main():
             left -= cyc
         return seq
 
+    def spmv_bytes_model(si, nr):
+        """bytes one solver SpMV streams: values (8) and column ids (4) per entry + row pointer, x and y per row; with the
+        column patterns (fedd_spmv_patterns) a 2-byte pattern id per row replaces the column ids of the rows that have one"""
+        if si.get("column_patterns"):
+            return 8.0 * si["nnz_streamed"] + 22.0 * nr + 4.0 * si["nnz_streamed"] * si["rows_with_explicit_columns"] / max(nr, 1)
+        return 12.0 * si["nnz_streamed"] + 20.0 * nr
+
     def kernel_table(tm, m, nr, nnz, info):
         # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md section 6), this rank's share
         shared = info["n_unique"] * 4 <= info["n_subdomains"]
         models = {
-            "spmv": 12.0 * info["spmv"]["nnz_streamed"] + 20.0 * nr,
+            "spmv": spmv_bytes_model(info["spmv"], nr),
             # every stored inverse once, the dof lists once, r in and z out once (r is gathered ~4x over through the
             # caches: cache traffic, not counted)
             "schwarz_apply": info["inverse_bytes"] + 4.0 * info.get("sum_sizes", 0) + 2 * 8.0 * nr,
@@ -344,7 +351,7 @@ def main():
         c.spmv_device(50)
         c.sync()
         ms, nl = c.timing_get()["spmv"]
-        b = 12.0 * info["spmv"]["nnz_streamed"] + 20.0 * nr
+        b = spmv_bytes_model(info["spmv"], nr)
         spmv_b2b = {"ms_per_launch": ms / nl, "GBs": b / (ms / nl) / 1e6, "frac_hbm_peak": b / (ms / nl) / 1e6 / HBM_PEAK_GBS,
                     "note": "50 launches back to back on resident vectors" +
                             ("; the matrix (%.0f MB) fits the 256 MB Infinity Cache, so this is not a pure HBM figure"
@@ -466,6 +473,8 @@ def main():
             "spmv_frac_hbm_peak": kern["spmv"]["GBs"] / HBM_PEAK_GBS if "spmv" in kern else None,
             "spmv_bytes": None if "spmv" not in kern else {
                 "nnz_pattern": info["spmv"]["nnz_pattern"], "nnz_streamed": info["spmv"]["nnz_streamed"],
+                "column_patterns": info["spmv"].get("column_patterns", 0),
+                "rows_with_explicit_columns": info["spmv"].get("rows_with_explicit_columns"),
                 "streamed_bytes_per_launch": kern["spmv"]["bytes"],
                 "parity_csr_bytes_per_launch": 12.0 * nnz + 20.0 * nr,
                 "frac_hbm_peak_on_streamed_bytes": kern["spmv"]["GBs"] / HBM_PEAK_GBS,
@@ -473,7 +482,9 @@ def main():
                 "effective_frac_hbm_peak_on_parity_csr_bytes": (12.0 * nnz + 20.0 * nr) / kern["spmv"]["ms_per_launch"] / 1e6 / HBM_PEAK_GBS,
                 "note": "the solver streams a compacted copy of the owned rows (exact zeros dropped: 8 of the 15 pattern "
                         "entries of an interior Kuhn-cube row, all but the 1 of a Dirichlet row); fractions are quoted on "
-                        "the bytes actually streamed, the parity-CSR figure (SURVEY 8d model) is the effective rate"},
+                        "the bytes actually streamed, the parity-CSR figure (SURVEY 8d model) is the effective rate; "
+                        "with column_patterns > 0 the rows repeat their column offsets and the stream carries a 2-byte "
+                        "pattern id per row instead of 4 bytes per entry (values per row, y bit for bit the same)"},
             "mesh_generation_s": t_mesh, "mesh_upload_s": t_upload,
         }
         if N > 1:

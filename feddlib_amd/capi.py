@@ -84,6 +84,7 @@ SIGNATURES = {
     "fedd_schwarz_info": [C.c_void_p, _i64p, _i64p, _i64p],
     "fedd_schwarz_unique": [C.c_void_p, _i64p],
     "fedd_schwarz_sizes": [C.c_void_p, _i64p, _i64p],
+    "fedd_spmv_patterns": [C.c_void_p, _i64p, _i64p],
     "fedd_gmres": [C.c_void_p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int, _ip, _f64p],
     "fedd_set_option": [C.c_void_p, C.c_char_p, C.c_double],
     "fedd_timing_enable": [C.c_void_p, C.c_int],
@@ -463,7 +464,9 @@ class Context:
     def spmv_info(self):
         a, b = C.c_int64(), C.c_int64()
         _chk(self._L.fedd_spmv_info(self._h, C.byref(a), C.byref(b)))
-        return dict(nnz_pattern=a.value, nnz_streamed=b.value)
+        p, e = C.c_int64(), C.c_int64()
+        _chk(self._L.fedd_spmv_patterns(self._h, C.byref(p), C.byref(e)))
+        return dict(nnz_pattern=a.value, nnz_streamed=b.value, column_patterns=p.value, rows_with_explicit_columns=e.value)
 
     def spmv_device(self, reps):
         _chk(self._L.fedd_spmv_device(self._h, reps))

@@ -549,6 +549,15 @@ extern "C" int fedd_spmv_info(fedd_ctx* c, int64_t* nnz_pattern, int64_t* nnz_st
     return 0;
 }
 
+extern "C" int fedd_spmv_patterns(fedd_ctx* c, int64_t* n_patterns, int64_t* n_rows_explicit) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_spmv_patterns: no matrix");
+    const bool on = c->cs_valid && c->cs_npat > 0 && c->spmv_pattern;
+    if (n_patterns) *n_patterns = on ? c->cs_npat : 0;
+    if (n_rows_explicit) *n_rows_explicit = on ? c->cs_nexpl : c->n_rows;
+    return 0;
+}
+
 extern "C" int fedd_read_bandwidth(fedd_ctx* c, int64_t bytes, int reps, double* gb_per_s) {
     NEED_DEVICE(c);
     FEDD_CHECK(bytes >= (1 << 20) && reps > 0 && gb_per_s, "fedd_read_bandwidth: bytes %lld reps %d", (long long)bytes, reps);
@@ -687,6 +696,8 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     } else if (k == "schwarz_dedupe") c->sw_dedupe = (int)value;
     else if (k == "apply_span") c->apply_span = (int)value;
     else if (k == "md2_gy") c->md2_gy = (int)value;
+    else if (k == "spmv_pattern") { c->spmv_pattern = (int)value; c->cs_valid = false; }
+    else if (k == "spmv_pat_nu") { c->spmv_pat_nu = (int)value; c->cs_valid = false; }
     else if (k == "md2_nch") c->md2_nch = (int)value;
     else if (k == "halo_overlap") { c->halo_overlap = (int)value; c->have_schwarz = false; }
     else if (k == "schwarz_big") c->sw_big = (int)value;

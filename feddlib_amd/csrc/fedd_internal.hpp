@@ -71,6 +71,7 @@ struct DevBuf {
 
 constexpr int MAX_BC = 16;
 constexpr int MAX_DOFS = 3;
+constexpr int SPMV_PAT_LMAX = 16;       // longest offset list of the SpMV pattern table (spmv.hip SPAT_L)
 constexpr int SCHWARZ_NMAX = 256;  // largest overlapping subdomain (dofs) the register / LDS dense kernels take
 constexpr int SCHWARZ_NMAX_BIG = 1024;  // ... and the batched matrix-core inversion of the large-subdomain path
 
@@ -191,6 +192,16 @@ struct fedd_ctx {
     int32_t cs_tot32 = 0;
     fedd::DevBuf<int32_t> d_cs_rowptr, d_cs_col, d_cs_rows, d_cs_wincnt;
     fedd::DevBuf<double> d_cs_val;
+    int spmv_pattern = 1;                       // option "spmv_pattern": rows that repeat their column offsets share a pattern (spmv.hip)
+    int spmv_pat_nu = 0;                        // option "spmv_pat_nu": 16-byte loads per lane of k_spmv_pat (2, 4, 6, 8; 0 = 4)
+    int cs_pat_len = fedd::SPMV_PAT_LMAX;           // longest pattern in the table
+    int cs_pat_nu = 8;                          // pattern SpMV: window = 256 * cs_pat_nu values
+    fedd::DevBuf<int32_t> d_cs_prows;           // first row of each of those windows
+    int32_t cs_max_len = 1;                     // longest row of the compacted stream
+    int32_t cs_npat = 0, cs_nexpl = 0;          // patterns in use (0: dictionary off), rows that keep explicit columns
+    fedd::DevBuf<uint64_t> d_cs_hash;           // row hashes [n] | table keys
+    fedd::DevBuf<int32_t> d_cs_pati;            // slot of row [n] | table min row | pattern of slot | lengths | offset lists | counters
+    fedd::DevBuf<uint16_t> d_cs_pat;            // pattern id per row (0xffff: explicit columns)
     fedd::DevCsr aux[fedd::MAX_AUX];            // stored blocks (A, B, B^T, C) of a mixed problem
     bool merged = false;                        // system matrix = merged blocks (dof -> node map below)
     int64_t merged_nA = 0;                      // rows of block row 0

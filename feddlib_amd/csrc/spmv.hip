@@ -38,10 +38,10 @@ __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ rowptr
 constexpr int SP_CHUNK = 2048;
 
 __global__ void k_spmv_block_rows(const int32_t* __restrict__ rowptr, int32_t n_rows, int32_t nb,
-                                  int32_t* __restrict__ block_row) {
+                                  int32_t* __restrict__ block_row, int chunk = SP_CHUNK) {
     const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
-    const int64_t target = (int64_t)b * SP_CHUNK;
+    const int64_t target = (int64_t)b * chunk;
     int32_t lo = 0, hi = n_rows;
     while (lo < hi) {
         const int32_t mid = (lo + hi) >> 1;
@@ -306,6 +306,233 @@ int read_bandwidth(fedd_ctx* c, int64_t bytes, int reps, double* gbs) {
     return 0;
 }
 
+// ---- column patterns of the compacted stream ---------------------------------------------------------------------
+// On a mesh with repeated cells the rows of the matrix repeat their column OFFSETS (col - row): the 214^3 cube has a
+// few dozen distinct offset lists among its 9.9 M rows.  The solver's stream then needs no column index per entry: a
+// 16-bit pattern id per row and a small table of offset lists (in LDS) give the columns, the values stay per row, exact.
+// 12 -> 8 bytes per entry.  Rows whose list is not in the table (more than SPAT_L entries, or the table full) keep
+// their explicit columns (id SPAT_EXPL); more than SPAT_P patterns (an unstructured mesh): the dictionary is not used.
+// The sum of a row runs over its entries in order with separate multiply and add, exactly like k_spmv_win: same bits.
+constexpr int SPAT_P = 64, SPAT_L = 16, SPAT_TS = 1024;
+constexpr uint16_t SPAT_EXPL = 0xffff;
+
+__device__ __forceinline__ uint64_t sp_mix(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+// 8 lanes per row: hash of (length, offsets in order); 0 = the row keeps explicit columns
+__global__ void k_pat_hash(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int32_t n,
+                           unsigned long long* __restrict__ hash) {
+    const int32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int e = threadIdx.x & 7;
+    unsigned long long h = 0;
+    int len = 0;
+    if (r < n) {
+        const int32_t b = rowptr[r];
+        len = rowptr[r + 1] - b;
+        if (len <= SPAT_L)
+            for (int j = e; j < len; j += 8)
+                h += sp_mix(((unsigned long long)(j + 1) << 40) ^ (unsigned long long)(uint32_t)(col[b + j] - r));
+    }
+    for (int off = 4; off > 0; off >>= 1) h += __shfl_xor(h, off, 8);
+    if (r < n && e == 0) {
+        h = sp_mix(h + (unsigned long long)len);
+        hash[r] = (len >= 1 && len <= SPAT_L) ? (h | 1ull) : 0ull;
+    }
+}
+
+// table insert (the lanes of a wave that carry the same hash send one of them); the slot keeps the lowest row seen
+__global__ void k_pat_insert(const unsigned long long* __restrict__ hash, int32_t n, unsigned long long* __restrict__ tkey,
+                             int32_t* __restrict__ tmin, int32_t* __restrict__ slot_of, int32_t* __restrict__ n_claimed) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long h = r < n ? hash[r] : 0ull;
+    const bool active = h != 0ull;
+    uint64_t todo = __ballot(active);
+    int32_t mine = -1;
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const unsigned long long lh = __shfl(h, leader, 64);
+        const uint64_t same = __ballot(active && h == lh) & todo;
+        int32_t s_found = -1;
+        // (many more distinct lists than the table is meant for -- an unstructured mesh --: stop looking, the rows keep
+        // their explicit columns and the dictionary ends up unused)
+        if (lane == leader && __hip_atomic_load(n_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 4 * SPAT_P) {
+            int s = (int)(lh % SPAT_TS);
+            for (int probe = 0; probe < 64; ++probe) {
+                // plain look first: after the first waves the key is there and its lowest row is below this one, and
+                // hundreds of thousands of atomics on a handful of addresses would serialise in L2
+                unsigned long long old = __hip_atomic_load(&tkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == 0ull) {
+                    old = atomicCAS(&tkey[s], 0ull, lh);
+                    if (old == 0ull) atomicAdd(n_claimed, 1);
+                }
+                if (old == 0ull || old == lh) {
+                    if (__hip_atomic_load(&tmin[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > r) atomicMin(&tmin[s], r);
+                    s_found = s;
+                    break;
+                }
+                s = s + 1 == SPAT_TS ? 0 : s + 1;
+            }
+        }
+        s_found = __shfl(s_found, leader, 64);
+        if ((same >> lane) & 1ull) mine = s_found;
+        todo &= ~same;
+    }
+    if (r < n) slot_of[r] = mine;
+}
+
+// one workgroup: pattern ids in slot order, offset lists from the representative rows
+__global__ __launch_bounds__(256) void k_pat_table(const unsigned long long* __restrict__ tkey, const int32_t* __restrict__ tmin,
+                                                   const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                   int32_t* __restrict__ pat_of_slot, int32_t* __restrict__ plen,
+                                                   int32_t* __restrict__ pdelta, int32_t* __restrict__ n_pat) {
+    __shared__ int32_t cnt[SPAT_TS];
+    const int tid = threadIdx.x;
+    for (int s = tid; s < SPAT_TS; s += 256) cnt[s] = tkey[s] != 0ull ? 1 : 0;
+    __syncthreads();
+    if (tid == 0) {         // (a thousand slots: a serial scan is microseconds)
+        int run = 0;
+        for (int s = 0; s < SPAT_TS; ++s) {
+            const int c = cnt[s];
+            cnt[s] = c ? run : -1;
+            run += c;
+        }
+        *n_pat = run;
+        n_pat[3] = 0;       // (longest pattern, below)
+    }
+    __syncthreads();
+    for (int s = tid; s < SPAT_TS; s += 256) {
+        const int id = cnt[s];
+        pat_of_slot[s] = id < SPAT_P ? id : -1;
+        if (id >= 0 && id < SPAT_P) {
+            const int32_t r = tmin[s], b = rowptr[r], len = rowptr[r + 1] - b;
+            plen[id] = len;
+            atomicMax(n_pat + 3, len);
+            for (int j = 0; j < SPAT_L; ++j) pdelta[id * SPAT_L + j] = j < len ? col[b + j] - r : 0;
+        }
+    }
+}
+
+// per row: its pattern id, checked entry by entry against the table (a colliding hash costs explicit columns, never a
+// wrong product); n_expl counts the rows that keep explicit columns
+__global__ void k_pat_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int32_t n,
+                           const int32_t* __restrict__ slot_of, const int32_t* __restrict__ pat_of_slot,
+                           const int32_t* __restrict__ plen, const int32_t* __restrict__ pdelta, uint16_t* __restrict__ pat,
+                           int32_t* __restrict__ n_expl) {
+    // 8 lanes per row (consecutive lanes read consecutive column ids)
+    const int32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int e = threadIdx.x & 7;
+    int id = -1, len = 0;
+    bool ok = true;
+    if (r < n) {
+        const int32_t s = slot_of[r];
+        id = s >= 0 ? pat_of_slot[s] : -1;
+        const int32_t b = rowptr[r];
+        len = rowptr[r + 1] - b;
+        if (id >= 0) {
+            ok = len == plen[id];
+            if (ok)
+                for (int j = e; j < len; j += 8) ok = ok && (col[b + j] - r == pdelta[id * SPAT_L + j]);
+        }
+    }
+    unsigned bad = ok ? 0u : 1u;
+    for (int off = 4; off > 0; off >>= 1) bad |= __shfl_xor(bad, off, 8);
+    if (bad) id = -1;
+    const bool writer = r < n && e == 0;
+    if (writer) pat[r] = id >= 0 ? (uint16_t)id : SPAT_EXPL;
+    // one atomic per wave for the count (every row of an unstructured mesh lands here)
+    const uint64_t expl = __ballot(writer && id < 0);
+    if (expl && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(expl)) atomicAdd(n_expl, (int32_t)__builtin_popcountll(expl));
+    int wmax = writer ? len : 0;                                    // longest compacted row: one atomic per wave, if at all
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
+    if ((threadIdx.x & 63) == 0 && wmax > __hip_atomic_load(n_expl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(n_expl + 1, wmax);
+}
+
+// The windowed SpMV on the value stream alone: workgroup lb brings the values [CH lb, CH lb + CH + overhang) to LDS
+// (coalesced, non-temporal, addresses independent of any other load), then one lane per row multiplies its values with x
+// at row + offset -- consecutive lanes are consecutive rows of (mostly) one pattern, so the reads of x are coalesced,
+// which the per-entry gathers of k_spmv_win are not.  CH = 256 NU with NU = the usual row length: a window then holds
+// about 256 rows, one per lane.  (A variant with 256 ROWS per workgroup was slower, 174 against 152 us at 214^3: its value
+// loads depend on two row pointers.)
+template <bool NT, int NU, int LU /* unrolled entries per row: 8 when no pattern is longer, else SPAT_L */>
+__global__ __launch_bounds__(256) void k_spmv_pat(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                                  const double* __restrict__ val, const uint16_t* __restrict__ pat,
+                                                  const int32_t* __restrict__ plen, const int32_t* __restrict__ pdelta,
+                                                  int32_t n_pat, const double* __restrict__ x, double* __restrict__ y,
+                                                  const int32_t* __restrict__ block_row, int32_t nb, int32_t nnz, int32_t ovh) {
+    extern __shared__ double sval[];                    // [CH + ovh]
+    __shared__ int32_t sdelta[SPAT_P * SPAT_L];
+    __shared__ int32_t slen[SPAT_P];
+    constexpr int CH = 512 * NU;                        // NU 16-byte loads per lane (the value array is padded by a window)
+    const int tid = threadIdx.x;
+    const int32_t q = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int32_t lb = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
+    const int32_t R0 = block_row[lb], R1 = block_row[lb + 1];
+    const int32_t base = lb * CH, last = nnz - 1;
+    vd2 v[NU];
+    const vd2* __restrict__ val2 = reinterpret_cast<const vd2*>(val + base);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) v[u] = NT ? __builtin_nontemporal_load(val2 + tid + u * 256) : val2[tid + u * 256];
+    double vo = 0.0;
+    if (tid < ovh) {
+        const int32_t idx = min(base + CH + tid, last);
+        vo = NT ? __builtin_nontemporal_load(val + idx) : val[idx];
+    }
+    // the lane's first two rows: bounds and pattern ids requested with the stream
+    const int32_t r_a = max(min(R0 + tid, R1 - 1), 0), r_b = max(min(R0 + tid + 256, R1 - 1), 0);
+    const int32_t rb0 = rowptr[r_a], rb1 = rowptr[r_b];
+    const uint16_t id0 = pat[r_a], id1 = pat[r_b];
+    for (int i = tid; i < n_pat * SPAT_L; i += 256) sdelta[i] = pdelta[i];
+    for (int i = tid; i < n_pat; i += 256) slen[i] = plen[i];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) reinterpret_cast<vd2*>(sval)[tid + u * 256] = v[u];
+    if (tid < ovh) sval[CH + tid] = vo;
+    __syncthreads();
+    int trip = 0;
+    for (int32_t r = R0 + tid; r < R1; r += 256, ++trip) {
+        const int32_t rb = trip == 0 ? rb0 : trip == 1 ? rb1 : rowptr[r];
+        const int32_t b = rb - base;
+        const uint16_t id = trip == 0 ? id0 : trip == 1 ? id1 : pat[r];
+        double s = 0.0;
+        {
+            // separate multiply and add, in entry order: the bits of k_spmv_win (HIP contracts a * b + c by default, also
+            // through __dmul_rn / __dadd_rn, which are plain operators)
+#pragma clang fp contract(off)
+            if (id != SPAT_EXPL) {
+                const int len = slen[id];
+                const int32_t* __restrict__ dl = sdelta + (int)id * SPAT_L;
+                double xv[LU], av[LU];
+#pragma unroll
+                for (int j = 0; j < LU; ++j) {          // all loads of the row in flight together
+                    const bool on = j < len;
+                    xv[j] = on ? x[r + dl[j]] : 0.0;
+                    av[j] = on ? sval[b + j] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < LU; ++j)
+                    if (j < len) {
+                        const double pr = av[j] * xv[j];
+                        s = s + pr;
+                    }
+            } else {
+                const int32_t e = rowptr[r + 1] - base;
+                for (int32_t p = b; p < e; ++p) {
+                    const double pr = sval[p] * x[colind[base + p]];
+                    s = s + pr;
+                }
+            }
+        }
+        y[r] = s;
+    }
+}
+
 // window -> first row table of the parity CSR (one-off per pattern)
 static int spmv_window_rows(fedd_ctx* c) {
     const int32_t nb = (int32_t)(c->nnz / SP_CHUNK + 1);
@@ -332,7 +559,7 @@ static int spmv_compact_build(fedd_ctx* c) {
     c->cs_nnz = total;
     FEDD_TRY(c->d_cs_rowptr.ensure((size_t)n + 1));
     FEDD_TRY(c->d_cs_col.ensure((size_t)total + 1));
-    FEDD_TRY(c->d_cs_val.ensure((size_t)total + 1));
+    FEDD_TRY(c->d_cs_val.ensure((size_t)total + 4096 + 8));      // (k_spmv_pat reads whole 16-byte windows)
     hipLaunchKernelGGL(k_cs_fill, dim3((unsigned)nb), dim3(256), 0, c->stream, (const int32_t*)c->d_rowptr.p,
                        (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, (const int32_t*)c->d_spmv_rows.p,
                        (const int32_t*)c->d_cs_wincnt.p, c->spmv_drop_tol, c->d_cs_rowptr.p, c->d_cs_col.p, c->d_cs_val.p);
@@ -342,6 +569,51 @@ static int spmv_compact_build(fedd_ctx* c) {
     FEDD_TRY(c->d_cs_rows.ensure((size_t)nbc + 1));
     hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nbc + 1 + 255) / 256)), dim3(256), 0, c->stream,
                        (const int32_t*)c->d_cs_rowptr.p, n, nbc, c->d_cs_rows.p);
+    // column patterns (see k_spmv_pat)
+    c->cs_npat = 0;
+    if (c->spmv_pattern && total > 0) {
+        FEDD_TRY(c->d_cs_hash.ensure((size_t)n + SPAT_TS));
+        FEDD_TRY(c->d_cs_pati.ensure((size_t)n + 2 * SPAT_TS + SPAT_P * (SPAT_L + 1) + 16));
+        FEDD_TRY(c->d_cs_pat.ensure((size_t)n + 1));
+        unsigned long long* hash = (unsigned long long*)c->d_cs_hash.p;
+        unsigned long long* tkey = hash + n;
+        int32_t* slot_of = c->d_cs_pati.p;
+        int32_t* tmin = slot_of + n;
+        int32_t* pat_of_slot = tmin + SPAT_TS;
+        int32_t* plen = pat_of_slot + SPAT_TS;
+        int32_t* pdelta = plen + SPAT_P;
+        int32_t* counters = pdelta + SPAT_P * SPAT_L;      // claimed slots | patterns | explicit rows
+        FEDD_HIP(hipMemsetAsync(tkey, 0, SPAT_TS * sizeof(unsigned long long), c->stream));
+        FEDD_HIP(hipMemsetAsync(tmin, 0x7f, SPAT_TS * sizeof(int32_t), c->stream));
+        FEDD_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int32_t), c->stream));
+        const dim3 b256(256), gr((unsigned)((n + 255) / 256)), gr8((unsigned)(((int64_t)n * 8 + 255) / 256));
+        hipLaunchKernelGGL(k_pat_hash, gr8, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const int32_t*)c->d_cs_col.p, n, hash);
+        // (a table that fills up means "no repeated patterns": the rows that find no slot keep explicit columns)
+        hipLaunchKernelGGL(k_pat_insert, gr, b256, 0, c->stream, (const unsigned long long*)hash, n, tkey, tmin, slot_of, counters);
+        hipLaunchKernelGGL(k_pat_table, dim3(1), b256, 0, c->stream, (const unsigned long long*)tkey, (const int32_t*)tmin,
+                           (const int32_t*)c->d_cs_rowptr.p, (const int32_t*)c->d_cs_col.p, pat_of_slot, plen, pdelta, counters + 1);
+        hipLaunchKernelGGL(k_pat_rows, gr8, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const int32_t*)c->d_cs_col.p, n,
+                           (const int32_t*)slot_of, (const int32_t*)pat_of_slot, (const int32_t*)plen, (const int32_t*)pdelta,
+                           c->d_cs_pat.p, counters + 2);
+        int32_t h[5] = {0, 0, 0, 0, 0};    // claimed slots | patterns | explicit rows | longest row | longest pattern
+        FEDD_HIP(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        // worth it when most rows found a pattern (an unstructured mesh fills the table and finds none) and 256 rows of
+        // values fit a modest LDS run; matrices that fit the Infinity Cache keep the per-entry kernel (measured: 100^3
+        // cells 20.5 us against 25.6 us)
+        c->cs_max_len = std::max(1, h[3]);
+        const bool big = 12.0 * (double)total > 256.0 * 1024.0 * 1024.0 || c->spmv_pattern == 2;
+        c->cs_npat = (big && h[1] >= 1 && (int64_t)h[2] * 4 <= (int64_t)n) ? std::min<int32_t>(h[1], SPAT_P) : 0;
+        c->cs_nexpl = h[2];
+        c->cs_pat_len = h[4];
+        if (c->cs_npat > 0) {
+            c->cs_pat_nu = c->spmv_pat_nu == 2 || c->spmv_pat_nu == 4 || c->spmv_pat_nu == 6 || c->spmv_pat_nu == 8 ? c->spmv_pat_nu : 4;
+            const int32_t nbp = (int32_t)(total / (512 * c->cs_pat_nu) + 1);
+            FEDD_TRY(c->d_cs_prows.ensure((size_t)nbp + 1));
+            hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nbp + 1 + 255) / 256)), dim3(256), 0, c->stream,
+                               (const int32_t*)c->d_cs_rowptr.p, n, nbp, c->d_cs_prows.p, 512 * c->cs_pat_nu);
+        }
+    }
     ts.stop();
     FEDD_HIP(hipGetLastError());
     c->cs_valid = true;
@@ -375,7 +647,31 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
         ScopedTimer ts(c, FEDD_T_SPMV);
         if (c->cs_nnz == 0)
             FEDD_HIP(hipMemsetAsync(d_y_owned, 0, (size_t)n * sizeof(double), c->stream));
-        else if (nt)
+        else if (c->cs_npat > 0 && c->spmv_pattern) {
+            const int32_t* plen = c->d_cs_pati.p + n + 2 * SPAT_TS;
+            const int32_t* pdelta = plen + SPAT_P;
+            const int nu = c->cs_pat_nu;                        // 16-byte loads per lane: window = 512 nu values
+            const int32_t nbp = (int32_t)(c->cs_nnz / (512 * nu) + 1);
+            const size_t ldp = (size_t)(512 * nu + ovh) * sizeof(double);
+#define SPMV_PAT1(NT_, NU_, LU_)                                                                                                    \
+    hipLaunchKernelGGL((k_spmv_pat<NT_, NU_, LU_>), dim3((unsigned)nbp), dim3(256), ldp, c->stream, (const int32_t*)c->d_cs_rowptr.p, \
+                       (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, (const uint16_t*)c->d_cs_pat.p, plen,           \
+                       pdelta, c->cs_npat, x, d_y_owned, (const int32_t*)c->d_cs_prows.p, nbp, (int32_t)c->cs_nnz, ovh)
+#define SPMV_PAT(NT_, NU_)                                 \
+    if (c->cs_pat_len <= 8) SPMV_PAT1(NT_, NU_, 8);         \
+    else SPMV_PAT1(NT_, NU_, SPAT_L)
+#define SPMV_PAT_NU(NT_)                 \
+    switch (nu) {                        \
+        case 2: SPMV_PAT(NT_, 2); break; \
+        case 4: SPMV_PAT(NT_, 4); break; \
+        case 6: SPMV_PAT(NT_, 6); break; \
+        default: SPMV_PAT(NT_, 8); break; \
+    }
+            if (nt) { SPMV_PAT_NU(true) } else { SPMV_PAT_NU(false) }
+#undef SPMV_PAT_NU
+#undef SPMV_PAT
+#undef SPMV_PAT1
+        } else if (nt)
             hipLaunchKernelGGL(k_spmv_win<true>, dim3((unsigned)nbc), dim3(256), lds, c->stream, (const int32_t*)c->d_cs_rowptr.p,
                                (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, x, d_y_owned,
                                (const int32_t*)c->d_cs_rows.p, nbc, (int32_t)c->cs_nnz, ovh);

@@ -348,6 +348,12 @@ int fedd_timing_get(fedd_ctx* ctx, int timer, double* total_ms, int64_t* launche
  * non-temporal loads, `reps` launches back to back, best of three batches) on this GPU, i.e. the ceiling that
  * the measured fractions of the 8 TB/s spec can be compared with ("of spec" and "of
  * measured") */
+/* column patterns of the solver's compacted SpMV stream (option "spmv_pattern", default 1): rows that repeat their column
+ * offsets (col - row) share an offset list, so the stream carries 8 instead of 12 bytes per entry (values per row, exact; a
+ * 16-bit pattern id per row).  n_patterns = 0: not in use (option off, no solve yet, or the matrix has no repeated rows);
+ * n_rows_explicit = rows that keep explicit column indices. */
+int fedd_spmv_patterns(fedd_ctx* ctx, int64_t* n_patterns, int64_t* n_rows_explicit);
+
 int fedd_read_bandwidth(fedd_ctx* ctx, int64_t bytes, int reps, double* gb_per_s);
 
 /* multi-GPU: exchange plan for the owned/ghost split (import of ghost x / r entries before SpMV

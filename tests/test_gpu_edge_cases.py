@@ -238,3 +238,62 @@ def test_box_lattice_refines_itself_when_a_subdomain_would_exceed_the_dense_solv
         np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
     finally:
         ctx.schwarz_set_target(0, 1.0)
+
+
+@pytest.mark.parametrize("dim,M,dofs", [(3, 20, 1), (2, 70, 1), (3, 10, 3)])
+def test_spmv_column_patterns_give_the_same_bits(fedd_lib, ctx, dim, M, dofs):
+    """spmv_pattern: rows that repeat their column offsets share an offset list and the solver's stream carries values
+    only.  Forced on (2) on these small matrices (by default only matrices beyond the Infinity Cache take it): a handful of
+    patterns covers the structured mesh, and y is the y of the per-entry kernel bit for bit (same products, same order)."""
+    m = fedd_lib.structured_mesh(dim, 1, M)
+    ctx.mesh_set_dict(m)
+    if dofs == 1:
+        ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+        ctx.assemble(fedd_lib.FORM_LAPLACE)
+        ctx.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+    else:
+        ctx.pattern_build(dofs, fedd_lib.BLOCK_FULL)
+        ctx.assemble(fedd_lib.FORM_LINELAS, [1.5, 1.0])
+        ctx.dirichlet([2], np.zeros(dofs))
+    nr = ctx.csr_sizes()[0]
+    x = np.random.default_rng(7).standard_normal(nr)
+    ctx.set_option("spmv_pattern", 0)
+    y0 = ctx.spmv(x)
+    assert ctx.spmv_info()["column_patterns"] == 0
+    try:
+        ctx.set_option("spmv_pattern", 2)
+        for nu in (2, 4, 6, 8):
+            ctx.set_option("spmv_pat_nu", nu)
+            y1 = ctx.spmv(x)
+            info = ctx.spmv_info()
+            assert np.array_equal(y1, y0), (nu, np.abs(y1 - y0).max())
+            if dofs == 1:       # scalar stencil: every row finds a pattern, and there are few
+                assert 1 <= info["column_patterns"] <= 64 and info["rows_with_explicit_columns"] == 0, info
+        # the elasticity rows are longer than the 16 entries a pattern holds: they keep explicit columns (dictionary off)
+        if dofs > 1:
+            assert info["column_patterns"] == 0 or info["rows_with_explicit_columns"] > 0
+    finally:
+        ctx.set_option("spmv_pattern", 1)
+        ctx.set_option("spmv_pat_nu", 0)
+
+
+def test_spmv_column_patterns_fall_back_on_an_unstructured_mesh(fedd_lib, ctx):
+    m = fedd_lib.read_mesh(os.path.join(GOLD, "DFG3DCylinder_1k.mesh"), 3)
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+    ctx.assemble(fedd_lib.FORM_LAPLACE)
+    ctx.dirichlet([1, 2, 4], [0.0, 0.0, 0.0])
+    nr = ctx.csr_sizes()[0]
+    x = np.random.default_rng(8).standard_normal(nr)
+    ctx.set_option("spmv_pattern", 0)
+    y0 = ctx.spmv(x)
+    try:
+        ctx.set_option("spmv_pattern", 2)
+        y1 = ctx.spmv(x)
+        info = ctx.spmv_info()
+        assert np.array_equal(y1, y0)
+        # no two rows of an unstructured mesh share their offsets (beyond the Dirichlet rows' single entry): not used
+        assert info["column_patterns"] == 0 and info["rows_with_explicit_columns"] == nr, info
+    finally:
+        ctx.set_option("spmv_pattern", 1)
+

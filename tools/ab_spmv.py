@@ -36,8 +36,13 @@ for rep in range(2):
         c.sync()
         t = c.timing_get()["spmv"]
         ms = t[0] / t[1]
-        b = 12.0 * c.spmv_info()["nnz_streamed"] + 20.0 * nr
+        si = c.spmv_info()
+        if si["column_patterns"]:    # values + pattern id and row pointer per row + explicit columns of the rows without a pattern
+            b = 8.0 * si["nnz_streamed"] + 22.0 * nr + 4.0 * si["nnz_streamed"] * si["rows_with_explicit_columns"] / nr
+        else:
+            b = 12.0 * si["nnz_streamed"] + 20.0 * nr
         err = np.abs(y - y0).max() / np.abs(y0).max()
-        print("M %d %-40s %.2f us  %.0f GB/s streamed (%.3f of 8 TB/s, %.3f of ceiling)  diff vs first: %.1e"
-              % (M, cfg, ms * 1e3, b / ms / 1e6, b / ms / 8e9, b / ms / 1e6 / ceiling, err), flush=True)
+        print("M %d %-40s %.2f us  %.0f GB/s streamed (%.3f of 8 TB/s, %.3f of ceiling)  diff vs first: %.1e  patterns %d explicit rows %d"
+              % (M, cfg, ms * 1e3, b / ms / 1e6, b / ms / 8e9, b / ms / 1e6 / ceiling, err, si["column_patterns"],
+                 si["rows_with_explicit_columns"]), flush=True)
 c.close()
