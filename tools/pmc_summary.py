@@ -13,15 +13,16 @@ def load(d, name):
     return acc
 
 fe = load(sys.argv[1], "FETCH_SIZE"); wr = load(sys.argv[2], "WRITE_SIZE")
-classes = {"spmv": "k_spmv_win<", "schwarz_apply": "k_apply", "assemble": "k_assemble_pairs<", "multidot": "k_multidot(",
+classes = {"spmv": ("k_spmv_win<", "k_spmv_pat<"), "schwarz_apply": "k_apply", "assemble": "k_assemble_pairs<", "multidot": "k_multidot(",
            "multiaxpy": "k_multiaxpy(", "gs_dot": "k_multidot2", "gs_update": "k_axpy2", "invert": "k_invert_reg<7"}
 # (gs_dot / gs_update: the basis grows from launch to launch; the figure is the mean over all launches of the solve, like
 # bench.py's byte model.  schwarz_apply with shared inverses is a gather kernel: the doubling of FETCH_SIZE is calibrated
 # on streaming reads and may overstate its traffic)
 out = {}
 for key, pat in classes.items():
-    fk = [v for k, vs in fe.items() if pat in k for v in vs]
-    wk = [v for k, vs in wr.items() if pat in k for v in vs]
+    pats = pat if isinstance(pat, tuple) else (pat,)
+    fk = [v for k, vs in fe.items() if any(p in k for p in pats) for v in vs]
+    wk = [v for k, vs in wr.items() if any(p in k for p in pats) for v in vs]
     if not fk: continue
     # drop gated-out launches (near-zero traffic) of the DGKS second pass
     fk2 = ([v for v in fk if v > 0.05 * max(fk)] or fk) if key in ("multidot", "multiaxpy") else fk
