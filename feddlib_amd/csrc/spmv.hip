@@ -571,7 +571,10 @@ static int spmv_compact_build(fedd_ctx* c) {
                        (const int32_t*)c->d_cs_rowptr.p, n, nbc, c->d_cs_rows.p);
     // column patterns (see k_spmv_pat)
     c->cs_npat = 0;
-    if (c->spmv_pattern && total > 0) {
+    // (matrices that fit the Infinity Cache keep the per-entry kernel -- measured: 100^3 cells 20.5 us against 25 us --,
+    // so the dictionary is not built for them; option value 2 forces it)
+    const bool big = 12.0 * (double)total > 256.0 * 1024.0 * 1024.0 || c->spmv_pattern == 2;
+    if (c->spmv_pattern && total > 0 && big) {
         FEDD_TRY(c->d_cs_hash.ensure((size_t)n + SPAT_TS));
         FEDD_TRY(c->d_cs_pati.ensure((size_t)n + 2 * SPAT_TS + SPAT_P * (SPAT_L + 1) + 16));
         FEDD_TRY(c->d_cs_pat.ensure((size_t)n + 1));
@@ -598,12 +601,9 @@ static int spmv_compact_build(fedd_ctx* c) {
         int32_t h[5] = {0, 0, 0, 0, 0};    // claimed slots | patterns | explicit rows | longest row | longest pattern
         FEDD_HIP(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         FEDD_HIP(hipStreamSynchronize(c->stream));
-        // worth it when most rows found a pattern (an unstructured mesh fills the table and finds none) and 256 rows of
-        // values fit a modest LDS run; matrices that fit the Infinity Cache keep the per-entry kernel (measured: 100^3
-        // cells 20.5 us against 25.6 us)
+        // worth it when most rows found a pattern (an unstructured mesh fills the table and finds none)
         c->cs_max_len = std::max(1, h[3]);
-        const bool big = 12.0 * (double)total > 256.0 * 1024.0 * 1024.0 || c->spmv_pattern == 2;
-        c->cs_npat = (big && h[1] >= 1 && (int64_t)h[2] * 4 <= (int64_t)n) ? std::min<int32_t>(h[1], SPAT_P) : 0;
+        c->cs_npat = (h[1] >= 1 && (int64_t)h[2] * 4 <= (int64_t)n) ? std::min<int32_t>(h[1], SPAT_P) : 0;
         c->cs_nexpl = h[2];
         c->cs_pat_len = h[4];
         if (c->cs_npat > 0) {
