@@ -84,6 +84,7 @@ SIGNATURES = {
     "fedd_schwarz_info": [C.c_void_p, _i64p, _i64p, _i64p],
     "fedd_schwarz_unique": [C.c_void_p, _i64p],
     "fedd_schwarz_sizes": [C.c_void_p, _i64p, _i64p],
+    "fedd_schwarz_conforming": [C.c_void_p, _i64p],
     "fedd_spmv_patterns": [C.c_void_p, _i64p, _i64p],
     "fedd_gmres": [C.c_void_p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int, _ip, _f64p],
     "fedd_set_option": [C.c_void_p, C.c_char_p, C.c_double],
@@ -505,6 +506,9 @@ class Context:
             ss, so = C.c_int64(), C.c_int64()
             if self._L.fedd_schwarz_sizes(self._h, C.byref(ss), C.byref(so)) == 0:
                 out.update(sum_sizes=ss.value, sum_owned=so.value)
+            nc = C.c_int64()
+            if self._L.fedd_schwarz_conforming(self._h, C.byref(nc)) == 0:
+                out.update(n_conforming=nc.value)
         return out
 
     def schwarz_apply(self, r):

@@ -524,6 +524,13 @@ extern "C" int fedd_schwarz_unique(fedd_ctx* c, int64_t* n_unique) {
     return 0;
 }
 
+extern "C" int fedd_schwarz_conforming(fedd_ctx* c, int64_t* n_conforming) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_schwarz && n_conforming, "fedd_schwarz_conforming: no preconditioner");
+    *n_conforming = c->sw_big_active ? 0 : c->sw_nconf;
+    return 0;
+}
+
 extern "C" int fedd_schwarz_sizes(fedd_ctx* c, int64_t* sum_sizes, int64_t* sum_owned) {
     NEED_DEVICE(c);
     FEDD_CHECK(c->have_schwarz && !c->sw_big_active, "fedd_schwarz_sizes: no preconditioner of the small-subdomain path");

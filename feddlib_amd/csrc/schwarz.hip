@@ -434,12 +434,34 @@ __global__ void k_order_key(const int32_t* __restrict__ sub_n, const int32_t* __
     key[b] = k;
 }
 
+// record of a place of the apply order: (subdomain, representative, columns | owned rows << 10 | conforming << 20, first dof).
+// conforming = the dof list is the representative's list shifted (dof_k - dof_0 equal for all k): on a structured mesh
+// every box of a class; the apply then computes the ids from the representative's offsets instead of reading the list.
+// 16 lanes per place.
 __global__ void k_pack_order(const int32_t* __restrict__ ord, const int32_t* __restrict__ rep, const int32_t* __restrict__ sub_n,
-                             const int32_t* __restrict__ sub_nown, int32_t n, int4* __restrict__ rec) {
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t sidx = ord[i];
-    rec[i] = make_int4(sidx, rep ? rep[sidx] : sidx, sub_n[sidx], sub_nown[sidx]);
+                             const int32_t* __restrict__ sub_nown, const int32_t* __restrict__ sub_dofs, int32_t n,
+                             int4* __restrict__ rec, int32_t* __restrict__ n_conf) {
+    const int32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int e = threadIdx.x & 15;
+    bool same = true;
+    int32_t sidx = 0, rp = 0, nn = 0, a0 = 0;
+    if (i < n) {
+        sidx = ord[i];
+        rp = rep ? rep[sidx] : sidx;
+        nn = sub_n[sidx];
+        const int32_t* __restrict__ mine = sub_dofs + (int64_t)sidx * NMAX;
+        const int32_t* __restrict__ ref = sub_dofs + (int64_t)rp * NMAX;
+        a0 = mine[0];
+        const int32_t r0 = ref[0];
+        same = sub_n[rp] == nn;
+        if (same)
+            for (int k = e; k < nn; k += 16) same = same && (mine[k] - a0 == ref[k] - r0);
+    }
+    unsigned bad = same ? 0u : 1u;
+    for (int off = 8; off > 0; off >>= 1) bad |= __shfl_xor(bad, off, 16);
+    if (i < n && e == 0) rec[i] = make_int4(sidx, rp, nn | (sub_nown[sidx] << 10) | (bad ? 0 : 1 << 20), a0);
+    const uint64_t conf = __ballot(i < n && e == 0 && !bad);
+    if (conf && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(conf)) atomicAdd(n_conf, (int32_t)__builtin_popcountll(conf));
 }
 
 __global__ void k_fp_share(const int32_t* __restrict__ rep, int32_t nsub, int64_t* __restrict__ inv_ptr) {
@@ -833,6 +855,7 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
     constexpr int U = (16 * KW + 63) / 64;      // 16-byte loads per lane and batch
     __shared__ double part[4][RT][4][64];
     __shared__ int32_t ids[2][AM_MB][S];
+    __shared__ __attribute__((aligned(16))) int32_t soff[16 * KW];      // dof offsets of the current representative's list
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lj = lane & 15, lk = lane >> 4;
     const int lm = tid >> 4, lc = tid & 15;     // id loads: subdomain lm of the batch, columns 4 lc + 64 u ...
     // XCD-contiguous ranges (neighbouring boxes gather overlapping parts of r: one L2)
@@ -841,8 +864,10 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
     const int32_t p_end = min(nsub, (wg + 1) * span);   // span = a multiple of 64
     int32_t p_chunk = wg * span;
     if (p_chunk >= p_end) return;
-    // chunk = 64 places: lane = place; record = (subdomain, representative, columns, owned rows)
+    // chunk = 64 places: lane = place; record = (subdomain, representative, columns | owned rows << 10 | conforming << 20,
+    // first dof), see k_pack_order
     const int4 none = make_int4(0, -1, 0, 0);
+    int32_t soff_rep = -1;                      // representative whose offsets soff holds
     int4 hdr = p_chunk + lane < p_end ? order[p_chunk + lane] : none;
     int4 hdr_n = p_chunk + 64 + lane < p_end ? order[p_chunk + 64 + lane] : none;
     int cnt = min(64, p_end - p_chunk);
@@ -856,13 +881,23 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         return min(min(mb_, AM_MB), cnt_ - pos_);
     };
     // the dof list of subdomain lm of a batch, this lane's columns (whole rows: sub_dofs rows are NMAX long)
+    // ... or, for a batch of conforming subdomains of the representative whose offsets are in soff, computed: first dof +
+    // offset (no read of the list: 124 MB per apply at 214^3 cells)
     auto load_ids = [&](const int4& h, int pos_, int mb_, int n_, int4 (&v)[U]) {
         const int32_t sm = __shfl(h.x, pos_ + lm, 64);
+        const int32_t a0 = __shfl(h.w, pos_ + lm, 64);
+        const bool computed = ((__builtin_amdgcn_readlane(h.z, pos_) >> 20) & 1) && __builtin_amdgcn_readlane(h.y, pos_) == soff_rep;
         const int4* __restrict__ row = (const int4*)(sub_dofs + (int64_t)sm * NMAX);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c4 = lc + 16 * u;
-            v[u] = (lm < mb_ && 4 * c4 < n_ && 4 * c4 < 16 * KW) ? row[c4] : make_int4(0, 0, 0, 0);
+            const bool on = lm < mb_ && 4 * c4 < n_ && 4 * c4 < 16 * KW;
+            if (computed) {     // (uniform over the workgroup)
+                const int4 o = on ? reinterpret_cast<const int4*>(soff)[c4] : make_int4(0, 0, 0, 0);
+                v[u] = make_int4(a0 + o.x, a0 + o.y, a0 + o.z, a0 + o.w);
+            } else {
+                v[u] = on ? row[c4] : make_int4(0, 0, 0, 0);
+            }
         }
     };
     auto park_ids = [&](int buf, const int4 (&v)[U]) {
@@ -882,7 +917,7 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
     int pos = 0, mb = batch_len(starts, cnt, 0), buf = 0;
     {
         int4 v[U];
-        load_ids(hdr, 0, mb, __builtin_amdgcn_readlane(hdr.z, 0), v);
+        load_ids(hdr, 0, mb, __builtin_amdgcn_readlane(hdr.z, 0) & 1023, v);
         park_ids(0, v);
     }
     __syncthreads();
@@ -890,10 +925,16 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
     double a[RT][KW];
     for (;;) {
         const int32_t rp = __builtin_amdgcn_readlane(hdr.y, pos);
-        const int n = __builtin_amdgcn_readlane(hdr.z, pos), nrow = __builtin_amdgcn_readlane(hdr.w, pos);
-        if (rp != cur) {    // (uniform) this lane's A fragments of the new inverse
+        const int32_t packed = __builtin_amdgcn_readlane(hdr.z, pos);
+        const int n = packed & 1023, nrow = (packed >> 10) & 1023;
+        if (rp != cur) {    // (uniform) this lane's A fragments of the new inverse, and the representative's dof offsets
             const int32_t s0 = __builtin_amdgcn_readlane(hdr.x, pos);
             const double* __restrict__ src = inv + inv_ptr[s0];
+            {
+                const int32_t* __restrict__ ref = sub_dofs + (int64_t)rp * NMAX;
+                const int32_t r0 = ref[0];
+                if (tid < 16 * KW) soff[tid] = tid < n ? ref[tid] - r0 : 0;
+            }
 #pragma unroll
             for (int kk = 0; kk < KW; ++kk) {
                 const int c = 4 * (w + 4 * kk) + lk;
@@ -904,6 +945,8 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
                 }
             }
             cur = rp;
+            __syncthreads();    // soff is read below (next batch's ids); rare: once per run of a representative
+            soff_rep = rp;
         }
         // B fragments: entries of r at the dof ids of subdomain lj
         double bv[KW];
@@ -933,10 +976,10 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
                 starts_n = run_starts(hdr_n, cnt_n);
                 pos_n = 0;
                 mb_n = batch_len(starts_n, cnt_n, 0);
-                load_ids(hdr_n, 0, mb_n, __builtin_amdgcn_readlane(hdr_n.z, 0), v);
+                load_ids(hdr_n, 0, mb_n, __builtin_amdgcn_readlane(hdr_n.z, 0) & 1023, v);
             } else {
                 mb_n = batch_len(starts, cnt, pos_n);
-                load_ids(hdr, pos_n, mb_n, __builtin_amdgcn_readlane(hdr.z, pos_n), v);
+                load_ids(hdr, pos_n, mb_n, __builtin_amdgcn_readlane(hdr.z, pos_n) & 1023, v);
             }
         }
         ap_d4 acc[RT];
@@ -1246,6 +1289,7 @@ int schwarz_setup(fedd_ctx* c) {
     // ---- the order the apply walks the subdomains in: sorted by representative (stable: lattice order within one); with
     // several ranks and option "halo_overlap" the subdomains without ghost dofs first ----
     c->sw_nint = -1;
+    c->sw_nconf = 0;
     {
         const bool split = c->halo_overlap && restricted && (c->n_cols != c->n_rows || !c->halo.peers.empty());
         if (c->sw_dedupe || split) {
@@ -1257,7 +1301,7 @@ int schwarz_setup(fedd_ctx* c) {
             int32_t* iota = ord + 2 * nsub;
             int32_t* keys_in = ord + 3 * nsub;      // (the records overwrite this part afterwards)
             int32_t* n_int = ord + 8 * nsub + 4;
-            FEDD_HIP(hipMemsetAsync(n_int, 0, sizeof(int32_t), c->stream));
+            FEDD_HIP(hipMemsetAsync(n_int, 0, 2 * sizeof(int32_t), c->stream));     // interior subdomains | conforming ones
             hipLaunchKernelGGL(k_iota, gs, blk, 0, c->stream, iota, (int32_t)nsub);
             hipLaunchKernelGGL(k_order_key, gs, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p, (const int32_t*)c->d_sub_dofs.p, rep,
                                (int32_t)nsub, (int32_t)n_rows, split ? 1 : 0, keys_in, n_int);
@@ -1268,15 +1312,15 @@ int schwarz_setup(fedd_ctx* c) {
             FEDD_HIP(hipcub::DeviceRadixSort::SortPairs((void*)c->d_dense_ws.p, tmp_bytes, (const int32_t*)keys_in, keys_out,
                                                         (const int32_t*)iota, ord, (int)nsub, 0, 32, c->stream));
             // records (subdomain, representative, columns, owned rows) in that order: one 16-byte load per place
-            hipLaunchKernelGGL(k_pack_order, gs, blk, 0, c->stream, (const int32_t*)ord, rep, (const int32_t*)c->d_sub_n.p,
-                               (const int32_t*)c->d_sub_nown.p, (int32_t)nsub, (int4*)(ord + 4 * nsub));
+            hipLaunchKernelGGL(k_pack_order, dim3((unsigned)(((int64_t)nsub * 16 + 255) / 256)), blk, 0, c->stream, (const int32_t*)ord, rep,
+                               (const int32_t*)c->d_sub_n.p, (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,
+                               (int32_t)nsub, (int4*)(ord + 4 * nsub), n_int + 1);
             c->sw_order_off = 4 * (int64_t)nsub;
-            if (split) {
-                int32_t h = 0;
-                FEDD_HIP(hipMemcpyAsync(&h, n_int, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-                FEDD_HIP(hipStreamSynchronize(c->stream));
-                c->sw_nint = h;
-            }
+            int32_t h[2] = {0, 0};
+            FEDD_HIP(hipMemcpyAsync(h, n_int, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            FEDD_HIP(hipStreamSynchronize(c->stream));
+            if (split) c->sw_nint = h[0];
+            c->sw_nconf = h[1];
         }
     }
     // ---- slab offsets ----

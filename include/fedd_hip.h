@@ -296,6 +296,9 @@ int fedd_schwarz_unique(fedd_ctx* ctx, int64_t* n_unique);
 /* sum over this rank's subdomains of their sizes (owned + overlap dofs) and of their owned dofs: what one apply gathers
  * and scatters (byte model of the apply kernel in bench.py); either output may be NULL */
 int fedd_schwarz_sizes(fedd_ctx* ctx, int64_t* sum_sizes, int64_t* sum_owned);
+/* subdomains whose dof list is their representative's list shifted by a constant (every box of a class on a structured mesh):
+ * the matrix-core apply computes their dof ids from the representative's offsets and does not read their lists */
+int fedd_schwarz_conforming(fedd_ctx* ctx, int64_t* n_conforming);
 
 /* right-preconditioned restarted GMRES (replaces Thyra::solve on the Belos "Block GMRES"
  * LOWS, feddlib/problems/Solver/LinearSolver_def.hpp:72-135; parametersSolver.xml:5-15).
