@@ -30,7 +30,11 @@ static int body() {
         comm->backend()->recv((rank + size - 1) % size, rank, &in, 1);
         bad += in != 10.0 + (rank + size - 1) % size;
     }
-    std::cout << "rank " << rank << " of " << size << " bad " << bad << std::endl;
+    {   // one write per rank: the ranks may be threads of this process
+        static std::mutex out;
+        std::lock_guard<std::mutex> lk(out);
+        std::cout << "rank " << rank << " of " << size << " bad " << bad << std::endl;
+    }
     return bad;
 }
 
