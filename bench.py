@@ -483,6 +483,9 @@ def main():
                 "frac_hbm_peak_on_streamed_bytes": kern["spmv"]["GBs"] / HBM_PEAK_GBS,
                 "frac_measured_ceiling_on_streamed_bytes": (kern["spmv"]["GBs"] / read_ceiling) if read_ceiling else None,
                 "effective_frac_hbm_peak_on_parity_csr_bytes": (12.0 * nnz + 20.0 * nr) / kern["spmv"]["ms_per_launch"] / 1e6 / HBM_PEAK_GBS,
+                # the same launch priced on the compacted (value, column) stream it replaces when column patterns are in use
+                "effective_frac_hbm_peak_on_compacted_csr_bytes": (12.0 * info["spmv"]["nnz_streamed"] + 20.0 * nr)
+                                                                   / kern["spmv"]["ms_per_launch"] / 1e6 / HBM_PEAK_GBS,
                 "note": "the solver streams a compacted copy of the owned rows (exact zeros dropped: 8 of the 15 pattern "
                         "entries of an interior Kuhn-cube row, all but the 1 of a Dirichlet row); fractions are quoted on "
                         "the bytes actually streamed, the parity-CSR figure (SURVEY 8d model) is the effective rate; "
