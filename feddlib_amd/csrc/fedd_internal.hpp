@@ -193,7 +193,7 @@ struct fedd_ctx {
     fedd::DevBuf<int32_t> d_cs_rowptr, d_cs_col, d_cs_rows, d_cs_wincnt;
     fedd::DevBuf<double> d_cs_val;
     int spmv_pattern = 1;                       // option "spmv_pattern": rows that repeat their column offsets share a pattern (spmv.hip)
-    int spmv_pat_nu = 0;                        // option "spmv_pat_nu": 16-byte loads per lane of k_spmv_pat (2, 4, 6, 8; 0 = 4)
+    int spmv_pat_nu = 0;                        // option "spmv_pat_nu": 16-byte loads per lane of k_spmv_pat (2 ... 8; 0 = by the usual row length)
     int cs_pat_len = fedd::SPMV_PAT_LMAX;           // longest pattern in the table
     int cs_pat_nu = 8;                          // pattern SpMV: window = 256 * cs_pat_nu values
     fedd::DevBuf<int32_t> d_cs_prows;           // first row of each of those windows

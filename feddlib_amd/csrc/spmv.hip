@@ -607,7 +607,11 @@ static int spmv_compact_build(fedd_ctx* c) {
         c->cs_nexpl = h[2];
         c->cs_pat_len = h[4];
         if (c->cs_npat > 0) {
-            c->cs_pat_nu = c->spmv_pat_nu == 2 || c->spmv_pat_nu == 4 || c->spmv_pat_nu == 6 || c->spmv_pat_nu == 8 ? c->spmv_pat_nu : 4;
+            c->cs_pat_nu = (c->spmv_pat_nu >= 2 && c->spmv_pat_nu <= 8)
+                               ? c->spmv_pat_nu
+                               // about 256 rows per window, one per lane and one trip: 512 nu values ~ 256 x the usual row length
+                               // (214^3 cells, 6.8 entries per row: nu 3: 127 us, 4: 136, 5: 135, 6: 137)
+                               : (int)std::min<int64_t>(8, std::max<int64_t>(2, total / (2 * (int64_t)std::max<int32_t>(n, 1))));
             const int32_t nbp = (int32_t)(total / (512 * c->cs_pat_nu) + 1);
             FEDD_TRY(c->d_cs_prows.ensure((size_t)nbp + 1));
             hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nbp + 1 + 255) / 256)), dim3(256), 0, c->stream,
@@ -663,8 +667,11 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
 #define SPMV_PAT_NU(NT_)                 \
     switch (nu) {                        \
         case 2: SPMV_PAT(NT_, 2); break; \
+        case 3: SPMV_PAT(NT_, 3); break; \
         case 4: SPMV_PAT(NT_, 4); break; \
+        case 5: SPMV_PAT(NT_, 5); break; \
         case 6: SPMV_PAT(NT_, 6); break; \
+        case 7: SPMV_PAT(NT_, 7); break; \
         default: SPMV_PAT(NT_, 8); break; \
     }
             if (nt) { SPMV_PAT_NU(true) } else { SPMV_PAT_NU(false) }

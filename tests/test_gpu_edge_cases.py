@@ -262,7 +262,7 @@ def test_spmv_column_patterns_give_the_same_bits(fedd_lib, ctx, dim, M, dofs):
     assert ctx.spmv_info()["column_patterns"] == 0
     try:
         ctx.set_option("spmv_pattern", 2)
-        for nu in (2, 4, 6, 8):
+        for nu in (0, 2, 3, 4, 5, 6, 7, 8):
             ctx.set_option("spmv_pat_nu", nu)
             y1 = ctx.spmv(x)
             info = ctx.spmv_info()
