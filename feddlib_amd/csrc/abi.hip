@@ -705,6 +705,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "md2_gy") c->md2_gy = (int)value;
     else if (k == "spmv_pattern") { c->spmv_pattern = (int)value; c->cs_valid = false; }
     else if (k == "spmv_pat_nu") { c->spmv_pat_nu = (int)value; c->cs_valid = false; }
+    else if (k == "spmv_win_nu") { c->spmv_win_nu = (int)value; c->cs_valid = false; }
     else if (k == "md2_nch") c->md2_nch = (int)value;
     else if (k == "halo_overlap") { c->halo_overlap = (int)value; c->have_schwarz = false; }
     else if (k == "schwarz_big") c->sw_big = (int)value;

@@ -193,6 +193,8 @@ struct fedd_ctx {
     fedd::DevBuf<int32_t> d_cs_rowptr, d_cs_col, d_cs_rows, d_cs_wincnt;
     fedd::DevBuf<double> d_cs_val;
     int spmv_pattern = 1;                       // option "spmv_pattern": rows that repeat their column offsets share a pattern (spmv.hip)
+    int spmv_win_nu = 0;                        // option "spmv_win_nu": entries per lane of k_spmv_win on the compacted stream (4 ... 8; 0 = by row length)
+    int cs_win_nu = 8;
     int spmv_pat_nu = 0;                        // option "spmv_pat_nu": 16-byte loads per lane of k_spmv_pat (2 ... 8; 0 = by the usual row length)
     int cs_pat_len = fedd::SPMV_PAT_LMAX;           // longest pattern in the table
     int cs_pat_nu = 8;                          // pattern SpMV: window = 256 * cs_pat_nu values

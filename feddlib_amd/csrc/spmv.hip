@@ -113,13 +113,14 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__
 // that cache (spmv_nt = -1).  Also tried on the window kernel: gathering in the row phase from LDS-staged (val, col)
 // with 1 / 2 lanes per row (376 -> 386 / 391 us at 214^3): the gathers are not what limits it; in real traffic
 // (2.14 GB per launch, x fetched three times) the kernel runs at 0.91 of the read ceiling.
-template <bool NT>
+// NU = entries per lane: the window is 256 NU entries (8 = SP_CHUNK by default; option "spmv_win_nu" for the compacted stream).
+template <bool NT, int NU = SP_CHUNK / 256>
 __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                   const double* __restrict__ val, const double* __restrict__ x,
                                                   double* __restrict__ y, const int32_t* __restrict__ block_row,
                                                   int32_t nb, int32_t nnz, int32_t ovh) {
     extern __shared__ double prod[];
-    constexpr int NU = SP_CHUNK / 256, CH = SP_CHUNK;
+    constexpr int CH = 256 * NU;
     const int tid = threadIdx.x;
     const int32_t q = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
     const int32_t lb = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
@@ -565,10 +566,13 @@ static int spmv_compact_build(fedd_ctx* c) {
                        (const int32_t*)c->d_cs_wincnt.p, c->spmv_drop_tol, c->d_cs_rowptr.p, c->d_cs_col.p, c->d_cs_val.p);
     c->cs_tot32 = (int32_t)total;   // (lives in the context: the copy below is asynchronous)
     FEDD_HIP(hipMemcpyAsync(c->d_cs_rowptr.p + n, &c->cs_tot32, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    const int32_t nbc = (int32_t)(total / SP_CHUNK + 1);
+    // (unlike k_spmv_pat the per-entry kernel gains nothing from one-trip windows: 214^3 cells, nu 8 / 7 / 6 / 5: 180 / 183 /
+    // 184 / 184 us; 107^3: 24.2 -> 22.5 us with 6, 100^3: no difference -- 8 stays, the option is kept for A/B)
+    c->cs_win_nu = (c->spmv_win_nu >= 4 && c->spmv_win_nu <= 8) ? c->spmv_win_nu : 8;
+    const int32_t nbc = (int32_t)(total / (256 * c->cs_win_nu) + 1);
     FEDD_TRY(c->d_cs_rows.ensure((size_t)nbc + 1));
     hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nbc + 1 + 255) / 256)), dim3(256), 0, c->stream,
-                       (const int32_t*)c->d_cs_rowptr.p, n, nbc, c->d_cs_rows.p);
+                       (const int32_t*)c->d_cs_rowptr.p, n, nbc, c->d_cs_rows.p, 256 * c->cs_win_nu);
     // column patterns (see k_spmv_pat)
     c->cs_npat = 0;
     // (matrices that fit the Infinity Cache keep the per-entry kernel -- measured: 100^3 cells 20.5 us against 25 us --,
@@ -644,9 +648,10 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
     if (windowed && c->spmv_compact) {
         // the compacted stream (numerically zero entries left out): same kernel, fewer bytes
         if (!c->cs_valid) FEDD_TRY(spmv_compact_build(c));
-        const int32_t nbc = (int32_t)(c->cs_nnz / SP_CHUNK + 1);
+        const int wnu = c->cs_win_nu;
+        const int32_t nbc = (int32_t)(c->cs_nnz / (256 * wnu) + 1);
         const int32_t ovh = (int32_t)std::max<int64_t>(c->max_row_nnz, 1);
-        const size_t lds = (size_t)(SP_CHUNK + ovh) * sizeof(double);
+        const size_t lds = (size_t)(256 * wnu + ovh) * sizeof(double);
         const bool nt = c->spmv_nt < 0 ? 12.0 * (double)c->cs_nnz > 256.0 * 1024.0 * 1024.0 : c->spmv_nt != 0;
         ScopedTimer ts(c, FEDD_T_SPMV);
         if (c->cs_nnz == 0)
@@ -678,14 +683,23 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
 #undef SPMV_PAT_NU
 #undef SPMV_PAT
 #undef SPMV_PAT1
-        } else if (nt)
-            hipLaunchKernelGGL(k_spmv_win<true>, dim3((unsigned)nbc), dim3(256), lds, c->stream, (const int32_t*)c->d_cs_rowptr.p,
-                               (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, x, d_y_owned,
-                               (const int32_t*)c->d_cs_rows.p, nbc, (int32_t)c->cs_nnz, ovh);
-        else
-            hipLaunchKernelGGL(k_spmv_win<false>, dim3((unsigned)nbc), dim3(256), lds, c->stream, (const int32_t*)c->d_cs_rowptr.p,
-                               (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, x, d_y_owned,
-                               (const int32_t*)c->d_cs_rows.p, nbc, (int32_t)c->cs_nnz, ovh);
+        } else {
+#define SPMV_WIN(NT_, NU_)                                                                                                       \
+    hipLaunchKernelGGL((k_spmv_win<NT_, NU_>), dim3((unsigned)nbc), dim3(256), lds, c->stream, (const int32_t*)c->d_cs_rowptr.p, \
+                       (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, x, d_y_owned,                               \
+                       (const int32_t*)c->d_cs_rows.p, nbc, (int32_t)c->cs_nnz, ovh)
+#define SPMV_WIN_NU(NT_)                 \
+    switch (wnu) {                       \
+        case 4: SPMV_WIN(NT_, 4); break; \
+        case 5: SPMV_WIN(NT_, 5); break; \
+        case 6: SPMV_WIN(NT_, 6); break; \
+        case 7: SPMV_WIN(NT_, 7); break; \
+        default: SPMV_WIN(NT_, 8); break; \
+    }
+            if (nt) { SPMV_WIN_NU(true) } else { SPMV_WIN_NU(false) }
+#undef SPMV_WIN_NU
+#undef SPMV_WIN
+        }
         ts.stop();
         FEDD_HIP(hipGetLastError());
         return 0;
