@@ -1,6 +1,6 @@
 """Iteration counts of the fixed-grid (strong-scaling) split used by bench.py, with the N ranks as threads of
 one process on one GPU (capi.ThreadGroup; development aid -- times are meaningless, counts are not).
-usage: threads_scaling.py [global cells per direction] [ghost element layers: 1, 2 (overlap rows), 4 (whole boxes)] [box_kind]"""
+usage: threads_scaling.py [global cells per direction] [ghost element layers: 1, 2 (overlap rows), box width + 1 (whole boxes)] [box_kind] [nodes per box]"""
 import os
 import sys
 import threading
@@ -13,6 +13,7 @@ from feddlib_amd import capi  # noqa: E402
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 GHOSTS = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 BOX = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+TARGET = int(sys.argv[4]) if len(sys.argv) > 4 else 27
 DECOMP = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
 
 
@@ -31,7 +32,7 @@ def rank_main(group, rank, dec, cells, out):
         c.assemble(capi.FORM_LAPLACE)
         c.assemble_rhs([1.0])
         c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
-        c.schwarz_set_target(27, 1.0)
+        c.schwarz_set_target(TARGET, 1.0)
         if two:
             c.schwarz_set_coarse(0.0)
             c.schwarz_setup(1, capi.COMBINE_RESTRICTED, two_level=1, coarse_kind=capi.COARSE_Q1)
@@ -53,6 +54,6 @@ for N in (1, 2, 4, 8):
         t.start()
     for t in th:
         t.join()
-    print("ghost mode %d box_kind %d: N %d blocks %s of %s cells: one level %d its (%.1e), two levels %d its (%.1e)"
-          % (GHOSTS, BOX, N, "x".join(map(str, dec)), "x".join(map(str, cells)), out[0]["one"][0], out[0]["one"][1],
+    print("ghost layers %d box_kind %d nodes per box %d: N %d blocks %s of %s cells: one level %d its (%.1e), two levels %d its (%.1e)"
+          % (GHOSTS, BOX, TARGET, N, "x".join(map(str, dec)), "x".join(map(str, cells)), out[0]["one"][0], out[0]["one"][1],
              out[0]["two"][0], out[0]["two"][1]), flush=True)
