@@ -241,6 +241,7 @@ struct fedd_ctx {
     fedd::DevBuf<uint64_t> d_sw_fp;             // fingerprints [2 nsub] | hash table keys [2 tsize]
     fedd::DevBuf<int32_t> d_sw_order;           // subdomains sorted by representative [nsub] | sort scratch [2 nsub] | pad | records int4[nsub]
     int64_t sw_order_off = 0;                   // where the records start (in int32 units, 16-byte aligned)
+    fedd::DevBuf<int32_t> d_sw_replist;         // the representatives (the subdomains that are inverted)
     fedd::DevBuf<int32_t> d_sw_rep;             // representative [nsub] | sizes for the inversion [nsub] | slot [nsub] | table min [tsize]
     int sw_big = -1;                            // large-subdomain path: -1 = for merged block systems, 0 = never, 1 = always
     bool sw_big_active = false;                 // the current preconditioner was built by schwarz_setup_big

@@ -464,6 +464,12 @@ __global__ void k_pack_order(const int32_t* __restrict__ ord, const int32_t* __r
     if (conf && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(conf)) atomicAdd(n_conf, (int32_t)__builtin_popcountll(conf));
 }
 
+// the representatives (any order: every one is inverted by its own workgroup)
+__global__ void k_rep_list(const int32_t* __restrict__ rep, int32_t nsub, int32_t* __restrict__ list, int32_t* __restrict__ cnt) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nsub && rep[b] == b) list[atomicAdd(cnt, 1)] = b;
+}
+
 __global__ void k_fp_share(const int32_t* __restrict__ rep, int32_t nsub, int64_t* __restrict__ inv_ptr) {
     const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nsub) return;
@@ -518,12 +524,14 @@ __global__ __launch_bounds__(256, (T <= 7 ? 4 : 2)) void k_invert_reg(const int3
                                                        const double* __restrict__ val, int32_t n_rows,
                                                        int restricted, const int64_t* __restrict__ inv_ptr,
                                                        double* __restrict__ inv, int32_t* __restrict__ bad,
-                                                       int n_lo, int n_hi, int32_t p_off, int own_le) {
+                                                       int n_lo, int n_hi, int32_t p_off, int own_le,
+                                                       const int32_t* __restrict__ ids) {
     constexpr int NP = 16 * T;
     __shared__ int32_t sdof[NP];
     __shared__ double stage[16][NP + 1];
     __shared__ double colbuf[2][NP], rowbuf[2][NP];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // ids: the subdomains to invert (the representatives, when equal local matrices share an inverse); else all
+    const int b = ids ? ids[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
     const int n = sub_n[b];
     if (n <= n_lo || n > n_hi) return;  // another size class handles this subdomain
     const int no = sub_nown[b];
@@ -1340,14 +1348,27 @@ int schwarz_setup(fedd_ctx* c) {
     FEDD_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), c->stream));
     // size classes of the register-tiled kernel (n <= 16 T); anything larger falls back below
     {
-        const dim3 grid((unsigned)nsub);
+        // with shared inverses only the representatives are inverted: their list instead of one (idle) workgroup per
+        // subdomain and size class (ten launches over 166 375 workgroups were 0.8 ms of early exits)
+        const int32_t* rep_ids = nullptr;
+        int64_t n_inv_wg = nsub;
+        if (c->sw_dedupe && c->sw_nrep > 0 && c->sw_nrep < nsub) {
+            FEDD_TRY(c->d_sw_replist.ensure((size_t)c->sw_nrep + 1));
+            int32_t* cnt = c->d_flags.p + 8;
+            FEDD_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
+            hipLaunchKernelGGL(k_rep_list, dim3((unsigned)((nsub + 255) / 256)), blk, 0, c->stream, (const int32_t*)c->d_sw_rep.p,
+                               (int32_t)nsub, c->d_sw_replist.p, cnt);
+            rep_ids = c->d_sw_replist.p;
+            n_inv_wg = c->sw_nrep;
+        }
+        const dim3 grid((unsigned)n_inv_wg);
 #define INV_REG1(T, TA, LO, HI, OWN_LE)                                                                        \
     if (max_n > (LO))                                                                                          \
         hipLaunchKernelGGL((k_invert_reg<T, TA>), grid, blk, 0, c->stream, sub_n_inv,                           \
                            (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,                   \
                            (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p,                       \
                            (const double*)c->d_val.p, n_stored, restricted, (const int64_t*)c->d_inv_ptr.p,      \
-                           c->d_inv.p, d_bad, (LO), (HI), p_off, (OWN_LE))
+                           c->d_inv.p, d_bad, (LO), (HI), p_off, (OWN_LE), rep_ids)
         // restricted combine on a plain system: boxes with at most 32 owned dofs take the variant
         // that drops finished overlap rows from the update, the others the generic one
         const bool rows_only = restricted && !c->merged && c->inv_kind != 2;
