@@ -105,12 +105,22 @@ __global__ __launch_bounds__(64) void k_node_pattern(const int32_t* __restrict__
 }
 
 // fill pass when the count pass stashed its lists: stash[k][node] -> colind[rowptr[node] + k]
-__global__ void k_pattern_compact(const int32_t* __restrict__ stash, const int32_t* __restrict__ rowptr, int32_t n_own,
-                                  int32_t* __restrict__ colind) {
-    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_own) return;
-    const int32_t b = rowptr[r], len = rowptr[r + 1] - b;
-    for (int k = 0; k < len; ++k) colind[b + k] = stash[(int64_t)k * n_own + r];
+// A workgroup takes 128 rows, i.e. one contiguous run of colind: the lists are read coalesced ([k][node] layout), put in
+// place in LDS and written out as one coalesced stream (a lane writing its own row's entries made every store instruction
+// touch 64 cache lines: 1.33 ms for 148 M entries).  cap = longest list the stash holds.
+__global__ __launch_bounds__(128) void k_pattern_compact(const int32_t* __restrict__ stash, const int32_t* __restrict__ rowptr,
+                                                         int32_t n_own, int cap, int32_t* __restrict__ colind) {
+    extern __shared__ int32_t sh[];         // [128 * cap]
+    const int tid = threadIdx.x;
+    const int32_t R0 = blockIdx.x * 128, R1 = min(n_own, R0 + 128);
+    const int32_t b0 = rowptr[R0], total = rowptr[R1] - b0;
+    const int32_t r = R0 + tid;
+    if (r < R1) {
+        const int32_t b = rowptr[r] - b0, len = rowptr[r + 1] - rowptr[r];
+        for (int k = 0; k < len; ++k) sh[b + k] = stash[(int64_t)k * n_own + r];
+    }
+    __syncthreads();
+    for (int32_t i = tid; i < total; i += 128) colind[b0 + i] = sh[i];
 }
 
 // node pattern -> dof pattern, closed form (no scan): node-wise interleaved dofs
@@ -240,8 +250,11 @@ int build_pattern(fedd_ctx* c, int dofs, int block_mode) {
         ncol = c->d_itmp2.p;
     }
     if (stash) {
-        hipLaunchKernelGGL(k_pattern_compact, dim3((unsigned)((n_own + 255) / 256)), dim3(256), 0, c->stream,
-                           (const int32_t*)stash, (const int32_t*)nptr, n_own, ncol);
+        const size_t lds_c = (size_t)128 * (size_t)std::max(1, max_nn) * sizeof(int32_t);     // 128 rows of at most max_nn entries
+        if (lds_c > 64 * 1024)
+            FEDD_HIP(hipFuncSetAttribute((const void*)k_pattern_compact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+        hipLaunchKernelGGL(k_pattern_compact, dim3((unsigned)((n_own + 127) / 128)), dim3(128), lds_c, c->stream,
+                           (const int32_t*)stash, (const int32_t*)nptr, n_own, max_nn, ncol);
     } else {
         if (lds > 64 * 1024)
             FEDD_HIP(hipFuncSetAttribute((const void*)k_node_pattern<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
