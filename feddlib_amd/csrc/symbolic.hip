@@ -62,9 +62,19 @@ __global__ __launch_bounds__(64) void k_node_pattern(const int32_t* __restrict__
     const int32_t r = blockIdx.x * 64 + lane;
     if (r >= n_own) return;
     int len = 0;
+    int32_t seen0 = -1, seen1 = -1;     // the two most recent candidates: neighbouring elements repeat their nodes
     auto insert = [&](int32_t col) {
-        int pos = 0;
-        while (pos < len && lst[pos * 64 + lane] < col) ++pos;
+        if (col == seen0 || col == seen1) return;
+        seen1 = seen0;
+        seen0 = col;
+        // lower bound by bisection (lists of ~15-30 entries: 4-5 dependent LDS reads instead of ~len / 2)
+        int lo = 0, hi = len;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (lst[mid * 64 + lane] < col) lo = mid + 1;
+            else hi = mid;
+        }
+        const int pos = lo;
         if (pos < len && lst[pos * 64 + lane] == col) return;
         if (len < cap) {
             for (int k = len; k > pos; --k) lst[k * 64 + lane] = lst[(k - 1) * 64 + lane];
