@@ -81,11 +81,14 @@ extern "C" int fedd_ctx_create(fedd_ctx** out, int device, const void* nccl_uniq
             delete c;
             return 1;
         }
-        if (hipHostMalloc((void**)&c->h_pinned, 4096 * sizeof(double)) != hipSuccess) {
+        if (hipHostMalloc((void**)&c->h_pinned, 4096 * sizeof(double), hipHostMallocMapped) != hipSuccess) {
             set_error("fedd_ctx_create: pinned allocation failed");
             fedd_ctx_destroy(c);   // frees the stream too
             return 1;
         }
+        // the solver's small kernel writes its convergence numbers straight into this buffer (option "gmres_hostwrite" 0: copies)
+        if (hipHostGetDevicePointer((void**)&c->h_pinned_dev, c->h_pinned, 0) != hipSuccess) c->h_pinned_dev = nullptr;
+        c->h_pinned_map = c->h_pinned_dev;
         if (nranks > 1 && nccl_unique_id) {  // without an id: host-callback transport (tests only)
             ncclUniqueId id;
             memcpy(&id, nccl_unique_id, 128);
@@ -703,6 +706,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     } else if (k == "schwarz_dedupe") c->sw_dedupe = (int)value;
     else if (k == "apply_span") c->apply_span = (int)value;
     else if (k == "md2_gy") c->md2_gy = (int)value;
+    else if (k == "gmres_hostwrite") c->h_pinned_dev = value != 0 ? c->h_pinned_map : nullptr;
     else if (k == "spmv_pattern") { c->spmv_pattern = (int)value; c->cs_valid = false; }
     else if (k == "spmv_pat_nu") { c->spmv_pat_nu = (int)value; c->cs_valid = false; }
     else if (k == "spmv_win_nu") { c->spmv_win_nu = (int)value; c->cs_valid = false; }

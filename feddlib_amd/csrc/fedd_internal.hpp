@@ -278,6 +278,8 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_w;                   // [n_rows]
     fedd::DevBuf<double> d_part;                // dot partials
     fedd::DevBuf<double> d_small;               // H, cs, sn, g, h, scalars
+    double* h_pinned_map = nullptr;             // device pointer of h_pinned (kept while the option switches h_pinned_dev off)
+    double* h_pinned_dev = nullptr;             // the same buffer as the device sees it (nullptr: not mapped, copies are used)
     double* h_pinned = nullptr;                 // small pinned host mirror
     int gm_restart_alloc = 0;
     const double* gm_mask = nullptr;            // != nullptr: GMRES solves the constrained system (dofs with mask 0 held), see gmres.hip

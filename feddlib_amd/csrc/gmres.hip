@@ -353,7 +353,10 @@ struct Off2 {
 // The small algebra of a DCGS2 step (one workgroup): finalise column kc = k - 1 of H, rotate it,
 // update g and the residual, and prepare the coefficients of sweep 2 and the next first-pass column.
 // misc[0] = |g_k| (residual), misc[2] = beta (0: breakdown), cf = [s (m) | t (m) | 1/beta | c_last].
-__global__ __launch_bounds__(256) void k_dcgs2_small(double* __restrict__ S, Off o, Off2 o2, int k, int m) {
+// host_out (pinned host memory, device-visible): the three numbers the host's lagged convergence test reads -- written by
+// the kernel itself, so that no copy engine call sits in the stream between two iterations (8.7 us each)
+__global__ __launch_bounds__(256) void k_dcgs2_small(double* __restrict__ S, Off o, Off2 o2, int k, int m,
+                                                     double* __restrict__ host_out) {
     extern __shared__ double sm[];  // s[m] | t[m] | hc[m+2] | lcs[m] | lsn[m] | Hs[m+1]
     __shared__ double red[2][256];
     double* s = sm;
@@ -449,6 +452,12 @@ __global__ __launch_bounds__(256) void k_dcgs2_small(double* __restrict__ S, Off
         S[o.misc + 0] = fabs(sj * gj);
         S[o.misc + 1] = ib;
         S[o.misc + 2] = beta;
+        if (host_out) {
+            host_out[0] = fabs(sj * gj);
+            host_out[1] = ib;
+            host_out[2] = beta;
+            __threadfence_system();
+        }
     }
 }
 
@@ -691,7 +700,8 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
                 hipLaunchKernelGGL(k_reduce_cols, dim3(2 * k + 2), blk, 0, st, (const double*)c->d_part.p, S + o2.st, nblkd,
                                    (const int32_t*)nullptr);
                 FEDD_TRY(allreduce_sum(c, S + o2.st, 2 * k + 2));
-                hipLaunchKernelGGL(k_dcgs2_small, dim3(1), blk, (size_t)(6 * m + 8) * sizeof(double), st, S, o, o2, k, m);
+                hipLaunchKernelGGL(k_dcgs2_small, dim3(1), blk, (size_t)(6 * m + 8) * sizeof(double), st, S, o, o2, k, m,
+                                   c->h_pinned_dev ? c->h_pinned_dev + 4 * (j & 1) : (double*)nullptr);
                 if (k < m) {  // the last step of a cycle needs no further basis vector
                     ScopedTimer tu(c, FEDD_T_GS_UPDATE);
                     hipLaunchKernelGGL(k_axpy2, dim3(nblk2), blk, 0, st, V, ldv, n, k, (const double*)(S + o2.cf), m, u,
@@ -700,7 +710,8 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
                 }
                 t.stop();
             }
-            FEDD_HIP(hipMemcpyAsync(c->h_pinned + 4 * (j & 1), S + o.misc, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (!c->h_pinned_dev)
+                FEDD_HIP(hipMemcpyAsync(c->h_pinned + 4 * (j & 1), S + o.misc, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
             FEDD_HIP(hipEventRecord(ev[j & 1], st));
             ++issued;
             ++queued;
