@@ -838,7 +838,17 @@ static int gdsw_setup(fedd_ctx* c) {
     // default: one cell per 1000 nodes, at most 8^3 (scalar) / 5^3 (vector) cells: (2 g - 1)^dim * dofs coarse dofs
     const bool reduced = c->co_kind == FEDD_COARSE_RGDSW;
     double target = c->co_cells_target;
-    if (!(target > 0)) target = std::min(reduced ? 1728.0 : (dofs == 1 ? 512.0 : 125.0), std::max(1.0, std::floor(n_global / 1000.0)));
+    // RGDSW has (g - 1)^dim * dofs coarse dofs only: one cell per 400 nodes, as many as the dense coarse solver takes
+    // (vector problems in 3D: 13^3 cells = 5184 coarse dofs; cfg 5's share: 123 outer iterations against 186 with 9^3 cells,
+    // setup 1.6 against 1.7 s -- profiles/r02_gdsw_tol_sweep.txt)
+    if (!(target > 0)) {
+        if (reduced) {
+            const int gmax = (int)std::floor(std::pow((double)COARSE_MAX_DOFS / dofs, 1.0 / dim)) + 1;
+            target = std::min(std::pow((double)std::min(gmax, 20), (double)dim), std::max(1.0, std::floor(n_global / 400.0)));
+        } else {
+            target = std::min(dofs == 1 ? 512.0 : 125.0, std::max(1.0, std::floor(n_global / 1000.0)));
+        }
+    }
     CoarseGeom cg;
     cg.dim = dim;
     cg.reduced = reduced ? 1 : 0;
