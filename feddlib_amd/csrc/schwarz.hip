@@ -937,6 +937,11 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
             }
         }
     };
+    // a batch is "direct" when its subdomains conform and the offsets of its representative are the ones in soff: its
+    // ids are then formed where they are used (first dof + offset) and never pass through the LDS lists
+    auto is_direct = [&](const int4& h, int pos_) {
+        return ((__builtin_amdgcn_readlane(h.z, pos_) >> 20) & 1) && __builtin_amdgcn_readlane(h.y, pos_) == soff_rep;
+    };
     uint64_t starts = run_starts(hdr, cnt);
     int pos = 0, mb = batch_len(starts, cnt, 0), buf = 0;
     {
@@ -946,6 +951,7 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
     }
     __syncthreads();
     int32_t cur = -1;
+    bool direct = false;        // (the first batch of a workgroup reads its lists: soff is not loaded yet)
     double a[RT][KW];
     for (;;) {
         const int32_t rp = __builtin_amdgcn_readlane(hdr.y, pos);
@@ -974,17 +980,30 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         }
         // B fragments: entries of r at the dof ids of subdomain lj
         double bv[KW];
+        int32_t od[RT];     // the rows this lane writes at the end: result register w of tile t = row 16 t + lk + 4 w of subdomain lj
+        if (direct) {       // (uniform over the workgroup)
+            const int32_t a0 = __shfl(hdr.w, pos + lj, 64);
 #pragma unroll
-        for (int kk = 0; kk < KW; ++kk) {
-            const int c = 4 * (w + 4 * kk) + lk;
-            bv[kk] = (lj < mb && c < n) ? r[ids[buf][lj][c]] : 0.0;
-        }
-        // the rows this lane writes at the end: result register w of tile t = row 16 t + lk + 4 w of subdomain lj
-        int32_t od[RT];
+            for (int kk = 0; kk < KW; ++kk) {
+                const int c = 4 * (w + 4 * kk) + lk;
+                bv[kk] = (lj < mb && c < n) ? r[a0 + soff[c]] : 0.0;
+            }
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const int i = 16 * t + lk + 4 * w;
-            od[t] = (lj < mb && i < nrow) ? ids[buf][lj][i] : -1;
+            for (int t = 0; t < RT; ++t) {
+                const int i = 16 * t + lk + 4 * w;
+                od[t] = (lj < mb && i < nrow) ? a0 + soff[i] : -1;
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk) {
+                const int c = 4 * (w + 4 * kk) + lk;
+                bv[kk] = (lj < mb && c < n) ? r[ids[buf][lj][c]] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const int i = 16 * t + lk + 4 * w;
+                od[t] = (lj < mb && i < nrow) ? ids[buf][lj][i] : -1;
+            }
         }
         // where the next batch is: in this chunk or at the start of the next one; its dof lists are requested now
         int pos_n = pos + mb;
@@ -994,16 +1013,19 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         int mb_n = 0;
         uint64_t starts_n = starts;
         int cnt_n = cnt;
+        bool direct_n = false;
         if (!last) {
             if (cross) {
                 cnt_n = min(64, p_end - (p_chunk + 64));
                 starts_n = run_starts(hdr_n, cnt_n);
                 pos_n = 0;
                 mb_n = batch_len(starts_n, cnt_n, 0);
-                load_ids(hdr_n, 0, mb_n, __builtin_amdgcn_readlane(hdr_n.z, 0) & 1023, v);
+                direct_n = is_direct(hdr_n, 0);
+                if (!direct_n) load_ids(hdr_n, 0, mb_n, __builtin_amdgcn_readlane(hdr_n.z, 0) & 1023, v);
             } else {
                 mb_n = batch_len(starts, cnt, pos_n);
-                load_ids(hdr, pos_n, mb_n, __builtin_amdgcn_readlane(hdr.z, pos_n) & 1023, v);
+                direct_n = is_direct(hdr, pos_n);
+                if (!direct_n) load_ids(hdr, pos_n, mb_n, __builtin_amdgcn_readlane(hdr.z, pos_n) & 1023, v);
             }
         }
         ap_d4 acc[RT];
@@ -1024,7 +1046,7 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         for (int t = 0; t < RT; ++t)
             if (od[t] >= 0) z[od[t]] = ((part[0][t][w][lane] + part[1][t][w][lane]) + part[2][t][w][lane]) + part[3][t][w][lane];
         if (last) break;
-        park_ids(buf ^ 1, v);
+        if (!direct_n) park_ids(buf ^ 1, v);
         if (cross) {        // (uniform) next chunk: its records were requested a chunk ago; request the one after it
             p_chunk += 64;
             hdr = hdr_n;
@@ -1032,6 +1054,7 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         }
         __syncthreads();    // part and ids[buf] are rewritten by the next batch; ids[buf ^ 1] is complete
         buf ^= 1;
+        direct = direct_n;
         pos = pos_n;
         mb = mb_n;
         starts = starts_n;
