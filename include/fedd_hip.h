@@ -316,7 +316,11 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
  * local matrices, else the flat streaming kernel), 1 = strided, 2 = flat without the compact LDS layout, 4 = matrix-core
  * kernel whenever the inverses are shared (any number of subdomains); "apply_span" places per workgroup of that kernel
  * (multiples of 64; 0 = 64 / 128 by the number of subdomains); "md2_gy" column groups in flight per row block of the
- * Gram-Schmidt dot sweep (0 = by vector length); "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
+ * Gram-Schmidt dot sweep (0 = by vector length), "md2_nch" its 512-row chunks per workgroup (2 or 4; default 4);
+ * "gmres_hostwrite" 1 (default) = the solver's small kernel writes the three numbers of the host's lagged convergence test
+ * into mapped pinned memory itself, 0 = an asynchronous copy per iteration;
+ * "spmv_pattern" 1 (default) = column patterns for matrices beyond the Infinity Cache (fedd_spmv_patterns), 2 = for every
+ * matrix, 0 = off; "spmv_pat_nu" / "spmv_win_nu" window sizes of the pattern / per-entry SpMV kernels (0 = default); "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
  * matrix cores, 2 = scalar-pivot without dropping rows;
  * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes;
  * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank;
