@@ -714,3 +714,51 @@ def test_interior_first_order_with_the_ghost_import_on_a_second_stream(fedd_lib)
         za, zb = o["res"][(1, 4, 1)][0], o["res"][(0, 0, 1)][0]
         np.testing.assert_allclose(za, zb, rtol=0, atol=1e-11 * np.abs(zb).max())
 
+
+def _thread_rank_patterns(capi, group, rank, dec, M, out, errs):
+    try:
+        world = group.world
+        m = capi.structured_mesh(3, dec, [M] * 3, rank, ghosts=4)
+        c = capi.Context(device=0, rank=rank, nranks=world, nccl_id=None)
+        c.mesh_set_dict(m)
+        c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, [M] * 3, m["gid_rep"]))
+        c.comm_set_thread_group(group)
+        c.pattern_build(1, capi.BLOCK_SCALAR)
+        c.assemble(capi.FORM_LAPLACE)
+        c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+        xg = np.random.default_rng(21).standard_normal(m["n_global"])
+        c.set_option("spmv_pattern", 0)
+        y0 = c.spmv(xg[m["gid_uni"]])
+        c.set_option("spmv_pattern", 2)
+        y1 = c.spmv(xg[m["gid_uni"]])
+        out[rank] = dict(y0=y0, y1=y1, info=c.spmv_info())
+        c.close()
+    except Exception as e:      # pragma: no cover
+        import traceback
+        errs.append("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+        try:
+            group._barrier.abort()
+        except Exception:
+            pass
+
+
+def test_spmv_column_patterns_with_ghost_columns(fedd_lib):
+    """The column patterns of the SpMV stream on several ranks: the offsets of rows at a rank boundary reach into the
+    ghost part of the column space (other offsets, more patterns, or explicit columns) -- the product stays the
+    per-entry kernel's bit for bit."""
+    import threading
+    dec, M = (1, 2, 2), 10
+    group = fedd_lib.ThreadGroup(4)
+    out, errs = [None] * 4, []
+    th = [threading.Thread(target=_thread_rank_patterns, args=(fedd_lib, group, r, dec, M, out, errs)) for r in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, "\n".join(errs)
+    used = 0
+    for o in out:
+        assert o is not None and np.array_equal(o["y0"], o["y1"])
+        used += o["info"]["column_patterns"] > 0
+    assert used >= 1        # (at least one rank's rows repeat enough for the dictionary to be used)
+
