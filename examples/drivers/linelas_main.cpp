@@ -33,7 +33,8 @@ typedef default_no NO;
 
 using namespace FEDD;
 
-int main(int argc, char* argv[]) {
+// the body every rank runs (the reference's main between MPI_Init and MPI_Finalize)
+static int run(int argc, char* argv[]) {
     std::string xmlProblemFile = "parametersProblem.xml", xmlPrecFile = "parametersPrec.xml", xmlSolverFile = "parametersSolver.xml";
     std::string outFile = "solutionLinElas.txt";
     for (int i = 1; i < argc; ++i) {
@@ -44,11 +45,14 @@ int main(int argc, char* argv[]) {
             return false;
         };
         if (val("problemfile", xmlProblemFile) || val("precfile", xmlPrecFile) || val("solverfile", xmlSolverFile) || val("out", outFile)) continue;
+        std::string tmp;
+        if (val("ranks-as-threads", tmp)) continue;     // handled by main
         std::cerr << "unknown option " << a << std::endl;
         return 2;
     }
     try {
-        Teuchos::RCP<const Teuchos::Comm<int> > comm = Teuchos::rcp(new Teuchos::Comm<int>(0, 1));
+        Teuchos::RCP<const Teuchos::Comm<int> > comm = Teuchos::DefaultComm<int>::getComm();
+        const bool root = comm->getRank() == 0;
         // steadyLinElas_Perf/main.cpp:114-115: every FEDD timer goes into one stacked timer, reported at the end
         Teuchos::RCP<Teuchos::StackedTimer> stackedTimer = Teuchos::rcp(new Teuchos::StackedTimer("Steady Linear Elasticity Performance Test"));
         Teuchos::TimeMonitor::setStackedTimer(stackedTimer);
@@ -110,17 +114,20 @@ int main(int argc, char* argv[]) {
             }
         }
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        std::cout << "iterations " << its << " relres " << linElas.getLastRelativeResidual() << std::endl;
-        std::cout << "Solve Problem " << secs << " s" << std::endl;
+        if (root) {
+            std::cout << "iterations " << its << " relres " << linElas.getLastRelativeResidual() << std::endl;
+            std::cout << "Solve Problem " << secs << " s" << std::endl;
+        }
 
         Teuchos::RCP<const MultiVector<SC, LO, GO, NO> > exportSolution = linElas.getSolution()->getBlock(0);
-        std::ofstream out(outFile);
+        // several ranks: every rank writes the entries of its unique map (<out>.<rank>)
+        std::ofstream out(comm->getSize() > 1 ? outFile + "." + std::to_string(comm->getRank()) : outFile);
         out << std::setprecision(17);
         auto map = exportSolution->getMap();
         auto data = exportSolution->getData(0);
         for (size_t i = 0; i < data.size(); ++i) out << map->getGlobalElement((LO)i) << " " << data[i] << "\n";
 
-        if (parameterListAll->sublist("General").get("ParaViewExport", false)) {       // main.cpp:228-240
+        if (comm->getSize() == 1 && parameterListAll->sublist("General").get("ParaViewExport", false)) {       // main.cpp:228-240
             Teuchos::RCP<ExporterParaView<SC, LO, GO, NO> > exPara(new ExporterParaView<SC, LO, GO, NO>());
             exPara->setup("displacements", domain->getMesh(), discType);
             exPara->addVariable(exportSolution, "values", "Vector", dim, domain->getMapUnique());
@@ -131,10 +138,28 @@ int main(int argc, char* argv[]) {
         stackedTimer->stop("Steady Linear Elasticity Performance Test");                 // main.cpp:245-249
         Teuchos::StackedTimer::OutputOptions options;
         options.output_fraction = options.output_histogram = options.output_minmax = true;
-        stackedTimer->report(std::cout, comm, options);
+        if (root) stackedTimer->report(std::cout, comm, options);
     } catch (const std::exception& e) {
         std::cerr << "exception: " << e.what() << std::endl;
         return 1;
     }
     return 0;
+}
+
+// ranks = processes under a launcher (RANK / WORLD_SIZE and FEDD_RENDEZVOUS in the environment, RCCL between the GPUs),
+// or, with --ranks-as-threads=N, N threads of this process sharing one GPU (functional runs of the N > 1 path)
+int main(int argc, char* argv[]) {
+    Teuchos::GlobalMPISession mpiSession(&argc, &argv);
+    int threads = 0;
+    for (int i = 1; i < argc; ++i)
+        if (std::strncmp(argv[i], "--ranks-as-threads=", 19) == 0) threads = std::atoi(argv[i] + 19);
+    if (threads > 1) {
+        try {
+            return Teuchos::runAsRanks(threads, [&](int) { return run(argc, argv); });
+        } catch (const std::exception& e) {
+            std::cerr << "exception: " << e.what() << std::endl;
+            return 1;
+        }
+    }
+    return run(argc, argv);
 }

@@ -546,8 +546,9 @@ public:
     }
     static void report(std::ostream& os) { summarize(os); }
 private:
-    static std::map<std::string, RCP<Time>>& registry() { static std::map<std::string, RCP<Time>> r; return r; }
-    static RCP<StackedTimer>& stacked() { static RCP<StackedTimer> s; return s; }
+    // per thread: with the ranks as threads of one process (runAsRanks) every rank has its own timers, like every MPI process
+    static std::map<std::string, RCP<Time>>& registry() { static thread_local std::map<std::string, RCP<Time>> r; return r; }
+    static RCP<StackedTimer>& stacked() { static thread_local RCP<StackedTimer> s; return s; }
     Time* t_;
 };
 

@@ -232,6 +232,30 @@ def test_reference_steady_linelas_perf_xml_files(linelas_driver, tmp_path):
     assert "FEDD - device - schwarz apply:" in log and "FEDD - device - assemble:" in log and "Remainder:" in log
 
 
+def test_reference_steady_linelas_perf_on_eight_ranks(linelas_driver, tmp_path):
+    """The same parameter files the way the reference's CMakeLists runs them: 8 ranks (N = 2 subdomain blocks per direction,
+    H/h = 4), here as threads of the driver on one GPU.  Displacements of the 9^3-node cube against the one-rank oracle
+    system; the stacked-timer report comes from rank 0."""
+    out = tmp_path / "sol.txt"
+    r = subprocess.run([linelas_driver, "--problemfile=%s" % os.path.join(LINELAS_XML, "parametersProblem.xml"),
+                        "--precfile=%s" % os.path.join(LINELAS_XML, "parametersPrec.xml"),
+                        "--solverfile=%s" % os.path.join(LINELAS_XML, "parametersSolver.xml"), "--out=%s" % out,
+                        "--ranks-as-threads=8"], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    mt = re.search(r"iterations (\d+) relres (\S+)", r.stdout)
+    assert mt and float(mt.group(2)) <= 1e-6, r.stdout
+    m = fo.build_mesh_structured(3, 1, 8)
+    A_bc, rhs_bc, _, _, _ = fo.linelas_problem(m, 2.0e6, 0.4, f=(0.0, 1.0, 0.0), bc_flags=(2,))
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    x = np.full(xd.shape[0], np.nan)
+    for rank in range(8):
+        part = np.loadtxt(str(out) + ".%d" % rank, ndmin=2)
+        x[part[:, 0].astype(int)] = part[:, 1]
+    assert not np.isnan(x).any()
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-4 * np.abs(xd).max())      # tolerance-limited (1e-6 residual)
+    assert r.stdout.count("Steady Linear Elasticity Performance Test:") == 1
+
+
 def test_linelas_two_level_tight_tolerance(linelas_driver, tmp_path):
     prob = tmp_path / "p.xml"
     prob.write_text(open(os.path.join(LINELAS_XML, "parametersProblem.xml")).read()
