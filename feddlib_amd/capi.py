@@ -91,6 +91,8 @@ SIGNATURES = {
     "fedd_timing_enable": [C.c_void_p, C.c_int],
     "fedd_timing_reset": [C.c_void_p],
     "fedd_timing_get": [C.c_void_p, C.c_int, _f64p, _i64p],
+    "fedd_timing_get_sampled": [C.c_void_p, C.c_int, _f64p, _i64p, _f64p],
+    "fedd_gmres_info": [C.c_void_p, _ip, _ip, _ip, _ip],
     "fedd_read_bandwidth": [C.c_void_p, C.c_int64, C.c_int, _f64p],
     "fedd_rccl_selftest": [C.c_void_p, C.c_int, _f64p],
     "fedd_halo_plan_sizes": [C.c_void_p, _ip, _i64p, _i64p],
@@ -545,6 +547,20 @@ class Context:
             _chk(self._L.fedd_timing_get(self._h, i, C.byref(ms), C.byref(n)))
             out[name] = (ms.value, n.value)
         return out
+
+    def timing_get_sampled(self):
+        """per class: (device ms, launches, algorithmic bytes) of the launches that were actually timed"""
+        out = {}
+        for i, name in enumerate(TIMER_NAMES):
+            ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+            _chk(self._L.fedd_timing_get_sampled(self._h, i, C.byref(ms), C.byref(n), C.byref(b)))
+            out[name] = (ms.value, n.value, b.value)
+        return out
+
+    def gmres_info(self):
+        k, s, nb, nc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _chk(self._L.fedd_gmres_info(self._h, C.byref(k), C.byref(s), C.byref(nb), C.byref(nc)))
+        return {"kind": k.value, "s": s.value, "blocks": nb.value, "cut_blocks": nc.value}
 
     def read_bandwidth(self, nbytes=2 << 30, reps=10):
         """GB/s of a read-only stream on this GPU (roofline calibration)."""

@@ -719,7 +719,16 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "asm_dbg") c->asm_dbg = (int)value;
     else if (k == "apply_kind") c->apply_kind = (int)value;
     else if (k == "inv_kind") c->inv_kind = (int)value;
-    else if (k == "gmres_kind") c->gmres_kind = (int)value;
+    else if (k == "gmres_kind") {
+        FEDD_CHECK(value == 0 || value == 1 || value == 2, "fedd_set_option: gmres_kind %g", value);
+        c->gmres_kind = (int)value;
+    } else if (k == "gmres_s") {
+        FEDD_CHECK(value >= 1 && value <= 8, "fedd_set_option: gmres_s %g (1 ... 8)", value);
+        c->gmres_s = (int)value;
+    } else if (k == "gmres_chol_tol") {
+        FEDD_CHECK(value > 0.0 && value < 1.0, "fedd_set_option: gmres_chol_tol %g", value);
+        c->gmres_chol_tol = value;
+    }
     else if (k == "ghost_overlap") c->ghost_overlap = (int)value;
     else FEDD_CHECK(false, "fedd_set_option: unknown key '%s'", key);
     return 0;
@@ -741,6 +750,7 @@ extern "C" int fedd_timing_reset(fedd_ctx* c) {
         c->timers[t].total_ms = 0;
         c->timers[t].launches = 0;
         c->timers[t].seen = 0;
+        c->timers[t].bytes = 0;
     }
     return 0;
 }
@@ -754,6 +764,27 @@ extern "C" int fedd_timing_get(fedd_ctx* c, int timer, double* total_ms, int64_t
     const auto& s = c->timers[timer];
     if (total_ms) *total_ms = s.launches > 0 ? s.total_ms * (double)s.seen / (double)s.launches : 0.0;
     if (launches) *launches = s.seen;
+    return 0;
+}
+
+extern "C" int fedd_timing_get_sampled(fedd_ctx* c, int timer, double* sampled_ms, int64_t* sampled_launches, double* sampled_bytes) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(timer >= 0 && timer < FEDD_T_COUNT, "fedd_timing_get_sampled: timer %d", timer);
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    FEDD_TRY(timing_flush(c));
+    const auto& s = c->timers[timer];
+    if (sampled_ms) *sampled_ms = s.total_ms;
+    if (sampled_launches) *sampled_launches = s.launches;
+    if (sampled_bytes) *sampled_bytes = s.bytes;
+    return 0;
+}
+
+extern "C" int fedd_gmres_info(fedd_ctx* c, int* kind, int* s, int* blocks, int* cut_blocks) {
+    FEDD_CHECK(c, "fedd_gmres_info: null context");
+    if (kind) *kind = c->gmres_kind;
+    if (s) *s = c->gmres_s;
+    if (blocks) *blocks = c->gmres_blocks;
+    if (cut_blocks) *cut_blocks = c->gmres_cut_blocks;
     return 0;
 }
 

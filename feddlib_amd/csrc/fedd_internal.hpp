@@ -120,6 +120,7 @@ struct TimerSlot {
     double total_ms = 0.0;
     int64_t launches = 0;   // launches that were timed
     int64_t seen = 0;       // launches that passed through (timed or not)
+    double bytes = 0.0;     // algorithmic bytes of the timed launches (classes whose launch sites state them)
     struct Pair {
         hipEvent_t first, second;
         bool cont;          // second half of a launch that was interrupted (e.g. by a collective): time, not a launch
@@ -218,7 +219,10 @@ struct fedd_ctx {
     int apply_kind = 0;                         // restricted apply: 0 = flat streaming kernel, 1 = strided (A/B)
     int inv_kind = 0;                           // local inverses: 0 = scalar-pivot kernel (drops finished rows), 1 = MFMA block sweep, 2 = scalar-pivot, all rows (A/B)
     int ghost_overlap = 1;                      // subdomains may contain ghost dofs (identity rows): 1 = yes (A/B)
-    int gmres_kind = 0;                         // Gram-Schmidt: 0 = delayed second pass (DCGS2), 1 = two passes (CGS2)
+    int gmres_kind = 2;                         // Gram-Schmidt: 0 = delayed second pass (DCGS2), 1 = two passes (CGS2), 2 = s-step blocks (BCGS-PIP2)
+    int gmres_s = 8;                            // s-step GMRES: Krylov vectors per block (1 ... 8)
+    double gmres_chol_tol = 1e-13;              // ... a block is cut where the squared sine of a new vector against its predecessors falls to this
+    int gmres_blocks = 0, gmres_cut_blocks = 0; // ... blocks / blocks that were cut in the last solve
     fedd::DevBuf<int32_t> d_node_bin;           // [n_own] compact bin id of each owned node
     fedd::DevBuf<int32_t> d_bin_ptr, d_bin_nodes;   // [nsub+1], [n_own]
     fedd::DevBuf<int32_t> d_sub_n, d_sub_nown;  // [nsub] total / owned dofs of each subdomain
@@ -314,12 +318,18 @@ struct ScopedTimer {
                                        timer == FEDD_T_ORTHO || timer == FEDD_T_COARSE_APPLY ||
                                        timer == FEDD_T_HALO || timer == FEDD_T_ALLREDUCE || timer == FEDD_T_GS_DOT ||
                                        timer == FEDD_T_GS_UPDATE;
+            // (the s-step solver launches its sweeps once per block, each over a different number of columns: all timed)
+            const bool block_sweeps = c->gmres_kind == 2 && (timer == FEDD_T_ORTHO || timer == FEDD_T_GS_DOT || timer == FEDD_T_GS_UPDATE);
             const int64_t k = c->timers[id].seen++;
-            if (per_iteration && c->timing_stride > 1 && k % c->timing_stride != 0) return;
+            if (per_iteration && !block_sweeps && c->timing_stride > 1 && k % c->timing_stride != 0) return;
             sampled = true;
             if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
                 (void)hipEventRecord(a, c->stream);
         }
+    }
+    // algorithmic bytes of this launch (counted when the launch is timed)
+    void bytes(double nbytes) {
+        if (sampled && !cont) c->timers[id].bytes += nbytes;
     }
     void stop() {
         if (c->timing && a && b) {

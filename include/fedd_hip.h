@@ -307,6 +307,9 @@ int fedd_schwarz_conforming(fedd_ctx* ctx, int64_t* n_conforming);
  * count the way Problem::solve does (its_out). */
 int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rtol, int max_it,
                int restart, int use_prec, int* its_out, double* relres_out);
+/* the orthogonalisation in use ("gmres_kind") and, for the s-step form, its block length and the blocks of the last solve
+ * (all, and those that were cut short because the block basis became numerically dependent); outputs may be NULL */
+int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_blocks);
 
 /* tuning knobs (A/B tests), 0 is the default of each: "spmv_kind" 0 = CSR-window (CSR-stream when a row has more than 256 entries), 1 = row-per-lane-group, 2 = CSR-stream;
  * "asm_kind" 0 = pair-parallel assembly (slot-addressed accumulation for the block forms -- elasticity, B / B^T --, slot sweep for
@@ -322,7 +325,13 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
  * "spmv_pattern" 1 (default) = column patterns for matrices beyond the Infinity Cache (fedd_spmv_patterns), 2 = for every
  * matrix, 0 = off; "spmv_pat_nu" / "spmv_win_nu" window sizes of the pattern / per-entry SpMV kernels (0 = default); "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
  * matrix cores, 2 = scalar-pivot without dropping rows;
- * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes;
+ * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes, 2 = s-step GMRES: the
+ * basis grows "gmres_s" (1 ... 8, default 8) vectors at a time and each block is orthogonalised by block Gram-Schmidt with two
+ * passes (four sweeps over the basis and two reductions per block instead of two sweeps and one reduction per iteration; same
+ * iterates as 0 / 1 in exact arithmetic; a block is cut where the squared sine of a new vector against its predecessors falls
+ * to "gmres_chol_tol", default 1e-13; the convergence claim is checked against the true residual and the residual returned is
+ * the true one; tolerances below 1e-9 / 1e-11 take blocks of at most 5 / 3 vectors, because the recurrence of a longer block
+ * loses touch with the true residual there), see fedd_gmres_info;
  * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank;
  * "asm_lds_kb" (default 37) = LDS budget in KB of the assembly kernel's contribution park, i.e. rows per workgroup;
  * "spmv_nt" 1 = the window SpMV streams the matrix non-temporally (x then survives in L2 between node planes:
@@ -351,6 +360,10 @@ int fedd_set_option(fedd_ctx* ctx, const char* key, double value);
 int fedd_timing_enable(fedd_ctx* ctx, int on);
 int fedd_timing_reset(fedd_ctx* ctx);
 int fedd_timing_get(fedd_ctx* ctx, int timer, double* total_ms, int64_t* launches);
+/* the launches of a class that were actually timed: their device time, their number and the algorithmic bytes their launch
+ * sites stated (Gram-Schmidt sweeps: 8 bytes x rows x columns read and written; 0 for classes that state none): the
+ * achieved-bandwidth figure of a class is sampled_bytes / sampled_ms, whatever the sampling stride */
+int fedd_timing_get_sampled(fedd_ctx* ctx, int timer, double* sampled_ms, int64_t* sampled_launches, double* sampled_bytes);
 /* calibration for the roofline figures: GB/s of a read-only stream over a scratch buffer of `bytes` (16-byte
  * non-temporal loads, `reps` launches back to back, best of three batches) on this GPU, i.e. the ceiling that
  * the measured fractions of the 8 TB/s spec can be compared with ("of spec" and "of

