@@ -54,6 +54,8 @@ def parse():
     # (profiles/r02_one_level_sweep_214_shared.txt: 248 ms against 312 ms for 27-node boxes; 145 against 178 iterations)
     ap.add_argument("--target", type=int, default=64, help="nodes per Schwarz subdomain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1: skip the extra entries per_gpu_share_n8, cfg5_share_one_gpu and cfg4_one_gpu")
     ap.add_argument("--no-two-level", action="store_true", help="skip the extra two-level measurement")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="development only: run the N > 1 path with all ranks on GPU 0, gloo + the library's "
@@ -100,13 +102,31 @@ def _recorded_full_cpu_run(full_cells, target):
     return None
 
 
+def host_cores():
+    """the cores this process may run on (the box's CPU share; os.cpu_count() is the whole host)"""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_run(a, M, nthr):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c
     return oracle_c.run_laplace3d(M, a.target, a.rtol, a.restart, a.max_it, threads=nthr)
 
 
-def cpu_baseline(a, full_cells, gpu_its, full=False):
+def cpu_baseline(a, full_cells, gpu_its, full=False, nthr=0):
     """The CPU restatement (oracle/oracle.c, kind 'port': C/OpenMP, the same driver sequence, preconditioner
     definition and tolerance as the GPU run -- not Trilinos) timed on this box's host cores.  The headline grid
     (214^3 cells) takes minutes on the CPU, so by default a bounded sample of THE SAME workload is run -- the same
@@ -115,7 +135,7 @@ def cpu_baseline(a, full_cells, gpu_its, full=False):
     iterations x (operator time per iteration and dof + Gram-Schmidt time per basis column and dof), with the
     iteration count of the full grid taken from the GPU run (same algorithm; the tests hold the two counts within
     +-2).  --cpu-full runs the full grid instead (recorded once per round under profiles/)."""
-    nthr = int(os.environ.get("FEDD_CPU_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    nthr = nthr or int(os.environ.get("FEDD_CPU_THREADS", "0")) or host_cores()
     n_full = (full_cells + 1) ** 3
     M = full_cells if full else min(a.cpu_cells, full_cells)
     r = cpu_run(a, M, nthr)
@@ -146,6 +166,155 @@ def cpu_baseline(a, full_cells, gpu_its, full=False):
             "seconds": t_full, "extrapolated": True, "full_grid_measured": _recorded_full_cpu_run(full_cells, a.target),
             "sample_measured": {"cells": M, "dofs": r["dofs"], "seconds": r["seconds"], "value": r["dofs"] / r["seconds"],
                                 "gmres_iterations": r["its"]}}
+
+
+def timed_passes(c, step, steps, warmup, stride=1):
+    """`warmup` untimed and `steps` timed passes of step() on one context; wall ms per pass, the last pass' return value and the
+    device-time table"""
+    for _ in range(warmup):
+        step()
+    c.sync()
+    c.timing_enable(stride)
+    c.timing_reset()
+    t0 = time.perf_counter()
+    ret = None
+    for _ in range(steps):
+        ret = step()
+    c.sync()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    tm = c.timing_get()
+    c.timing_enable(0)
+    return wall, ret, tm
+
+
+def phases(tm, steps):
+    return {k: round(v[0] / steps, 4) for k, v in tm.items() if not k.startswith("_")}
+
+
+def extra_per_gpu_share(capi, dev, a, its_headline):
+    """The share of ONE GPU of the 8-GPU run (BASELINE cfg 3: 2 x 2 x 2 blocks of 107^3 cells), on one GPU: the same step on a
+    107^3-cell cube (1 259 712 dofs) held to the iteration count of the full grid (rtol off, max_it = that count), because at
+    N = 8 every rank iterates as long as the whole problem does.  No communication in it: what it prices is the fixed cost
+    per iteration at the per-GPU vector length -- device time by kernel class and the wall-minus-device gap (launch latency,
+    host round trips) -- which bounds the 8-GPU step from below."""
+    m = capi.structured_mesh(3, (1, 1, 1), [107] * 3, 0)
+    c = capi.Context(device=dev)
+    c.mesh_set_dict(m)
+
+    def step():
+        c.pattern_build(1, capi.BLOCK_SCALAR)
+        c.assemble(capi.FORM_LAPLACE)
+        c.assemble_rhs([1.0])
+        c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+        c.schwarz_set_target(a.target, 1.0)
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+        return c.gmres(None, rtol=1e-300, max_it=its_headline, restart=a.restart, use_prec=True, want_x=False)[1:]
+
+    wall, (its, rel), tm = timed_passes(c, step, 3, 2)
+    per_it = ("spmv", "schwarz_apply", "ortho", "gs_dot", "gs_update")
+    dev_total = sum(v[0] for k, v in tm.items() if k not in ("gs_dot", "gs_update", "allreduce")) / 3
+    out = {"workload": "107^3-cell cube, %d dofs, held to the %d iterations of the 214^3 grid" % (m["n_global"], its),
+           "ms_per_step": wall, "gmres_iterations": its, "phases_device_ms_per_step": phases(tm, 3),
+           "device_us_per_iteration": {k: round(tm[k][0] / 3 / max(its, 1) * 1e3, 2) for k in per_it},
+           "device_ms_per_step": dev_total, "wall_minus_device_ms": wall - dev_total,
+           "solve_device_ms_per_iteration": round(sum(tm[k][0] for k in ("spmv", "schwarz_apply", "ortho")) / 3 / max(its, 1), 4),
+           "gmres": c.gmres_info(), "schwarz": c.schwarz_info()}
+    c.close()
+    return out
+
+
+def extra_cfg5_share(capi, dev, a):
+    """BASELINE cfg 5 (3D P1 linear elasticity, 189^3 nodes on 8 GPUs, two-level Schwarz) as the share of one GPU: a
+    94^3-cell cube, 2 571 375 dofs, steadyLinElas_Perf parameters (mu 2e6, nu 0.4, f = (0, 1, 0), Dirichlet on flag 2, rtol 1e-6,
+    restart 100; parametersProblem.xml:5-11, parametersSolver.xml), 8-node boxes; coarse level RGDSW as the XML names it, the Q1
+    lattice space and the one-level operator beside it.  Its matrix (113 M entries, 1.4 GB, no repeated column patterns per
+    3-dof row block) is the HBM-sized pattern-free SpMV case."""
+    M = 94
+    m = capi.structured_mesh(3, (1, 1, 1), [M] * 3, 0)
+    c = capi.Context(device=dev)
+    c.mesh_set_dict(m)
+    mu, nu = 2.0e6, 0.4
+    lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
+    n = 3 * m["n_global"]
+    out = {"workload": "3D P1 linear elasticity, 94^3 cells, %d dofs (one GPU's share of cfg 5), rtol 1e-6, 8-node boxes" % n}
+    kinds = (("one_level", None), ("q1", capi.COARSE_Q1), ("rgdsw", capi.COARSE_RGDSW))
+    for name, kind in kinds:
+        def step():
+            c.pattern_build(3, capi.BLOCK_FULL)
+            c.assemble(capi.FORM_LINELAS, [lam, mu])
+            c.assemble_rhs([0.0, 1.0, 0.0])
+            c.dirichlet([2], [0.0, 0.0, 0.0])
+            c.schwarz_set_target(8, 1.0)
+            if kind is None:
+                c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+            else:
+                c.schwarz_setup(1, capi.COMBINE_RESTRICTED, two_level=1, coarse_kind=kind)
+            return c.gmres(None, rtol=1e-6, max_it=2000, restart=100, use_prec=True, want_x=False)[1:]
+        wall, (its, rel), tm = timed_passes(c, step, 2, 1)
+        x, b = c.solution_get(), c.rhs_get()
+        e = {"ms_per_step": wall, "value": n / wall * 1e3, "unit": "DoF/s", "gmres_iterations": its, "relres": rel,
+             "true_relres": float(np.linalg.norm(b - c.spmv(x)) / np.linalg.norm(b)),
+             "phases_device_ms_per_step": phases(tm, 2)}
+        if kind is not None:
+            e["coarse_dofs"] = int(c.schwarz_coarse_sizes()[1])
+        if name == "one_level":
+            nr, _, nnz = c.csr_sizes()
+            si = c.spmv_info()
+            ms, nl = tm["spmv"]
+            byt = 12.0 * si["nnz_streamed"] + 20.0 * nr if not si.get("column_patterns") else \
+                8.0 * si["nnz_streamed"] + 22.0 * nr + 4.0 * si["nnz_streamed"] * si["rows_with_explicit_columns"] / max(nr, 1)
+            e["spmv"] = {"ms_per_launch": ms / max(nl, 1), "bytes_streamed": byt, "GBs": byt / (ms / max(nl, 1)) / 1e6,
+                         "frac_hbm_peak": byt / (ms / max(nl, 1)) / 1e6 / HBM_PEAK_GBS, "nnz": si,
+                         "parity_csr_bytes": 12.0 * nnz + 20.0 * nr}
+            ms, nl = tm["assemble"]
+            ab = 4.0 * m["conn"].size + 8.0 * 3 * m["xyz"].shape[0] + 12.0 * nnz + 4.0 * (nr + 1)
+            e["assemble"] = {"ms_per_launch": ms / max(nl, 1), "bytes": ab, "frac_hbm_peak": ab / (ms / max(nl, 1)) / 1e6 / HBM_PEAK_GBS}
+        out[name] = e
+    c.close()
+    return out
+
+
+def extra_cfg4(capi, dev):
+    """BASELINE cfg 4: P2 / P1 Stokes on DFG3DCylinder_6k.mesh (141 742 dofs), block assembly, merge, the driver's boundary
+    conditions (no-slip on flags 1 and 4, parabolic inflow on flag 2; stokes/main.cpp:80-88, 267-296), monolithic one-level
+    Schwarz on subdomains of several hundred dofs, GMRES to 1e-6 (the reference's stokes XML tolerance)."""
+    path = os.path.join(ROOT, "tests", "golden", "DFG3DCylinder_6k.mesh")
+    if not os.path.exists(path):
+        return None
+    m1 = capi.read_mesh(path, 3)
+    mv = capi.p2_of_p1(m1, volume_id=0)
+    n_p, nv = m1["xyz"].shape[0], mv["xyz"].shape[0]
+    n = 3 * nv + n_p
+    c = capi.Context(device=dev)
+    c.mesh_set_dict(mv)
+    X, flag, H = mv["xyz"], mv["flag_uni"], 0.41
+    nodes = np.nonzero(np.isin(flag, (1, 2, 4)))[0]
+    rows = (3 * nodes[:, None] + np.arange(3)[None, :]).ravel()
+    vals = np.zeros((nodes.shape[0], 3))
+    inflow = flag[nodes] == 2
+    vals[inflow, 0] = (16.0 * X[nodes, 1] * (H - X[nodes, 1]) * X[nodes, 2] * (H - X[nodes, 2]) / H ** 4)[inflow]
+
+    def step():
+        c.pattern_build(3, capi.BLOCK_DIAG)
+        c.assemble(capi.FORM_LAPLACE_VEC)
+        c.matrix_store(0)
+        c.assemble_div(n_p, 1, 2)
+        c.matrix_scale(1, -1.0)
+        c.matrix_scale(2, -1.0)
+        c.block_merge(0, 2, 1, -1)
+        c.rhs_set(np.zeros(n))
+        c.dirichlet_rows(rows, vals.ravel())
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+        return c.gmres(None, rtol=1e-6, max_it=3000, restart=300, use_prec=True, want_x=False)[1:]
+
+    wall, (its, rel), tm = timed_passes(c, step, 2, 1)
+    x, b = c.solution_get(), c.rhs_get()
+    out = {"workload": "P2/P1 Stokes, DFG3DCylinder_6k.mesh, %d dofs, merged system, monolithic one-level Schwarz, rtol 1e-6" % n,
+           "ms_per_step": wall, "value": n / wall * 1e3, "unit": "DoF/s", "gmres_iterations": its, "relres": rel,
+           "true_relres": float(np.linalg.norm(b - c.spmv(x)) / np.linalg.norm(b)),
+           "phases_device_ms_per_step": phases(tm, 2), "schwarz": c.schwarz_info()}
+    c.close()
+    return out
 
 
 def main():
@@ -228,7 +397,12 @@ def main():
         c.sync()
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
-        return dt, its, rel, c.timing_get()
+        tm_ = c.timing_get()
+        # the Gram-Schmidt sweeps: device time and algorithmic bytes of exactly the launches that were timed
+        smp = c.timing_get_sampled()
+        tm_["_sampled"] = {k: smp[k] for k in ("gs_dot", "gs_update")}
+        tm_["_gmres"] = c.gmres_info()
+        return dt, its, rel, tm_
 
     def true_relres(ctx):
         """||b - A x|| / ||b|| of the solution the last solve left on the device, formed with fedd_spmv
@@ -248,15 +422,6 @@ def main():
         return tr
 
     TIMING_STRIDE = 8       # the per-iteration kernel classes are timed every 8th launch (measure() below)
-
-    def gs_launch_cols(launches, per_cycle):
-        """basis columns k of the Gram-Schmidt launches of one solve, in launch order: cycles of k = 1 .. per_cycle"""
-        seq, left = [], launches
-        while left > 0:
-            cyc = min(per_cycle, left)
-            seq += range(1, cyc + 1)
-            left -= cyc
-        return seq
 
     def spmv_bytes_model(si, nr):
         """bytes one solver SpMV streams: values (8) and column ids (4) per entry + row pointer, x and y per row; with the
@@ -286,18 +451,18 @@ def main():
         if "schwarz_apply" in kern:
             kern["schwarz_apply"]["distinct_inverses"] = info["n_unique"]
             kern["schwarz_apply"]["kernel"] = "k_apply_mfma (shared inverses)" if shared and info["n_subdomains"] >= 4096 else "k_apply_flat"
-        # the two sweeps of a DCGS2 step over the k final basis columns (gmres.hip): sweep 1 reads them and u, B u;
-        # sweep 2 reads them and u, B u again and writes v_{k+1} and the next u.  k differs from launch to launch, and
-        # the timers sample every TIMING_STRIDE-th launch: the byte figure is the mean over exactly those launches.
-        for name, extra, per_cycle in (("gs_dot", 2, a.restart), ("gs_update", 4, a.restart - 1)):
+        # the sweeps of the Gram-Schmidt process over the Krylov basis (gmres.hip): the launch sites state their algorithmic
+        # bytes -- DCGS2 (gmres_kind 0): sweep 1 reads the k final columns, u and B u, sweep 2 reads them again and writes
+        # v_{k+1} and the next u; s-step (gmres_kind 2): a dot sweep reads the k final columns and the s block columns, an
+        # update sweep reads both and writes the block -- and the figure is bytes / time over exactly the timed launches
+        gk = tm.get("_gmres", {"kind": 0})
+        names = {0: ("k_multidot2", "k_axpy2"), 1: ("k_multidot", "k_multiaxpy"), 2: ("k_blockdot", "k_blockaxpy")}[gk["kind"]]
+        for name, kname in zip(("gs_dot", "gs_update"), names):
             ms, nl = tm.get(name, (0.0, 0))
-            if nl and nl % a.steps == 0 and per_cycle > 0:
-                cols = gs_launch_cols(nl // a.steps, per_cycle) * a.steps
-                sampled = cols[::TIMING_STRIDE]
-                b = 8.0 * nr * (sum(sampled) / len(sampled) + extra)
-                kern[name] = dict(ms_per_launch=ms / nl, launches=nl, total_ms=ms, GBs=b / (ms / nl) / 1e6, bytes=b,
-                                  mean_basis_columns=sum(sampled) / len(sampled),
-                                  kernel="k_multidot2" if name == "gs_dot" else "k_axpy2")
+            sms, snl, sb = tm.get("_sampled", {}).get(name, (0.0, 0, 0.0))
+            if nl and snl and sms > 0 and sb > 0:
+                kern[name] = dict(ms_per_launch=sms / snl, launches=nl, total_ms=ms, GBs=sb / sms / 1e6, bytes=sb / snl,
+                                  timed_launches=snl, mean_columns_per_launch=sb / snl / (8.0 * nr), kernel=kname)
         return kern
 
     def rounded(kern):
@@ -341,7 +506,7 @@ def main():
         two = {"value": n_global * a.steps / dt2, "unit": "DoF/s", "ms_per_step": dt2 / a.steps * 1e3,
                "gmres_iterations": its2, "relres": rel2, "true_relres": true_rel2, "coarse_cells": [int(v) for v in g2],
                "coarse_dofs": int(n02),
-               "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in tm2.items()},
+               "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in tm2.items() if not k.startswith("_")},
                "note": "same step with fedd_schwarz_setup(two_level=1, FEDD_COARSE_Q1); not the headline config"}
 
     # ---- extra: SpMV launched back to back on resident vectors (single GPU; no halo in the loop) ----
@@ -415,19 +580,27 @@ def main():
                 "spmv_nnz": info2["spmv"],
                 "spmv_frac_hbm_peak": k2["spmv"]["GBs"] / HBM_PEAK_GBS,
                 "schwarz_apply_frac_hbm_peak": k2["schwarz_apply"]["GBs"] / HBM_PEAK_GBS,
-                "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in t1.items()}}
+                "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in t1.items() if not k.startswith("_")}}
         if not a.no_two_level:
             d2, i2, r2, t2 = measure(c2, m2["n_global"], True)
             cfg2["two_level_variant"] = {"value": m2["n_global"] * a.steps / d2, "unit": "DoF/s",
                                          "ms_per_step": d2 / a.steps * 1e3, "gmres_iterations": i2, "relres": r2,
                                          "true_relres": checked(c2, "cfg 2 two-level"),
-                                         "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in t2.items()}}
+                                         "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in t2.items() if not k.startswith("_")}}
         c2.close()
         del m2
         if not a.no_cpu_baseline:
             # the same grid on the host cores: a same-workload partner for cfg2_one_gpu (no extrapolation)
             cfg2["cpu_baseline"] = cpu_baseline(a, 100, i1, full=True)
             cfg2["gpu_over_cpu"] = cfg2["value"] / cfg2["cpu_baseline"]["value"]
+
+    extras = {}
+    if N == 1 and not weak and not a.no_extras:
+        extras["per_gpu_share_n8"] = extra_per_gpu_share(capi, dev, a, its)
+        extras["cfg5_share_one_gpu"] = extra_cfg5_share(capi, dev, a)
+        e4 = extra_cfg4(capi, dev)
+        if e4 is not None:
+            extras["cfg4_one_gpu"] = e4
 
     if rank == 0:
         dominant = max(kern, key=lambda k: kern[k]["total_ms"])
@@ -446,6 +619,10 @@ def main():
                 pj = json.load(open(pmc))
                 if pj.get("cells_per_gpu") == cells and pj.get("n_gpus", 1) == N:
                     roofline["traffic"] = pj.get(dominant)
+                    # not measured in this run: the committed PMC passes of the same command (separate --pmc runs, as the
+                    # guide prescribes); the stamp says which source tree they were taken on
+                    roofline["traffic_source"] = {"file": "profiles/pmc_traffic.json", "git_sha": pj.get("git_sha"),
+                                                  "tag": pj.get("tag"), "kernel": pj.get("detail", {}).get(dominant, {}).get("kernel")}
             except Exception:
                 pass
         split = "x".join(map(str, dec))
@@ -472,7 +649,8 @@ def main():
                        "subdomains_per_gpu": info["n_subdomains"], "max_subdomain_size": info["max_size"]},
             "roofline": roofline,
             "kernels": rounded(kern),
-            "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in tm.items()},
+            "phases_device_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in tm.items() if not k.startswith("_")},
+            "gmres": tm["_gmres"],
             "spmv_frac_hbm_peak": kern["spmv"]["GBs"] / HBM_PEAK_GBS if "spmv" in kern else None,
             "spmv_bytes": None if "spmv" not in kern else {
                 "nnz_pattern": info["spmv"]["nnz_pattern"], "nnz_streamed": info["spmv"]["nnz_streamed"],
@@ -504,8 +682,14 @@ def main():
             out["two_level_variant"] = two
         if cfg2 is not None:
             out["cfg2_one_gpu"] = cfg2
+        out.update(extras)
         if N == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, cells[0], its, full=a.cpu_full)
+            out["cpu_baseline"]["host"] = {"cpu_model": host_cpu_model(), "os_cpu_count": os.cpu_count(),
+                                           "cores_available_to_this_process": host_cores()}
+            if host_cores() > 16 and not a.cpu_full:
+                c16 = cpu_baseline(a, cells[0], its, nthr=16)
+                out["cpu_baseline"]["with_16_threads"] = {"value": c16["value"], "seconds": c16["seconds"], "cores": c16["cores"]}
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if N > 1:

@@ -188,6 +188,7 @@ struct fedd_ctx {
     // fedd_csr_get keeps returning the reference pattern; SpMV streams this one (same y bit for bit for finite x).
     int spmv_compact = 1;                       // option "spmv_compact": 1 = on (default), 0 = stream the parity CSR
     double spmv_drop_tol = 2.220446049250313e-16;   // option "spmv_drop_tol": drop |a_ij| <= tol * max_k |a_ik|; 0 = exact zeros only
+    int spmv_exact_public = 1;                  // option "spmv_exact_public": fedd_spmv multiplies with the parity CSR (every stored entry), not with the solver's compacted stream
     bool cs_valid = false;                      // false after anything that writes d_val / the pattern
     int64_t cs_nnz = 0;
     int32_t cs_tot32 = 0;
@@ -286,6 +287,7 @@ struct fedd_ctx {
     double* h_pinned_dev = nullptr;             // the same buffer as the device sees it (nullptr: not mapped, copies are used)
     double* h_pinned = nullptr;                 // small pinned host mirror
     int gm_restart_alloc = 0;
+    int64_t gm_V_ldv = -1;                      // leading dimension the zeroed padding rows of d_V belong to (s-step solver)
     const double* gm_mask = nullptr;            // != nullptr: GMRES solves the constrained system (dofs with mask 0 held), see gmres.hip
 
     // ---- generic scratch ----

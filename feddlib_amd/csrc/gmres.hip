@@ -563,6 +563,7 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
     FEDD_CHECK(m + 2 <= 1024, "gmres: restart length above 1022 is not supported");
     const int nblk = (int)((n + MD_ROWS - 1) / MD_ROWS), nblk2 = (int)((n + AX_ROWS - 1) / AX_ROWS);
     FEDD_TRY(c->d_V.ensure((size_t)(m + 1) * ldv));
+    if (c->gm_V_ldv != ldv) c->gm_V_ldv = -1;   // another column layout: the s-step solver clears the basis before its next use
     // work vectors carry room for the ghost entries behind the owned ones (several ranks): the halo import of an
     // operator input then goes straight into the vector, without a copy into a column-length buffer first
     const int64_t nc = (std::max<int64_t>(n, c->n_cols) + 15) & ~(int64_t)15;
@@ -691,6 +692,7 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
                 ScopedTimer t(c, FEDD_T_ORTHO);
                 const int ncg = (k + 1 + MD2_CG - 1) / MD2_CG;
                 ScopedTimer td(c, FEDD_T_GS_DOT);
+                td.bytes(8.0 * (double)n * (k + 2));   // k basis columns, u, B u
                 if (md2_nch == 2)
                     hipLaunchKernelGGL(k_multidot2<2>, dim3(nblkd, std::min(md2_gy, ncg)), blk, 0, st, (const double*)V, ldv, n,
                                        k, (const double*)u, (const double*)wt, c->d_part.p, nblkd);
@@ -705,6 +707,7 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
                                    c->h_pinned_dev ? c->h_pinned_dev + 4 * (j & 1) : (double*)nullptr);
                 if (k < m) {  // the last step of a cycle needs no further basis vector
                     ScopedTimer tu(c, FEDD_T_GS_UPDATE);
+                    tu.bytes(8.0 * (double)n * (k + 4));   // k basis columns, u and B u in, v_{k+1} and the next u out
                     hipLaunchKernelGGL(k_axpy2, dim3(nblk2), blk, 0, st, V, ldv, n, k, (const double*)(S + o2.cf), m, u,
                                        (const double*)wt);
                     tu.stop();
@@ -782,30 +785,47 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
 
 constexpr int SS_CG = 4;   // basis columns per group of the block dot kernel
 
+// exchange step of the transpose reduction between lanes l and l ^ OFF for one pair of values: afterwards `lo` holds, in
+// the lanes with bit OFF clear, lo(l) + lo(l ^ OFF) and, in the lanes with it set, hi(l) + hi(l ^ OFF).
+// OFF = 32 / 16: gfx950's v_permlane32_swap / v_permlane16_swap move the halves (rows 2-3 of the first operand <-> rows
+// 0-1 of the second; odd rows of the first <-> even rows of the second) without going through the LDS crossbar.
+template <int OFF>
+__device__ __forceinline__ double xchg_add(double lo, double hi, int lane) {
+    if constexpr (OFF == 32 || OFF == 16) {
+        const unsigned l0 = __double2loint(lo), l1 = __double2hiint(lo), h0 = __double2loint(hi), h1 = __double2hiint(hi);
+        if constexpr (OFF == 32) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(l0, h0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);
+            return __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
+        } else {
+            const auto r0 = __builtin_amdgcn_permlane16_swap(l0, h0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(l1, h1, false, false);
+            return __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
+        }
+    } else {
+        const bool up = (lane & OFF) != 0;
+        const double keep = up ? hi : lo;
+        const double send = up ? lo : hi;
+        return keep + __shfl_xor(send, OFF, 64);
+    }
+}
+
 // all-lanes transpose reduction of NV values: afterwards lane l holds the wave total of value l >> (6 - log2 NV)
+// (values first, then selects on values: a select between two array ELEMENTS becomes an indexed access and sends the whole
+// array to scratch memory)
+template <int NV, int OFF, int W>
+__device__ __forceinline__ void wave_reduce_step(double (&a)[NV], int lane) {
+    if constexpr (W > 1) {
+#pragma unroll
+        for (int i = 0; i < W / 2; ++i) a[i] = xchg_add<OFF>(a[i], a[i + W / 2], lane);
+    } else {
+        a[0] += __shfl_xor(a[0], OFF, 64);
+    }
+    if constexpr (OFF > 1) wave_reduce_step<NV, OFF / 2, (W > 1 ? W / 2 : 1)>(a, lane);
+}
 template <int NV>
 __device__ __forceinline__ double wave_reduce_transpose(double (&a)[NV], int lane) {
-    int width = NV;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        if (width > 1) {
-            const bool up = (lane & off) != 0;
-            width >>= 1;
-#pragma unroll
-            for (int i = 0; i < NV / 2; ++i) {
-                if (i < width) {
-                    // (both values first, then selects on values: a select between the two array ELEMENTS becomes an
-                    // indexed access and sends the whole array to scratch memory)
-                    const double lo = a[i], hi = a[i + width];
-                    const double keep = up ? hi : lo;
-                    const double send = up ? lo : hi;
-                    a[i] = keep + __shfl_xor(send, off, 64);
-                }
-            }
-        } else {
-            a[0] += __shfl_xor(a[0], off, 64);
-        }
-    }
+    wave_reduce_step<NV, 32, NV>(a, lane);
     return a[0];
 }
 
@@ -821,6 +841,12 @@ __device__ __forceinline__ RowPair row_pair(int64_t r, int64_t n) {
     q.v1 = r + 1 < n;
     q.rc = q.v0 ? r : 0;
     return q;
+}
+template <bool NT>
+__device__ __forceinline__ double2 ldraw(const double* __restrict__ p, const RowPair& q) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d t = NT ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + q.rc)) : *reinterpret_cast<const v2d*>(p + q.rc);
+    return double2{t.x, t.y};
 }
 template <bool NT>
 __device__ __forceinline__ double2 ldp(const double* __restrict__ p, const RowPair& q) {
@@ -874,20 +900,24 @@ __global__ __launch_bounds__(256) void k_blockdot(const double* __restrict__ V, 
         }
         __syncthreads();
     };
-    for (int cg = blockIdx.y; cg < ncg; cg += gridDim.y) {
-        double2 v[SS_CG][NCH];
+    double2 v[SS_CG][NCH];
+    auto load_group = [&](int cg) {
 #pragma unroll
         for (int cc = 0; cc < SS_CG; ++cc) {
             const int col = cg * SS_CG + cc;
             const double* __restrict__ a = V + (int64_t)(col < ncol ? col : 0) * ldv;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                // final basis columns are streamed (non-temporal); the block's own columns are re-read soon
-                const double2 t = col < k ? ldp<true>(a, rp[ch]) : ldp<false>(a, rp[ch]);
-                v[cc][ch].x = col < ncol ? t.x : 0.0;
-                v[cc][ch].y = col < ncol ? t.y : 0.0;
+                // final basis columns are streamed (non-temporal); the block's own columns are re-read soon.
+                // Raw loads, no selects behind them (a select would make the wave wait for the load right here instead of
+                // at the products after the reduction of the previous group): rows past n meet w = 0 there (the padding
+                // rows of the basis are zeroed when it is allocated), columns past ncol are dropped when the sums are stored
+                v[cc][ch] = col < k ? ldraw<true>(a, rp[ch]) : ldraw<false>(a, rp[ch]);
             }
         }
+    };
+    if ((int)blockIdx.y < ncg) load_group(blockIdx.y);
+    for (int cg = blockIdx.y; cg < ncg; cg += gridDim.y) {
         double acc[NV];
 #pragma unroll
         for (int cc = 0; cc < SS_CG; ++cc)
@@ -898,6 +928,8 @@ __global__ __launch_bounds__(256) void k_blockdot(const double* __restrict__ V, 
                 for (int ch = 0; ch < NCH; ++ch) s += v[cc][ch].x * w[j][ch].x + v[cc][ch].y * w[j][ch].y;
                 acc[cc * S + j] = s;
             }
+        // the next group's loads are in flight while this one is reduced
+        if (cg + (int)gridDim.y < ncg) load_group(cg + gridDim.y);
         const double tot = wave_reduce_transpose<NV>(acc, lane);
         if ((lane & (GRP - 1)) == 0) sh[parked][wave][lane / GRP] = tot;
         if (++parked == SS_LDS_GROUPS) {
@@ -1229,7 +1261,16 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     FEDD_CHECK(m + 2 <= 1024, "gmres: restart length above 1022 is not supported");
     const int nblk = (int)((n + MD_ROWS - 1) / MD_ROWS), nblk2 = (int)((n + AX_ROWS - 1) / AX_ROWS);
     const int nblkd = (int)((n + 1023) / 1024);
-    FEDD_TRY(c->d_V.ensure((size_t)(m + 1) * ldv));
+    {
+        // the block kernels read whole 16-byte row pairs and rely on the padding rows [n, ldv) of every column being zero
+        // (and on finite data everywhere): a freshly (re)allocated basis, or one last used with another vector length, is cleared
+        const double* before = c->d_V.p;
+        FEDD_TRY(c->d_V.ensure((size_t)(m + 1) * ldv));
+        if (c->d_V.p != before || c->gm_V_ldv != ldv) {
+            FEDD_HIP(hipMemsetAsync(c->d_V.p, 0, c->d_V.cap * sizeof(double), c->stream));
+            c->gm_V_ldv = ldv;
+        }
+    }
     const int64_t nc = (std::max<int64_t>(n, c->n_cols) + 15) & ~(int64_t)15;
     FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)2 * nc, c->d_w.cap)));   // x trial | A x trial
     FEDD_TRY(c->d_Z.ensure((size_t)nc * 2));
@@ -1513,6 +1554,7 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
     FEDD_CHECK(m + 2 <= 1024, "gmres: restart length above 1022 is not supported");
     const int nblk = (int)((n + MD_ROWS - 1) / MD_ROWS), nblk2 = (int)((n + AX_ROWS - 1) / AX_ROWS);
     FEDD_TRY(c->d_V.ensure((size_t)(m + 1) * ldv));
+    if (c->gm_V_ldv != ldv) c->gm_V_ldv = -1;
     FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)n, c->d_w.cap)));
     FEDD_TRY(c->d_Z.ensure((size_t)n * 2));
     FEDD_TRY(c->d_part.ensure(std::max((size_t)(m + 2) * nblk, (size_t)nblk2)));

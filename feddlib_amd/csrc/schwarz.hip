@@ -269,8 +269,9 @@ __device__ __forceinline__ int bsearch_i32(const int32_t* a, int n, int32_t v);
 // ---- subdomains with the same local matrix share one slab ------------------------------------------------------------
 // On a mesh with repeated cells (the structured cube of the headline: 389 017 subdomains, a few hundred distinct local
 // matrices) most principal submatrices A_i are copies of one another up to rounding.  Each subdomain's matrix is
-// fingerprinted -- entries quantised to 2^-44 of their row's largest magnitude, 128 bits of order-independent hash over
-// (local row, local column, quantised value) plus the sizes --, the subdomain of lowest index with a given fingerprint is
+// fingerprinted -- entries quantised to 2^-44 of their row's largest magnitude, the rows' maxima quantised against the
+// subdomain's largest one and that one with a 40-bit mantissa (the absolute scale: A and 2 A are two matrices), 128 bits
+// of order-independent hash over (local row, local column, quantised value) plus the sizes --, the subdomain of lowest index with a given fingerprint is
 // its REPRESENTATIVE, only representatives are inverted and stored, every other subdomain's slab pointer refers to its
 // representative's slab.  Equal fingerprints = equal matrices to 6e-14 relative per entry (a collision of two
 // independent 64-bit hashes aside), i.e. inverses equal to ~1e-12: far inside the 1e-10 parity bar; a fingerprint that
@@ -327,6 +328,19 @@ __global__ __launch_bounds__(64) void k_sub_fingerprint(const int32_t* __restric
     __syncthreads();
     uint64_t h1 = 0, h2 = 0;
     const int grp = lane >> 4, e = lane & 15;
+    // The entries of a row are quantised against the row's own largest magnitude, which loses the row's absolute scale: two
+    // local matrices A_j = alpha A_i (boxes in mesh regions of different h, a partly scaled matrix) would share a
+    // fingerprint and an inverse that is wrong by 1 / alpha.  So the scale is part of the identity: every row's maximum
+    // relative to the subdomain's largest one (quantised like the entries), and that largest one itself with its
+    // mantissa rounded to 40 bits (equal matrices differ by rounding noise ~1e-15; a scale that differs by more than
+    // ~1e-12 is a different matrix).
+    double smax = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const int32_t g = sdof[i];
+        if (g < n_stored) smax = fmax(smax, rmax[g]);
+    }
+    for (int off = 32; off > 0; off >>= 1) smax = fmax(smax, __shfl_xor(smax, off, 64));
+    const double sscale = smax > 0.0 ? 17592186044416.0 / smax : 0.0;
     for (int i = grp; i < n; i += 4) {
         const int32_t g = sdof[i];
         if (g >= n_stored) {   // ghost row without a stored row: identity
@@ -335,6 +349,11 @@ __global__ __launch_bounds__(64) void k_sub_fingerprint(const int32_t* __restric
                 h2 += mix64(((uint64_t)i << 20) ^ 0xd1b54a32d192ed03ull);
             }
             continue;
+        }
+        if (e == 0) {
+            const uint64_t qs = (uint64_t)llrint(rmax[g] * sscale);
+            h1 += mix64((((uint64_t)i << 48) ^ qs) * 0x9fb21c651e98df25ull + 0x2545f4914f6cdd1dull);
+            h2 += mix64((((uint64_t)i << 48) + qs) ^ 0x94d049bb133111ebull);
         }
         const double scale = rmax[g] > 0.0 ? 17592186044416.0 / rmax[g] : 0.0;   // 2^44 / row max
         // pressure rows of a merged system are pivoted after the velocities: part of the matrix' identity
@@ -361,7 +380,9 @@ __global__ __launch_bounds__(64) void k_sub_fingerprint(const int32_t* __restric
         h2 += __shfl_down(h2, off, 64);
     }
     if (lane == 0) {
-        h1 = mix64(h1 + (uint64_t)n * 1000003ull + (uint64_t)no);
+        const uint64_t sbits = ((uint64_t)__double_as_longlong(smax) + (1ull << 11)) & ~((1ull << 12) - 1ull);
+        h1 = mix64(h1 + (uint64_t)n * 1000003ull + (uint64_t)no + mix64(sbits));
+        h2 += mix64(sbits ^ 0xbf58476d1ce4e5b9ull);
         if (h1 == 0) h1 = 1;   // 0 marks an empty table slot
         fp[2 * (int64_t)b] = h1;
         fp[2 * (int64_t)b + 1] = h2;

@@ -296,7 +296,21 @@ int schwarz_setup_big(fedd_ctx* c) {
     ScopedTimer timer(c, FEDD_T_SCHWARZ_SETUP);
     const int dim = c->dim, dofs = c->dofs;
     const int64_t n_rows = c->n_rows;
-    FEDD_CHECK(n_rows > 0, "schwarz setup: no owned rows");
+    if (c->nranks > 1) {
+        // rank-local failures are shared before the first collective of the setup: a rank that returned here on its own
+        // would leave the others waiting in the all-reduce below (the small path defers its checks the same way)
+        FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>(1, c->d_dtmp0.cap)));
+        const double mine = n_rows > 0 ? 0.0 : 1.0;
+        FEDD_HIP(hipMemcpyAsync(c->d_dtmp0.p, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        FEDD_TRY(allreduce_sum(c, c->d_dtmp0.p, 1));
+        double any = 0.0;
+        FEDD_HIP(hipMemcpyAsync(&any, c->d_dtmp0.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        FEDD_CHECK(any == 0.0, "schwarz setup: %d rank(s) own no rows", (int)any);
+    } else {
+        FEDD_CHECK(n_rows > 0, "schwarz setup: no owned rows");
+    }
     // ---- coordinates of the node that carries each owned dof (host) ----
     std::vector<double> xyz((size_t)c->n_node * dim);
     FEDD_HIP(hipMemcpyAsync(xyz.data(), c->d_xyz.p, xyz.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));

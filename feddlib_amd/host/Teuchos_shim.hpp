@@ -131,18 +131,26 @@ public:
     }
 private:
     void arrive(std::unique_lock<std::mutex>& lk) {      // reusable barrier (generation counter)
+        TEUCHOS_TEST_FOR_EXCEPTION(broken_, std::runtime_error, "ThreadGroup: a rank did not reach an earlier collective");
         const long gen = gen_;
         if (++count_ == world_) {
             count_ = 0;
             ++gen_;
             cv_.notify_all();
         } else {
-            const bool ok = cv_.wait_for(lk, std::chrono::seconds(120), [&] { return gen_ != gen; });
-            TEUCHOS_TEST_FOR_EXCEPTION(!ok, std::runtime_error, "ThreadGroup: a rank did not reach the collective");
+            const bool ok = cv_.wait_for(lk, std::chrono::seconds(120), [&] { return gen_ != gen || broken_; });
+            if (!ok || broken_) {
+                // a rank never arrived: the barrier is poisoned for everyone (the count of this generation can no longer be
+                // trusted), so the remaining ranks fail at their next collective instead of pairing up with a stale count
+                broken_ = true;
+                cv_.notify_all();
+            }
+            TEUCHOS_TEST_FOR_EXCEPTION(broken_, std::runtime_error, "ThreadGroup: a rank did not reach the collective");
         }
     }
     int world_, count_ = 0;
     long gen_ = 0;
+    bool broken_ = false;
     std::mutex m_;
     std::condition_variable cv_;
     std::vector<std::vector<char>> slots_;
@@ -527,9 +535,16 @@ public:
         t_->start();
         if (!stacked().is_null()) stacked()->start(t_->name());
     }
-    ~TimeMonitor() {
-        t_->stop();
-        if (!stacked().is_null()) stacked()->stop(t_->name());
+    ~TimeMonitor() noexcept {
+        // a destructor may run while another exception unwinds the FEDD_TIMER scopes of a rank thread: a throw from here
+        // (StackedTimer::stop checks that the names nest) would be std::terminate, so a mismatch is reported, not thrown
+        try {
+            t_->stop();
+            if (!stacked().is_null()) stacked()->stop(t_->name());
+        } catch (const std::exception& e) {
+            std::cerr << "TimeMonitor: " << e.what() << std::endl;
+        } catch (...) {
+        }
     }
     static RCP<Time> getNewCounter(const std::string& name) {
         auto& reg = registry();

@@ -344,6 +344,9 @@ int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_bloc
  * entries that are exactly 0.0 only (y then identical bit for bit, for finite x, to the product with the parity CSR), the
  * default also drops cancellation noise below one ulp of the row's largest entry (cf. the reference's optional setZeros_
  * threshold, FE_def.hpp:719-721), which changes y by less than the rounding error of the row sum;
+ * "spmv_exact_public" 1 (default) = fedd_spmv itself (Matrix::apply for the caller, residual checks) multiplies with the parity
+ * CSR, every stored entry, so its y is the reference's product whatever the solver streams; 0 = fedd_spmv runs the solver's
+ * compacted stream (tests and measurements of those kernels);
  * "schwarz_dedupe" 1 (default) = subdomains with the same local matrix share one inverse (see fedd_schwarz_unique), 0 = every
  * subdomain is inverted and stored on its own;
  * "halo_overlap" 1 = several ranks, restricted combine: the subdomains that hold no dof of another rank are applied while the

@@ -135,3 +135,44 @@ def test_matrix_change_invalidates_the_sharing(fedd_lib, ctx):
     ctx.matrix_scale(-1, 2.0)
     ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
     np.testing.assert_allclose(ctx.schwarz_apply(r), 0.5 * z1, rtol=0, atol=1e-12 * np.abs(z1).max())
+
+
+def test_scaled_copies_of_a_local_matrix_do_not_share_an_inverse(fedd_lib, ctx):
+    """A_j = 2 A_i must be two matrices (the fingerprint quantised every row against its own maximum and never
+    hashed the scale).  A cube whose nodes are mapped per coordinate by g(t) = t (t <= 1/2), 2 t - 1/2 (t > 1/2): the cells of
+    the octant beyond 1/2 are the cells of the first octant doubled, so 3D P1 Laplace entries there are exactly twice those of
+    the first octant (K ~ h; powers of two: bit for bit).  One-node boxes + one layer of overlap = the 15-node stencil
+    neighbourhood, the same graph in both octants: local matrices that differ by the factor 2 and by nothing else."""
+    M = 10
+    m = fedd_lib.structured_mesh(3, 1, M)
+    g = lambda t: np.where(t <= 0.5, t, 2.0 * t - 0.5)
+    m = dict(m)
+    m["xyz"] = g(m["xyz"])
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+    ctx.assemble(fedd_lib.FORM_LAPLACE)
+    # (flags are those of the unit cube's surface, which the map keeps on the surface)
+    ctx.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+    om = oracle_mesh(m)
+    A_bc = fo.laplace_problem(om)[0]
+    rowptr, col, val, gid = ctx.csr_get()
+    d = val[rowptr[:-1] + np.array([np.searchsorted(col[rowptr[i]:rowptr[i + 1]], i) for i in range(rowptr.shape[0] - 1)])]
+    x = m["xyz"]
+    inner1 = np.flatnonzero(np.all((x > 0.15) & (x < 0.35), axis=1))
+    inner2 = np.flatnonzero(np.all((x > 0.8) & (x < 1.2), axis=1))
+    assert inner1.size and inner2.size
+    assert np.allclose(d[inner2], 2.0 * d[inner1][0], rtol=1e-14, atol=0)     # the scenario is what it claims to be
+    r = np.random.default_rng(11).standard_normal(A_bc.shape[0])
+    node_bin, nb, _ = fo.schwarz_bins(m["xyz"], 1)
+    zo = fo.RAS(A_bc, node_bin, nb).apply(r)
+    out = {}
+    for dedupe, kind in ((0, 0), (1, 0), (1, 4)):
+        ctx.schwarz_set_target(1, 1.0)
+        ctx.set_option("schwarz_dedupe", dedupe)
+        ctx.set_option("apply_kind", kind)
+        ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+        out[(dedupe, kind)] = ctx.schwarz_apply(r)
+        info = ctx.schwarz_info()
+        assert info["n_subdomains"] == nb
+        np.testing.assert_allclose(out[(dedupe, kind)], zo, rtol=0, atol=1e-10 * np.abs(zo).max())
+    assert info["n_unique"] < info["n_subdomains"]          # sharing still happens where the matrices ARE equal

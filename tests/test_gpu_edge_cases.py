@@ -183,6 +183,7 @@ def test_spmv_kernels_agree(fedd_lib, ctx, dim, M):
     bit for bit (same products, same summation order)."""
     m, A_bc, rhs_bc, flags = laplace(fedd_lib, ctx, dim, M)
     x = np.random.default_rng(11).standard_normal(A_bc.shape[0])
+    ctx.set_option("spmv_exact_public", 0)     # fedd_spmv = the solver's stream in this test
     yo = fo.spmv(A_bc, x)
     ys = {}
     try:
@@ -218,10 +219,15 @@ def test_spmv_kernels_agree(fedd_lib, ctx, dim, M):
         ctx.set_option("spmv_drop_tol", 2.0 ** -52)
     # what the default tolerance changes is below the rounding error of the row sums
     assert np.abs(ys[0] - ys[2]).max() <= 2.0 ** -50 * np.abs(A_bc).max() * np.abs(x).max()
+    # the caller's own product (the default of fedd_spmv) is formed with the parity CSR, whatever the solver streams
+    ctx.set_option("spmv_exact_public", 1)
+    assert np.array_equal(ctx.spmv(x), ys[2])
+    ctx.set_option("spmv_exact_public", 0)
     # the compacted copy follows the matrix when it changes
     ctx.matrix_scale(-1, -2.5)
     np.testing.assert_allclose(ctx.spmv(x), -2.5 * yo, rtol=0, atol=1e-12 * np.abs(yo).max())
     ctx.matrix_scale(-1, -0.4)
+    ctx.set_option("spmv_exact_public", 1)
 
 
 def test_box_lattice_refines_itself_when_a_subdomain_would_exceed_the_dense_solver(fedd_lib, ctx):

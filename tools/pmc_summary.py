@@ -13,8 +13,8 @@ def load(d, name):
     return acc
 
 fe = load(sys.argv[1], "FETCH_SIZE"); wr = load(sys.argv[2], "WRITE_SIZE")
-classes = {"spmv": ("k_spmv_win<", "k_spmv_pat<"), "schwarz_apply": "k_apply", "assemble": "k_assemble_pairs<", "multidot": "k_multidot(",
-           "multiaxpy": "k_multiaxpy(", "gs_dot": "k_multidot2", "gs_update": "k_axpy2", "invert": "k_invert_reg<7"}
+classes = {"spmv": ("k_spmv_win<", "k_spmv_pat<"), "schwarz_apply": "k_apply", "assemble": ("k_assemble_pairs<", "k_assemble_tiles<"), "multidot": "k_multidot(",
+           "multiaxpy": "k_multiaxpy(", "gs_dot": ("k_multidot2", "k_blockdot<"), "gs_update": ("k_axpy2", "k_blockaxpy<"), "invert": "k_invert_reg<7"}
 # (gs_dot / gs_update: the basis grows from launch to launch; the figure is the mean over all launches of the solve, like
 # bench.py's byte model.  schwarz_apply with shared inverses is a gather kernel: the doubling of FETCH_SIZE is calibrated
 # on streaming reads and may overstate its traffic)
@@ -29,10 +29,13 @@ for key, pat in classes.items():
     wk2 = wk[:len(wk)]
     rd = 2.0 * 1024 * sum(fk2) / len(fk2)
     wrt = 1024 * sum(wk2) / max(1, len(wk2))
-    out[key] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wrt, "hbm_bytes_per_launch": rd + wrt,
+    names = sorted({k.split("(")[0] for k in fe if any(p in k for p in pats)})
+    out[key] = {"kernel": ", ".join(names), "read_bytes_per_launch": rd, "write_bytes_per_launch": wrt, "hbm_bytes_per_launch": rd + wrt,
                 "launches_sampled": len(fk2), "note": "FETCH_SIZE doubled (gfx950 128-B request correction), WRITE_SIZE as reported"}
 flat = {k: v["hbm_bytes_per_launch"] for k, v in out.items()}
 # the grid the passes were taken on (bench.py quotes `traffic` only for the same one): argv[4] = "214,214,214"
 cells = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else None
-json.dump({"cells_per_gpu": cells, "n_gpus": 1, "detail": out, **flat}, open(sys.argv[3], "w"), indent=1)
+# argv[5] / argv[6]: tag of the profile round and git SHA of the tree the passes ran on (bench.py stamps them next to `traffic`)
+json.dump({"cells_per_gpu": cells, "n_gpus": 1, "tag": sys.argv[5] if len(sys.argv) > 5 else None,
+           "git_sha": sys.argv[6] if len(sys.argv) > 6 else None, "detail": out, **flat}, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(flat, indent=1))
