@@ -105,9 +105,20 @@ def _recorded_full_cpu_run(full_cells, target):
 def host_cores():
     """the cores this process may run on (the box's CPU share; os.cpu_count() is the whole host)"""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    # a container's CPU share is a cgroup quota, not an affinity mask: 256 OpenMP threads on a 16-core share run 13x slower
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
+        try:
+            q, per = parse(open(path).read())
+            if q != "max" and int(q) > 0:
+                n = max(1, min(n, int(int(q) / int(per) + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
 
 
 def host_cpu_model():
@@ -237,7 +248,8 @@ def extra_cfg5_share(capi, dev, a):
     lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
     n = 3 * m["n_global"]
     out = {"workload": "3D P1 linear elasticity, 94^3 cells, %d dofs (one GPU's share of cfg 5), rtol 1e-6, 8-node boxes" % n}
-    kinds = (("one_level", None), ("q1", capi.COARSE_Q1), ("rgdsw", capi.COARSE_RGDSW))
+    # (the one-level operator alone needs > 2000 iterations on this problem with 8-node boxes: not a configuration anyone runs)
+    kinds = (("q1", capi.COARSE_Q1), ("rgdsw", capi.COARSE_RGDSW))
     for name, kind in kinds:
         def step():
             c.pattern_build(3, capi.BLOCK_FULL)
@@ -257,7 +269,7 @@ def extra_cfg5_share(capi, dev, a):
              "phases_device_ms_per_step": phases(tm, 2)}
         if kind is not None:
             e["coarse_dofs"] = int(c.schwarz_coarse_sizes()[1])
-        if name == "one_level":
+        if name == "q1":
             nr, _, nnz = c.csr_sizes()
             si = c.spmv_info()
             ms, nl = tm["spmv"]

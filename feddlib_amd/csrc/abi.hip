@@ -731,8 +731,10 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
         FEDD_CHECK(value == 0 || value == 1 || value == 2, "fedd_set_option: gmres_kind %g", value);
         c->gmres_kind = (int)value;
     } else if (k == "gmres_s") {
-        FEDD_CHECK(value >= 1 && value <= 8, "fedd_set_option: gmres_s %g (1 ... 8)", value);
+        FEDD_CHECK(value >= 1 && value <= 16, "fedd_set_option: gmres_s %g (1 ... 16)", value);
         c->gmres_s = (int)value;
+    } else if (k == "gmres_newton") {
+        c->gmres_newton = (int)value;
     } else if (k == "gmres_chol_tol") {
         FEDD_CHECK(value > 0.0 && value < 1.0, "fedd_set_option: gmres_chol_tol %g", value);
         c->gmres_chol_tol = value;

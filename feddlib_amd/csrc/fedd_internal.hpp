@@ -221,7 +221,8 @@ struct fedd_ctx {
     int inv_kind = 0;                           // local inverses: 0 = scalar-pivot kernel (drops finished rows), 1 = MFMA block sweep, 2 = scalar-pivot, all rows (A/B)
     int ghost_overlap = 1;                      // subdomains may contain ghost dofs (identity rows): 1 = yes (A/B)
     int gmres_kind = 2;                         // Gram-Schmidt: 0 = delayed second pass (DCGS2), 1 = two passes (CGS2), 2 = s-step blocks (BCGS-PIP2)
-    int gmres_s = 8;                            // s-step GMRES: Krylov vectors per block (1 ... 8)
+    int gmres_s = 16;                           // s-step GMRES: Krylov vectors per block (1 ... 16)
+    int gmres_newton = 1;                       // ... Newton block basis (Leja-ordered Ritz shifts) once the first s Arnoldi steps exist; 0 = monomial, blocks <= 8
     double gmres_chol_tol = 1e-13;              // ... a block is cut where the squared sine of a new vector against its predecessors falls to this
     int gmres_blocks = 0, gmres_cut_blocks = 0; // ... blocks / blocks that were cut in the last solve
     fedd::DevBuf<int32_t> d_node_bin;           // [n_own] compact bin id of each owned node
@@ -380,7 +381,9 @@ int block_merge(fedd_ctx* c, int slot_a, int slot_bt, int slot_b, int slot_c);
 // spmv.hip
 // x_has_tail: the buffer behind d_x_owned has room for all n_cols entries; the ghost values are then imported in
 // place (behind the owned entries) instead of into a copy of x
-int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_has_tail = false);   // incl. ghost import
+// d_sub != nullptr: y = A x - theta * d_sub (owned rows), fused into the kernel's store
+int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_has_tail = false, const double* d_sub = nullptr,
+               double theta = 0.0);   // incl. ghost import
 int halo_import(fedd_ctx* c, double* d_xcol, int dofs);                    // fill ghost tail
 int read_bandwidth(fedd_ctx* c, int64_t bytes, int reps, double* gbs);     // read-only streaming calibration
 

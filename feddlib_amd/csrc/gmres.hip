@@ -783,7 +783,8 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
 // threshold is cut there (the columns before it are valid) and the following blocks are shorter; the
 // convergence claim of the recurrence is checked against the true residual before it is accepted.
 
-constexpr int SS_CG = 4;   // basis columns per group of the block dot kernel
+// basis columns per group of the block dot kernel: groups x block columns = the wave totals one transpose reduction yields
+constexpr int ss_cg(int S) { return S >= 16 ? 2 : 4; }
 
 // exchange step of the transpose reduction between lanes l and l ^ OFF for one pair of values: afterwards `lo` holds, in
 // the lanes with bit OFF clear, lo(l) + lo(l ^ OFF) and, in the lanes with it set, hi(l) + hi(l ^ OFF).
@@ -867,7 +868,7 @@ constexpr int SS_LDS_GROUPS = 32;   // column groups whose wave totals are parke
 template <int S>
 __global__ __launch_bounds__(256) void k_blockdot(const double* __restrict__ V, int64_t ldv, int64_t n, int k, int sa_req,
                                                   const int32_t* __restrict__ d_sa, double* __restrict__ partial, int nblk) {
-    constexpr int NCH = 2, NV = SS_CG * S;
+    constexpr int NCH = 2, SS_CG = ss_cg(S), NV = SS_CG * S;
     static_assert(NV == 16 || NV == 32 || NV == 64, "block size");
     __shared__ double sh[SS_LDS_GROUPS][4][NV];
     const int sa = d_sa ? min(*d_sa, sa_req) : sa_req;
@@ -1005,44 +1006,51 @@ struct Off3 {
     int Hraw, P, C1, R1, R1i, Cc, cf1, ri1, cf2, ri2, th, res;
 };
 
-// upper Cholesky factor of the sa x sa leading block of the symmetric A (upper part read) via the unit-diagonal
-// scaling, cut at the first column whose pivot (relative to gdiag: the squared sine of the angle between the column
-// and the span of everything before it) is <= tol.  Returns the accepted columns; R and its inverse Ri are zero
-// outside the accepted upper triangle.  One lane.
+// Upper Cholesky factor of the sa x sa leading block of the symmetric A (upper part read) via the unit-diagonal scaling, cut
+// at the first column whose pivot (relative to gdiag: the squared sine of the angle between the column and the span of
+// everything before it) is <= tol.  Returns the accepted columns; R and its inverse Ri are zero outside the accepted upper
+// triangle.  Called by the whole workgroup (>= S * S lanes), A / W / R / Ri / dd in LDS; right-looking, one barrier-separated
+// step per column.
 template <int S>
-__device__ int chol_cut(const double (&A)[S][S], const double* gdiag, int sa, double tol, double (&R)[S][S], double (&Ri)[S][S]) {
-    double d[S];
-    for (int i = 0; i < S; ++i)
-        for (int j = 0; j < S; ++j) R[i][j] = Ri[i][j] = 0.0;
-    int ok = 0;
-    for (int j = 0; j < sa; ++j) {
-        if (!(A[j][j] > 0.0)) break;
-        d[j] = sqrt(A[j][j]);
-        // column j of U (U^T U = D^-1 A D^-1), kept in R unscaled for now
-        for (int i = 0; i < j; ++i) {
-            double s = A[i][j] / (d[i] * d[j]);
-            for (int p = 0; p < i; ++p) s -= R[p][i] * R[p][j];
-            R[i][j] = s / R[i][i];
-        }
-        double piv = 1.0;
-        for (int p = 0; p < j; ++p) piv -= R[p][j] * R[p][j];
-        if (!(piv * A[j][j] > tol * gdiag[j]) || !(piv > 0.0)) {
-            for (int i = 0; i < j; ++i) R[i][j] = 0.0;
-            break;
-        }
-        R[j][j] = sqrt(piv);
-        ok = j + 1;
+__device__ int chol_cut(double (&A)[S][S], const double* gdiag, int sa, double tol, double (&W)[S][S], double (&R)[S][S],
+                        double (&Ri)[S][S], double* dd, int* s_ok, int tid) {
+    const int i = tid / S, j = tid % S;
+    if (tid < S) dd[tid] = (tid < sa && A[tid][tid] > 0.0) ? sqrt(A[tid][tid]) : 0.0;
+    if (tid == 0) *s_ok = sa;
+    __syncthreads();
+    if (tid < S * S) {
+        W[i][j] = (i <= j && dd[i] > 0.0 && dd[j] > 0.0) ? A[i][j] / (dd[i] * dd[j]) : 0.0;
+        R[i][j] = 0.0;
+        Ri[i][j] = 0.0;
     }
-    for (int j = 0; j < ok; ++j)
-        for (int i = 0; i <= j; ++i) R[i][j] *= d[j];
-    for (int j = 0; j < ok; ++j) {
-        Ri[j][j] = 1.0 / R[j][j];
-        for (int i = 0; i < j; ++i) {
-            double s = 0.0;
-            for (int p = i; p < j; ++p) s += Ri[i][p] * R[p][j];
-            Ri[i][j] = -s * Ri[j][j];
+    __syncthreads();
+    for (int c = 0; c < sa; ++c) {
+        if (tid == 0) {
+            const double piv = W[c][c];
+            if (!(dd[c] > 0.0) || !(piv > 0.0) || !(piv * A[c][c] > tol * gdiag[c])) *s_ok = c;
+        }
+        __syncthreads();
+        if (*s_ok <= c) break;   // (uniform: read after the barrier)
+        const double rp = 1.0 / sqrt(W[c][c]);
+        __syncthreads();
+        if (tid < S && tid >= c) R[c][tid] = W[c][tid] * rp;   // row c of U (R[c][c] = sqrt(piv))
+        __syncthreads();
+        if (tid < S * S && i > c && i <= j) W[i][j] -= R[c][i] * R[c][j];
+        __syncthreads();
+    }
+    const int ok = *s_ok;
+    if (tid < S * S) R[i][j] = (i <= j && j < ok) ? R[i][j] * dd[j] : 0.0;
+    __syncthreads();
+    if (tid < ok) {   // column tid of the inverse by back substitution
+        const int cj = tid;
+        Ri[cj][cj] = 1.0 / R[cj][cj];
+        for (int r = cj - 1; r >= 0; --r) {
+            double acc = 0.0;
+            for (int p = r + 1; p <= cj; ++p) acc += R[r][p] * Ri[p][cj];
+            Ri[r][cj] = -acc / R[r][r];
         }
     }
+    __syncthreads();
     return ok;
 }
 
@@ -1070,15 +1078,17 @@ __device__ void gram_minus(const double* __restrict__ P, int k, double (&G)[S][S
 template <int S>
 __global__ __launch_bounds__(256) void k_ss_pass1(double* __restrict__ Sx, Off3 o3, int k, int sa_req, double tol,
                                                   int32_t* __restrict__ d_sa) {
-    __shared__ double G[S][S], A[S][S], R[S][S], Ri[S][S];
-    __shared__ double gd[S];
+    __shared__ double G[S][S], A[S][S], W[S][S], R[S][S], Ri[S][S];
+    __shared__ double gd[S], dd[S];
+    __shared__ int s_ok;
     const int tid = threadIdx.x;
     const double* P = Sx + o3.P;
     gram_minus<S>(P, k, G, A, tid);
     __syncthreads();
     if (tid < S) gd[tid] = G[tid][tid];
     __syncthreads();
-    if (tid == 0) d_sa[0] = chol_cut<S>(A, gd, sa_req, tol, R, Ri);
+    const int ok1 = chol_cut<S>(A, gd, sa_req, tol, W, R, Ri, dd, &s_ok, tid);
+    if (tid == 0) d_sa[0] = ok1;
     __syncthreads();
     for (int i = tid; i < k * S; i += 256) {
         const double v = P[i];
@@ -1100,8 +1110,8 @@ template <int S>
 __global__ __launch_bounds__(256) void k_ss_pass2(double* __restrict__ Sx, Off o, Off3 o3, int k, int sa_req, int m, double tol,
                                                   int32_t* __restrict__ d_sa, double* __restrict__ host_out) {
     extern __shared__ double dyn[];   // hc[m+2] | lcs[m] | lsn[m]
-    __shared__ double G[S][S], A[S][S], R2[S][S], R2i[S][S], R1[S][S], R1i[S][S], Rc[S][S], Rci[S][S];
-    __shared__ double gd[S], th[S];
+    __shared__ double G[S][S], A[S][S], W[S][S], R2[S][S], R2i[S][S], R1[S][S], R1i[S][S], Rc[S][S], Rci[S][S];
+    __shared__ double gd[S], th[S], dd[S];
     __shared__ int s_sa;
     double* hc = dyn;
     double* lcs = hc + (m + 2);
@@ -1125,9 +1135,7 @@ __global__ __launch_bounds__(256) void k_ss_pass2(double* __restrict__ Sx, Off o
         __syncthreads();
         if (tid < S) gd[tid] = G[tid][tid];
         __syncthreads();
-        if (tid == 0) s_sa = chol_cut<S>(A, gd, sa1, tol, R2, R2i);
-        __syncthreads();
-        sa = s_sa;
+        sa = chol_cut<S>(A, gd, sa1, tol, W, R2, R2i, dd, &s_sa, tid);
     }
     __syncthreads();
     const bool brk = sa == 0;
@@ -1252,6 +1260,70 @@ __global__ void k_ss_cycle_init(double* __restrict__ S, Off o, Off3 o3, int m, i
     }
 }
 
+// Real parts of the eigenvalues of a small upper Hessenberg matrix (column-major, leading dimension ld) by the unshifted QR
+// iteration with Givens rotations: crude (linear convergence), but the Ritz values only have to place the shifts of the Newton
+// block basis over the spectrum; whatever 2 x 2 blocks are left on the diagonal are resolved in closed form.
+static void hessenberg_real_parts(std::vector<double> H, int n, int ld, double* out) {
+    std::vector<double> cs((size_t)n), sn((size_t)n);
+    auto at = [&](int i, int j) -> double& { return H[(size_t)j * ld + i]; };
+    for (int sweep = 0; sweep < 500; ++sweep) {
+        for (int i = 0; i + 1 < n; ++i) {   // H <- Q^T H
+            const double a = at(i, i), b = at(i + 1, i), d = std::hypot(a, b);
+            cs[i] = d > 0 ? a / d : 1.0;
+            sn[i] = d > 0 ? b / d : 0.0;
+            for (int j = i; j < n; ++j) {
+                const double u = at(i, j), v = at(i + 1, j);
+                at(i, j) = cs[i] * u + sn[i] * v;
+                at(i + 1, j) = -sn[i] * u + cs[i] * v;
+            }
+        }
+        for (int i = 0; i + 1 < n; ++i)     // H <- H Q
+            for (int r = 0; r <= std::min(i + 1, n - 1); ++r) {
+                const double u = at(r, i), v = at(r, i + 1);
+                at(r, i) = cs[i] * u + sn[i] * v;
+                at(r, i + 1) = -sn[i] * u + cs[i] * v;
+            }
+    }
+    for (int i = 0; i < n;) {
+        const double sub = i + 1 < n ? std::fabs(at(i + 1, i)) : 0.0;
+        if (i + 1 < n && sub > 1e-10 * (std::fabs(at(i, i)) + std::fabs(at(i + 1, i + 1)))) {
+            const double a = at(i, i), b = at(i, i + 1), c2 = at(i + 1, i), d = at(i + 1, i + 1);
+            const double tr = 0.5 * (a + d), disc = 0.25 * (a - d) * (a - d) + b * c2;
+            const double rt = disc > 0.0 ? std::sqrt(disc) : 0.0;   // complex pair: its real part, twice
+            out[i] = tr + rt;
+            out[i + 1] = tr - rt;
+            i += 2;
+        } else {
+            out[i] = at(i, i);
+            ++i;
+        }
+    }
+}
+
+// Leja ordering: the largest point first, then always the point that maximises the product of its distances to the points taken;
+// every prefix of the sequence is then spread over the whole set (a short last block uses a prefix)
+static void leja_order(double* v, int n) {
+    std::vector<double> in(v, v + n), out;
+    std::vector<char> used((size_t)n, 0);
+    for (int t = 0; t < n; ++t) {
+        int best = -1;
+        double bestv = -1e300;
+        for (int i = 0; i < n; ++i) {
+            if (used[(size_t)i]) continue;
+            double score = 0.0;
+            if (out.empty()) score = std::fabs(in[(size_t)i]);
+            else for (double o : out) score += std::log(std::max(std::fabs(in[(size_t)i] - o), 1e-300));
+            if (score > bestv) {
+                bestv = score;
+                best = i;
+            }
+        }
+        used[(size_t)best] = 1;
+        out.push_back(in[(size_t)best]);
+    }
+    std::copy(out.begin(), out.end(), v);
+}
+
 template <int S>
 static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart,
                              int use_prec, int* its_out, double* relres_out) {
@@ -1317,9 +1389,10 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
         hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, out, nblk, (const int32_t*)nullptr);
         return allreduce_sum(c, out, 1);
     };
-    auto apply_B = [&](const double* in, double* out) -> int {  // out = A M^-1 in  (basis columns: no ghost tail)
+    // out = A M^-1 in - theta in  (basis columns: no ghost tail; the shift rides in the SpMV kernel's store)
+    auto apply_B = [&](const double* in, double* out, double theta) -> int {
         if (use_prec) FEDD_TRY(schwarz_apply(c, in, z, false));
-        return spmv_owned(c, use_prec ? z : in, out, use_prec);
+        return spmv_owned(c, use_prec ? z : in, out, use_prec, theta != 0.0 ? in : nullptr, theta);
     };
 
     FEDD_HIP(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), st));  // "Zero Initial Guess" (LinearSolver_def.hpp:76-78)
@@ -1378,8 +1451,16 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     // the recurrence residual of a block basis of condition kappa is good to about eps * kappa; measured on the Laplace cubes
     // (monomial basis): it parts from the true residual near 1e-11 for s = 8 and near 2e-13 for s = 4.  Below those floors a
     // claim fails its check and costs a restart, so tight tolerances take shorter blocks from the start.
-    const int s_tol = rtol >= 1e-9 ? 8 : (rtol >= 1e-11 ? 5 : 3);
-    int s_cur = std::max(1, std::min(std::min(c->gmres_s, S), s_tol));
+    const int s_tol = rtol >= 1e-9 ? 16 : (rtol >= 1e-11 ? 5 : 3);
+    const int s_goal = std::max(1, std::min(std::min(c->gmres_s, S), s_tol));
+    // Blocks longer than 8 need a better conditioned block basis than the monomial one (its condition grows tenfold every
+    // two vectors, 1e7 at s = 8): the Newton basis w_i = (B - theta_i) w_{i-1} with the Ritz values of the first s_goal
+    // Arnoldi steps as shifts, Leja-ordered (Bai, Hu, Reichel, "A Newton basis GMRES implementation", 1994).  Until those
+    // steps exist the blocks are monomial and at most 8 long.
+    const bool newton = c->gmres_newton && s_goal > 1;
+    bool have_shifts = false;
+    std::vector<double> theta((size_t)S, 0.0);
+    int s_cur = std::min(s_goal, 8);
     const bool dbg = getenv("FEDD_GMRES_DEBUG") != nullptr;
     double tol_abs = rtol * beta0;      // target of the recurrence residual; tightened when the true residual lags behind it
     double last_true = beta0;
@@ -1398,10 +1479,11 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
             const int room = std::min(m - (k - 1), max_it - its - (k - 1));
             if (room <= 0) break;
             const int sa = std::min(s_cur, room);
-            for (int i = 0; i < sa; ++i) FEDD_TRY(apply_B(V + (int64_t)(k - 1 + i) * ldv, V + (int64_t)(k + i) * ldv));
+            for (int i = 0; i < sa; ++i)
+                FEDD_TRY(apply_B(V + (int64_t)(k - 1 + i) * ldv, V + (int64_t)(k + i) * ldv, have_shifts ? theta[(size_t)i] : 0.0));
             {
                 ScopedTimer t(c, FEDD_T_ORTHO);
-                const int ncg = (k + sa + SS_CG - 1) / SS_CG;
+                const int ncg = (k + sa + ss_cg(S) - 1) / ss_cg(S);
                 const dim3 gd(nblkd, std::min(gy_dot, ncg));
                 const double dot_bytes = 8.0 * (double)n * (k + 2 * sa), upd_bytes = 8.0 * (double)n * (k + 2 * sa);
                 {
@@ -1515,6 +1597,28 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
             }
             k += sa_eff;
             if (sa_eff < sa) s_cur = std::max(1, sa_eff);   // the block basis became dependent: shorter blocks from here on
+            else if (newton && !have_shifts && k - 1 >= s_goal) {
+                // the shifts, once per solve: Ritz values of the leading s_goal x s_goal Hessenberg matrix
+                std::vector<double> Hh((size_t)s_goal * s_goal);
+                FEDD_HIP(hipMemcpy2DAsync(Hh.data(), (size_t)s_goal * sizeof(double), Sx + o3.Hraw, (size_t)(m + 1) * sizeof(double),
+                                          (size_t)s_goal * sizeof(double), (size_t)s_goal, hipMemcpyDeviceToHost, st));
+                FEDD_HIP(hipStreamSynchronize(st));
+                hessenberg_real_parts(Hh, s_goal, s_goal, theta.data());
+                leja_order(theta.data(), s_goal);
+                bool finite = true;
+                for (int i = 0; i < s_goal; ++i) finite = finite && std::isfinite(theta[(size_t)i]);
+                if (finite) {
+                    for (int i = 0; i < S; ++i) c->h_pinned[64 + i] = i < s_goal ? theta[(size_t)i] : 0.0;
+                    FEDD_HIP(hipMemcpyAsync(Sx + o3.th, c->h_pinned + 64, (size_t)S * sizeof(double), hipMemcpyHostToDevice, st));
+                    have_shifts = true;
+                    s_cur = s_goal;
+                    if (dbg) {
+                        fprintf(stderr, "[gmres s-step] Newton shifts:");
+                        for (int i = 0; i < s_goal; ++i) fprintf(stderr, " %.4f", theta[(size_t)i]);
+                        fprintf(stderr, "\n");
+                    }
+                }
+            }
         }
         if (done) break;
         if (!restart_now) {   // cycle used up (restart length or iteration limit)
@@ -1545,7 +1649,8 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
                 int* its_out, double* relres_out) {
     if (c->gmres_kind == 2 && !c->gm_mask) {
         if (c->gmres_s <= 4) return gmres_solve_sstep<4>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
-        return gmres_solve_sstep<8>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
+        if (c->gmres_s <= 8) return gmres_solve_sstep<8>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
+        return gmres_solve_sstep<16>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
     }
     if (c->gmres_kind == 0 || c->gmres_kind == 2 || c->gm_mask) return gmres_solve_dcgs2(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
     const int64_t n = c->n_rows;

@@ -12,10 +12,18 @@
 namespace fedd {
 namespace {
 
+// optional epilogue of every SpMV kernel: y = A x - theta * sub (the shifted operator application of the s-step solver's Newton
+// block basis, gmres.hip: one more vector read instead of a kernel of its own); sub == nullptr: y = A x
+struct SpmvEpi {
+    const double* sub;
+    double theta;
+};
+__device__ __forceinline__ double epi_apply(const SpmvEpi& e, double s, int64_t r) { return e.sub ? s - e.theta * e.sub[r] : s; }
+
 template <int LPR>
 __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                               const double* __restrict__ val, const double* __restrict__ x,
-                                              double* __restrict__ y, int32_t n_rows) {
+                                              double* __restrict__ y, int32_t n_rows, SpmvEpi epi) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int32_t row = (int32_t)(gid / LPR);
     const int l = (int)(gid % LPR);
@@ -26,7 +34,7 @@ __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ rowptr
     }
 #pragma unroll
     for (int off = LPR / 2; off > 0; off >>= 1) sum += __shfl_down(sum, off, LPR);
-    if (l == 0 && row < n_rows) y[row] = sum;
+    if (l == 0 && row < n_rows) y[row] = epi_apply(epi, sum, row);
 }
 
 // "CSR-stream": a workgroup owns the rows whose first entry lies in its SP_CHUNK-wide window of
@@ -57,7 +65,7 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__
                                                      const int32_t* __restrict__ colind,
                                                      const double* __restrict__ val, const double* __restrict__ x,
                                                      double* __restrict__ y, const int32_t* __restrict__ block_row,
-                                                     int32_t nb) {
+                                                     int32_t nb, SpmvEpi epi) {
     extern __shared__ double prod[];
     const int tid = threadIdx.x;
     // bijective XCD remap (blocks b and b+8 share an XCD): XCD k gets a contiguous range
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__
         const int32_t b = (first ? rb0 : rowptr[r]) - base, e = (first ? re0 : rowptr[r + 1]) - base;
         double s = 0.0;
         for (int32_t p = b; p < e; ++p) s += prod[p];
-        y[r] = s;
+        y[r] = epi_apply(epi, s, r);
     }
 }
 
@@ -118,7 +126,7 @@ template <bool NT, int NU = SP_CHUNK / 256>
 __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                   const double* __restrict__ val, const double* __restrict__ x,
                                                   double* __restrict__ y, const int32_t* __restrict__ block_row,
-                                                  int32_t nb, int32_t nnz, int32_t ovh) {
+                                                  int32_t nb, int32_t nnz, int32_t ovh, SpmvEpi epi) {
     extern __shared__ double prod[];
     constexpr int CH = 256 * NU;
     const int tid = threadIdx.x;
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ ro
         const int32_t e = (trip == 0 ? re0 : trip == 1 ? re1 : rowptr[r + 1]) - base;
         double s = 0.0;
         for (int32_t p = b; p < e; ++p) s += prod[p];
-        y[r] = s;
+        y[r] = epi_apply(epi, s, r);
     }
 }
 
@@ -467,7 +475,8 @@ __global__ __launch_bounds__(256) void k_spmv_pat(const int32_t* __restrict__ ro
                                                   const double* __restrict__ val, const uint16_t* __restrict__ pat,
                                                   const int32_t* __restrict__ plen, const int32_t* __restrict__ pdelta,
                                                   int32_t n_pat, const double* __restrict__ x, double* __restrict__ y,
-                                                  const int32_t* __restrict__ block_row, int32_t nb, int32_t nnz, int32_t ovh) {
+                                                  const int32_t* __restrict__ block_row, int32_t nb, int32_t nnz, int32_t ovh,
+                                                  SpmvEpi epi) {
     extern __shared__ double sval[];                    // [CH + ovh]
     __shared__ int32_t sdelta[SPAT_P * SPAT_L];
     __shared__ int32_t slen[SPAT_P];
@@ -530,7 +539,7 @@ __global__ __launch_bounds__(256) void k_spmv_pat(const int32_t* __restrict__ ro
                 }
             }
         }
-        y[r] = s;
+        y[r] = epi_apply(epi, s, r);
     }
 }
 
@@ -628,8 +637,9 @@ static int spmv_compact_build(fedd_ctx* c) {
     return 0;
 }
 
-int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_has_tail) {
+int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_has_tail, const double* d_sub, double theta) {
     const double* x = d_x_owned;
+    const SpmvEpi epi{d_sub, theta};
     if (c->n_cols != c->n_rows || !c->halo.peers.empty()) {   // also a rank that only sends takes part
         if (x_has_tail) {   // the caller's buffer takes the ghost values behind its owned entries
             FEDD_TRY(halo_import(c, const_cast<double*>(d_x_owned), c->dofs));
@@ -665,7 +675,7 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
 #define SPMV_PAT1(NT_, NU_, LU_)                                                                                                    \
     hipLaunchKernelGGL((k_spmv_pat<NT_, NU_, LU_>), dim3((unsigned)nbp), dim3(256), ldp, c->stream, (const int32_t*)c->d_cs_rowptr.p, \
                        (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, (const uint16_t*)c->d_cs_pat.p, plen,           \
-                       pdelta, c->cs_npat, x, d_y_owned, (const int32_t*)c->d_cs_prows.p, nbp, (int32_t)c->cs_nnz, ovh)
+                       pdelta, c->cs_npat, x, d_y_owned, (const int32_t*)c->d_cs_prows.p, nbp, (int32_t)c->cs_nnz, ovh, epi)
 #define SPMV_PAT(NT_, NU_)                                 \
     if (c->cs_pat_len <= 8) SPMV_PAT1(NT_, NU_, 8);         \
     else SPMV_PAT1(NT_, NU_, SPAT_L)
@@ -687,7 +697,7 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
 #define SPMV_WIN(NT_, NU_)                                                                                                       \
     hipLaunchKernelGGL((k_spmv_win<NT_, NU_>), dim3((unsigned)nbc), dim3(256), lds, c->stream, (const int32_t*)c->d_cs_rowptr.p, \
                        (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, x, d_y_owned,                               \
-                       (const int32_t*)c->d_cs_rows.p, nbc, (int32_t)c->cs_nnz, ovh)
+                       (const int32_t*)c->d_cs_rows.p, nbc, (int32_t)c->cs_nnz, ovh, epi)
 #define SPMV_WIN_NU(NT_)                 \
     switch (wnu) {                       \
         case 4: SPMV_WIN(NT_, 4); break; \
@@ -715,15 +725,15 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
         if (windowed && nt)
             hipLaunchKernelGGL(k_spmv_win<true>, dim3((unsigned)nb), dim3(256), lds, c->stream, (const int32_t*)c->d_rowptr.p,
                                (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, x, d_y_owned,
-                               (const int32_t*)c->d_spmv_rows.p, nb, (int32_t)c->nnz, ovh);
+                               (const int32_t*)c->d_spmv_rows.p, nb, (int32_t)c->nnz, ovh, epi);
         else if (windowed)
             hipLaunchKernelGGL(k_spmv_win<false>, dim3((unsigned)nb), dim3(256), lds, c->stream, (const int32_t*)c->d_rowptr.p,
                                (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, x, d_y_owned,
-                               (const int32_t*)c->d_spmv_rows.p, nb, (int32_t)c->nnz, ovh);
+                               (const int32_t*)c->d_spmv_rows.p, nb, (int32_t)c->nnz, ovh, epi);
         else
             hipLaunchKernelGGL(k_spmv_stream, dim3((unsigned)nb), dim3(256), lds, c->stream, (const int32_t*)c->d_rowptr.p,
                                (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, x, d_y_owned,
-                               (const int32_t*)c->d_spmv_rows.p, nb);
+                               (const int32_t*)c->d_spmv_rows.p, nb, epi);
         ts.stop();
         FEDD_HIP(hipGetLastError());
         return 0;
@@ -732,7 +742,7 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
 #define SPMV_LAUNCH(L)                                                                                        \
     hipLaunchKernelGGL(k_spmv<L>, dim3((unsigned)(((int64_t)n * L + 255) / 256)), dim3(256), 0, c->stream,      \
                        (const int32_t*)c->d_rowptr.p, (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, \
-                       x, d_y_owned, n)
+                       x, d_y_owned, n, epi)
     if (avg <= 4.0) SPMV_LAUNCH(4);
     else if (avg <= 10.0) SPMV_LAUNCH(8);
     else if (avg <= 24.0) SPMV_LAUNCH(16);

@@ -326,7 +326,9 @@ int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_bloc
  * matrix, 0 = off; "spmv_pat_nu" / "spmv_win_nu" window sizes of the pattern / per-entry SpMV kernels (0 = default); "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
  * matrix cores, 2 = scalar-pivot without dropping rows;
  * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes, 2 = s-step GMRES: the
- * basis grows "gmres_s" (1 ... 8, default 8) vectors at a time and each block is orthogonalised by block Gram-Schmidt with two
+ * basis grows "gmres_s" (1 ... 16) vectors at a time -- blocks longer than 8 on the Newton block basis ("gmres_newton" 1, the
+ * default: shifts = Leja-ordered Ritz values of the first gmres_s Arnoldi steps, which run in monomial blocks of at most 8; 0 =
+ * monomial basis, blocks of at most 8) -- and each block is orthogonalised by block Gram-Schmidt with two
  * passes (four sweeps over the basis and two reductions per block instead of two sweeps and one reduction per iteration; same
  * iterates as 0 / 1 in exact arithmetic; a block is cut where the squared sine of a new vector against its predecessors falls
  * to "gmres_chol_tol", default 1e-13; the convergence claim is checked against the true residual and the residual returned is

@@ -264,6 +264,7 @@ def test_spmv_column_patterns_give_the_same_bits(fedd_lib, ctx, dim, M, dofs):
     nr = ctx.csr_sizes()[0]
     x = np.random.default_rng(7).standard_normal(nr)
     ctx.set_option("spmv_pattern", 0)
+    ctx.set_option("spmv_exact_public", 0)     # fedd_spmv = the solver's stream in this test
     y0 = ctx.spmv(x)
     assert ctx.spmv_info()["column_patterns"] == 0
     try:
@@ -280,6 +281,7 @@ def test_spmv_column_patterns_give_the_same_bits(fedd_lib, ctx, dim, M, dofs):
             assert info["column_patterns"] == 0 or info["rows_with_explicit_columns"] > 0
     finally:
         ctx.set_option("spmv_pattern", 1)
+        ctx.set_option("spmv_exact_public", 1)
         ctx.set_option("spmv_pat_nu", 0)
 
 

@@ -727,6 +727,7 @@ def _thread_rank_patterns(capi, group, rank, dec, M, out, errs):
         c.assemble(capi.FORM_LAPLACE)
         c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
         xg = np.random.default_rng(21).standard_normal(m["n_global"])
+        c.set_option("spmv_exact_public", 0)     # fedd_spmv = the solver's stream in this test
         c.set_option("spmv_pattern", 0)
         y0 = c.spmv(xg[m["gid_uni"]])
         c.set_option("spmv_pattern", 2)
@@ -762,3 +763,80 @@ def test_spmv_column_patterns_with_ghost_columns(fedd_lib):
         used += o["info"]["column_patterns"] > 0
     assert used >= 1        # (at least one rank's rows repeat enough for the dictionary to be used)
 
+
+
+def _thread_rank_at_size(capi, group, rank, dec, cells, problem, target, ghosts, out, errs):
+    """one rank of a headline configuration in its own decomposition, at full size: assemble, solve to the XML's tolerance,
+    return the rank's pieces of ||b - A x||^2 and ||b||^2 (b - A x formed with fedd_spmv = the parity CSR + a halo import)"""
+    try:
+        world = group.world
+        m = capi.structured_mesh(3, dec, cells, rank, ghosts=ghosts)
+        c = capi.Context(device=0, rank=rank, nranks=world, nccl_id=None)
+        c.mesh_set_dict(m)
+        c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, cells, m["gid_rep"]))
+        c.comm_set_thread_group(group)
+        n_own = m["gid_uni"].shape[0]
+        del m
+        if problem == "laplace":
+            nnz = c.pattern_build(1, capi.BLOCK_SCALAR)
+            c.assemble(capi.FORM_LAPLACE)
+            c.assemble_rhs([1.0])
+            c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+            c.schwarz_set_target(target, 1.0)
+            c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+            rtol = 1e-8
+        else:
+            mu, nu = 2.0e6, 0.4
+            lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
+            nnz = c.pattern_build(3, capi.BLOCK_FULL)
+            c.assemble(capi.FORM_LINELAS, [lam, mu])
+            c.assemble_rhs([0.0, 1.0, 0.0])
+            c.dirichlet([2], [0.0, 0.0, 0.0])
+            c.schwarz_set_target(target, 1.0)
+            c.schwarz_setup(1, capi.COMBINE_RESTRICTED, two_level=1, coarse_kind=capi.COARSE_Q1)
+            rtol = 1e-6
+        x, its, rel = c.gmres(None, rtol=rtol, max_it=2000, restart=100, use_prec=True)
+        b = c.rhs_get()
+        r = b - c.spmv(x)
+        out[rank] = dict(n_own=n_own, nnz=nnz, its=its, rel=rel, rr=float(r @ r), bb=float(b @ b), xmax=float(np.abs(x).max()),
+                         peers=len(c.halo_plan()["peers"]))
+        c.close()
+    except Exception as e:      # pragma: no cover
+        import traceback
+        errs.append("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+        try:
+            group._barrier.abort()
+        except Exception:
+            pass
+
+
+@pytest.mark.parametrize("problem,M,target,ghosts,n_nodes,its_lo,its_hi",
+                         [("laplace", 107, 64, 5, 215 ** 3, 140, 150),      # BASELINE cfg 3 as the reference decomposes it
+                          ("linelas", 94, 8, 3, 189 ** 3, 20, 400)])         # BASELINE cfg 5 (Q1 coarse space)
+def test_headline_configs_in_their_own_decomposition_at_size(fedd_lib, problem, M, target, ghosts, n_nodes, its_lo, its_hi):
+    """cfg 3 (214^3 cells) and cfg 5 (188^3 cells, 20 253 807 dofs) as 2 x 2 x 2 blocks, the eight ranks as threads on one
+    GPU (host-staged transport; a one-GPU box admits no eight processes): every dof owned once, the same iteration count
+    on every rank, and the gathered TRUE residual of the distributed solve below the XML's tolerance."""
+    import threading
+    dec = (2, 2, 2)
+    group = fedd_lib.ThreadGroup(8, timeout=900.0)
+    out, errs = [None] * 8, []
+    th = [threading.Thread(target=_thread_rank_at_size, args=(fedd_lib, group, r, dec, [M] * 3, problem, target, ghosts, out, errs))
+          for r in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=1100)
+    assert not errs, "\n".join(errs)
+    assert all(o is not None for o in out)
+    assert sum(o["n_own"] for o in out) == n_nodes
+    assert len({o["its"] for o in out}) == 1 and its_lo <= out[0]["its"] <= its_hi, [o["its"] for o in out]
+    rtol = 1e-8 if problem == "laplace" else 1e-6
+    true_rel = (sum(o["rr"] for o in out) / sum(o["bb"] for o in out)) ** 0.5
+    assert true_rel <= rtol and all(o["rel"] <= rtol for o in out), (true_rel, [o["rel"] for o in out])
+    assert max(o["peers"] for o in out) == 7
+    if problem == "laplace":
+        assert sum(o["nnz"] for o in out) == 147968803                     # SURVEY 8a: the reference's nnz of cfg 3
+        assert abs(max(o["xmax"] for o in out) - 0.05621) < 1e-4           # centre value of -lap u = 1 on the unit cube
+    else:
+        assert sum(o["nnz"] for o in out) == 903725973                     # ... and of cfg 5

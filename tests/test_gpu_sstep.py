@@ -16,6 +16,7 @@ def ctx(fedd_lib):
     c = fedd_lib.Context(device=0)
     yield c
     c.set_option("gmres_kind", 2)
+    c.set_option("gmres_s", 16)
     c.close()
 
 
@@ -23,19 +24,26 @@ def _true_relres(A, b, x):
     return float(np.linalg.norm(b - A @ x) / np.linalg.norm(b))
 
 
-@pytest.mark.parametrize("s", [1, 2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("s", [1, 2, 3, 4, 5, 7, 8, 11, 12, 16])
 def test_same_iterations_as_the_one_vector_solver(fedd_lib, ctx, s):
-    """rtol 1e-8 (laplace/parametersSolver.xml): identical iteration count, true residual below the tolerance"""
-    m, om, A_bc, rhs_bc = _setup_laplace(fedd_lib, ctx, 3, 20)
-    ctx.schwarz_set_target(27, 1.0)
-    ctx.schwarz_setup(overlap=1, combine=fedd_lib.COMBINE_RESTRICTED)
+    """rtol 1e-8 (laplace/parametersSolver.xml): identical iteration count, true residual below the tolerance.  Blocks longer
+    than 8 (Newton basis) on the unpreconditioned operator, which takes enough iterations for several of them."""
+    prec = s <= 8
+    m, om, A_bc, rhs_bc = _setup_laplace(fedd_lib, ctx, 3, 20 if prec else 16)
+    if prec:
+        ctx.schwarz_set_target(27, 1.0)
+        ctx.schwarz_setup(overlap=1, combine=fedd_lib.COMBINE_RESTRICTED)
     ctx.set_option("gmres_kind", 0)
-    x0, its0, rel0 = ctx.gmres(None, rtol=1e-8, max_it=400, restart=100, use_prec=True)
+    x0, its0, rel0 = ctx.gmres(None, rtol=1e-8, max_it=400, restart=100, use_prec=prec)
     ctx.set_option("gmres_kind", 2)
     ctx.set_option("gmres_s", s)
-    x, its, rel = ctx.gmres(None, rtol=1e-8, max_it=400, restart=100, use_prec=True)
+    x, its, rel = ctx.gmres(None, rtol=1e-8, max_it=400, restart=100, use_prec=prec)
     info = ctx.gmres_info()
     assert info["kind"] == 2 and info["s"] == s and info["blocks"] >= (its + s - 1) // s
+    if s > 8:      # the long blocks were used: two monomial 8-blocks at most before the shifts exist
+        assert its >= 2 * s and info["blocks"] <= 2 + (its - s + s - 1) // s + info["cut_blocks"], (its, info)
+    else:
+        assert info["cut_blocks"] == 0
     assert abs(its - its0) <= 1, (its, its0)
     tr = _true_relres(A_bc, rhs_bc, x)
     assert tr <= 1e-8 and abs(rel - tr) <= 1e-3 * tr       # the reported residual IS the true one
@@ -112,15 +120,32 @@ def test_dependent_block_is_cut_not_trusted(fedd_lib, ctx):
     np.testing.assert_allclose(x, xd, rtol=0, atol=1e-7 * np.abs(xd).max())
 
 
-def test_bitwise_reproducible(fedd_lib, ctx):
+@pytest.mark.parametrize("s", [8, 16])
+def test_bitwise_reproducible(fedd_lib, ctx, s):
     m, om, A_bc, rhs_bc = _setup_laplace(fedd_lib, ctx, 3, 14)
-    ctx.schwarz_set_target(27, 1.0)
+    ctx.schwarz_set_target(8, 1.0)
     ctx.schwarz_setup(overlap=1, combine=fedd_lib.COMBINE_RESTRICTED)
     ctx.set_option("gmres_kind", 2)
-    ctx.set_option("gmres_s", 8)
+    ctx.set_option("gmres_s", s)
     x1, its1, _ = ctx.gmres(None, rtol=1e-9, max_it=300, restart=100, use_prec=True)
     x2, its2, _ = ctx.gmres(None, rtol=1e-9, max_it=300, restart=100, use_prec=True)
     assert its1 == its2 and np.array_equal(x1, x2)
+
+
+def test_newton_basis_is_what_makes_long_blocks_hold(fedd_lib, ctx):
+    """s = 16 on the monomial basis runs in blocks of at most 8 (by construction); on the Newton basis the 16-blocks go through"""
+    m, om, A_bc, rhs_bc = _setup_laplace(fedd_lib, ctx, 3, 16)
+    ctx.set_option("gmres_kind", 2)
+    ctx.set_option("gmres_s", 16)
+    out = {}
+    for newton in (0, 1):
+        ctx.set_option("gmres_newton", newton)
+        x, its, rel = ctx.gmres(None, rtol=1e-8, max_it=400, restart=100, use_prec=False)
+        out[newton] = (x, its, ctx.gmres_info()["blocks"])
+        assert rel <= 1e-8 and _true_relres(A_bc, rhs_bc, x) <= 1e-8
+    ctx.set_option("gmres_newton", 1)
+    assert abs(out[0][1] - out[1][1]) <= 1 and out[1][2] < out[0][2], [(o[1], o[2]) for o in out.values()]
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=1e-7 * np.abs(out[0][0]).max())
 
 
 def test_elasticity_and_two_level(fedd_lib, ctx):
@@ -140,7 +165,7 @@ def test_elasticity_and_two_level(fedd_lib, ctx):
         ctx.schwarz_setup(overlap=1, combine=fedd_lib.COMBINE_RESTRICTED, two_level=two, coarse_kind=fedd_lib.COARSE_Q1)
         for kind in (0, 2):
             ctx.set_option("gmres_kind", kind)
-            ctx.set_option("gmres_s", 8)
+            ctx.set_option("gmres_s", 16)
             x, its, rel = ctx.gmres(None, rtol=1e-8, max_it=500, restart=100, use_prec=True)
             out[(two, kind)] = (x, its, rel)
         x0, i0, _ = out[(two, 0)]

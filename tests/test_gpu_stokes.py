@@ -129,9 +129,11 @@ def test_small_stokes_solve(fedd_lib, ctx):
     rowptr, col, val, gid = ctx.csr_get()
     assert_matrix_close(sp.csr_matrix((val, col, rowptr), shape=(n, n)), M_bc)
     np.testing.assert_allclose(ctx.rhs_get(), rhs_bc, atol=1e-15)
-    x, its, rel = ctx.gmres(None, rtol=1e-13, max_it=n, restart=n, use_prec=False)
+    # (the default solver reports the TRUE residual: full GMRES on this indefinite system (cond ~ 2e4) leaves the true residual
+    # near 1e-10 when its recurrence says 1e-13 after n steps -- one more cycle from there reaches the tolerance)
+    x, its, rel = ctx.gmres(None, rtol=1e-12, max_it=3 * n, restart=n, use_prec=False)
     xd = fo.direct_solve(M_bc, rhs_bc)
-    assert rel <= 1e-12
+    assert rel <= 1e-12 and np.linalg.norm(rhs_bc - M_bc @ x) <= 1e-11 * np.linalg.norm(rhs_bc)
     np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
 
 
