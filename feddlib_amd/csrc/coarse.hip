@@ -332,6 +332,17 @@ __global__ __launch_bounds__(256) void k_fix_diag(double* __restrict__ K, int64_
 // =====================================================================================================
 template <int DIM> struct GdswCfg { static constexpr int NCLS = DIM == 3 ? 26 : 8; };
 
+// The classes that carry coarse functions, numbered compactly: GDSW all 3^dim - 1, RGDSW the classes of the coarse nodes only
+// (2^dim of them where every direction has >= 2 cells).  The basis is stored slot-major over these ACTIVE slots only:
+// Phi_T[a][row], a = active class index * dofs + component, leading dimension ldp >= n_rows: every kernel below reads it with
+// consecutive lanes on consecutive rows (the row-major [row][78] layout of round 2 made each lane walk its own 624-byte line:
+// 3.5 ms per application at 2.6 M dofs), and RGDSW moves 24 instead of 78 columns.
+struct GdAct {
+    int n;             // active classes
+    int8_t cls[26];    // active index -> class
+    int8_t idx[26];    // class -> active index, -1: carries no function
+};
+
 // class code of an entity coordinate: 0 even, 1 = 1 mod 4, 2 = 3 mod 4
 __device__ __forceinline__ int gd_code(int e) { return (e & 1) ? ((e & 3) == 1 ? 1 : 2) : 0; }
 
@@ -482,8 +493,8 @@ __global__ void k_gd_node_entity(CoarseGeom cg, const int32_t* __restrict__ conn
 // Phi <- Phi_Gamma (interface rows: 1 in the class of their own entity, component a; Dirichlet rows 0), interior
 // rows 0; imask = 1 on free interior dofs (the unknowns of the extension solves), 0 elsewhere
 template <int DIM>
-__global__ void k_gd_phi_init(CoarseGeom cg, const int32_t* __restrict__ ent, int dofs, int64_t n_rows,
-                              const double* __restrict__ mask, double* __restrict__ phi, double* __restrict__ imask) {
+__global__ void k_gd_phi_init(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int64_t n_rows, int64_t ldp,
+                              const double* __restrict__ mask, double* __restrict__ phiT, double* __restrict__ imask) {
     constexpr int NCLS = GdswCfg<DIM>::NCLS;
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
@@ -492,9 +503,9 @@ __global__ void k_gd_phi_init(CoarseGeom cg, const int32_t* __restrict__ ent, in
     int e[3];
     gd_entity_coords<DIM>(cg, ent[node], e);
     const int cls = gd_class<DIM>(e);
-    const int nsd = NCLS * dofs;
-    for (int s = 0; s < nsd; ++s) phi[r * nsd + s] = 0.0;
-    if (cls >= 0 && !cg.reduced) phi[r * nsd + cls * dofs + a] = mask[r];
+    const int nsa = act.n * dofs;
+    for (int s = 0; s < nsa; ++s) phiT[(int64_t)s * ldp + r] = 0.0;
+    if (cls >= 0 && !cg.reduced && act.idx[cls] >= 0) phiT[(int64_t)(act.idx[cls] * dofs + a) * ldp + r] = mask[r];
     if (cls >= 0 && cg.reduced) {
         // RGDSW, option 1 (Dohrmann, Widlund 2017): an interface node of entity e gets the value 1 / |C(e)| for every
         // coarse node of C(e), the coarse nodes adjacent to e: e_d odd stays, an even e_d (direction with >= 2 cells)
@@ -506,24 +517,24 @@ __global__ void k_gd_phi_init(CoarseGeom cg, const int32_t* __restrict__ ent, in
         for (int pass = 0; pass < 2; ++pass)
             for (int c2 = 0; c2 < NCLS; ++c2) {
                 int v[3] = {0, 0, 0};
-                if (!gd_entity_of<DIM>(cg, h, c2, v) || !gd_is_coarse_node<DIM>(cg, v)) continue;
+                if (act.idx[c2] < 0 || !gd_entity_of<DIM>(cg, h, c2, v) || !gd_is_coarse_node<DIM>(cg, v)) continue;
                 bool adj = true;
 #pragma unroll
                 for (int d = 0; d < DIM; ++d) adj = adj && ((e[d] & 1) ? v[d] == e[d] : (cg.g[d] >= 2 ? (v[d] == e[d] - 1 || v[d] == e[d] + 1) : v[d] == e[d]));
                 if (!adj) continue;
                 if (pass == 0) ++count;
-                else phi[r * nsd + c2 * dofs + a] = mask[r] / (double)count;
+                else phiT[(int64_t)(act.idx[c2] * dofs + a) * ldp + r] = mask[r] / (double)count;
             }
     }
     imask[r] = cls < 0 ? mask[r] : 0.0;
 }
 
-// v = column (cls, k) of Phi on the interface rows, 0 on the interior rows
-__global__ void k_gd_gamma_col(const double* __restrict__ phi, const double* __restrict__ imask, int64_t n_rows, int nsd,
-                               int slot, const double* __restrict__ mask, double* __restrict__ v) {
+// v = one column of Phi on the interface rows, 0 on the interior rows
+__global__ void k_gd_gamma_col(const double* __restrict__ phi_col, const double* __restrict__ imask, int64_t n_rows,
+                               const double* __restrict__ mask, double* __restrict__ v) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
-    v[r] = (imask[r] == 0.0 && mask[r] != 0.0) ? phi[r * nsd + slot] : 0.0;
+    v[r] = (imask[r] == 0.0 && mask[r] != 0.0) ? phi_col[r] : 0.0;
 }
 
 // b = -imask o w
@@ -532,20 +543,19 @@ __global__ void k_gd_rhs(const double* __restrict__ imask, const double* __restr
     if (r < n_rows) b[r] = imask[r] != 0.0 ? -w[r] : 0.0;
 }
 
-// interior rows: Phi[r][slot] = x[r]
-__global__ void k_gd_store(const double* __restrict__ imask, const double* __restrict__ x, int64_t n_rows, int nsd, int slot,
-                           double* __restrict__ phi) {
+// interior rows: Phi column = x
+__global__ void k_gd_store(const double* __restrict__ imask, const double* __restrict__ x, int64_t n_rows, double* __restrict__ phi_col) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n_rows && imask[r] != 0.0) phi[r * nsd + slot] = x[r];
+    if (r < n_rows && imask[r] != 0.0) phi_col[r] = x[r];
 }
 
 // restriction, step 1: per home cell the sums over its rows of Phi[r][slot] * rv[r], slot chunk `blockIdx.y` of 16,
 // fixed-order workgroup reduction (same pattern as k_restrict_cells)
 __global__ __launch_bounds__(256) void k_gd_restrict_cells(const int32_t* __restrict__ cell_ptr,
-                                                           const int32_t* __restrict__ cell_nodes, int dofs, int nsd,
-                                                           const double* __restrict__ phi, const double* __restrict__ rv,
+                                                           const int32_t* __restrict__ cell_nodes, int dofs, int nsd, int64_t ldp,
+                                                           const double* __restrict__ phiT, const double* __restrict__ rv,
                                                            double* __restrict__ part) {
-    constexpr int CH = 16;
+    constexpr int CH = 8;
     __shared__ double red[4][CH];
     const int cell = blockIdx.x, s0 = blockIdx.y * CH, tid = threadIdx.x;
     double acc[CH];
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(256) void k_gd_restrict_cells(const int32_t* __rest
         const double x = rv[r];
 #pragma unroll
         for (int q = 0; q < CH; ++q)
-            if (s0 + q < nsd) acc[q] = fma(phi[r * nsd + s0 + q], x, acc[q]);
+            if (s0 + q < nsd) acc[q] = fma(phiT[(int64_t)(s0 + q) * ldp + r], x, acc[q]);
     }
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
@@ -573,9 +583,8 @@ __global__ __launch_bounds__(256) void k_gd_restrict_cells(const int32_t* __rest
 
 // restriction, step 2: r0[(E, k)] = sum over the cells that see E (fixed order) of their class(E) partial sum
 template <int DIM>
-__global__ void k_gd_restrict_ent(CoarseGeom cg, int dofs, int64_t n_ent, const double* __restrict__ part,
+__global__ void k_gd_restrict_ent(CoarseGeom cg, GdAct act, int dofs, int64_t n_ent, const double* __restrict__ part,
                                   double* __restrict__ r0) {
-    constexpr int NCLS = GdswCfg<DIM>::NCLS;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_ent * dofs) return;
     const int32_t E = (int32_t)(t / dofs);
@@ -584,7 +593,7 @@ __global__ void k_gd_restrict_ent(CoarseGeom cg, int dofs, int64_t n_ent, const 
     gd_coarse_coords<DIM>(cg, E, e);
     const int cls = gd_class<DIM>(e);
     double sum = 0.0;
-    if (cls >= 0) {
+    if (cls >= 0 && act.idx[cls] >= 0) {
         // cells h with |2 h_d - e_d| <= 1: e_d even -> h_d = e_d / 2; odd -> (e_d - 1) / 2 and (e_d + 1) / 2
         for (int a = 0; a < (1 << DIM); ++a) {
             int h[3] = {0, 0, 0};
@@ -599,18 +608,17 @@ __global__ void k_gd_restrict_ent(CoarseGeom cg, int dofs, int64_t n_ent, const 
                 }
                 ok = ok && h[d] >= 0 && h[d] < cg.g[d];
             }
-            if (ok) sum += part[(int64_t)cell_of<DIM>(cg, h) * (NCLS * dofs) + cls * dofs + k];
+            if (ok) sum += part[(int64_t)cell_of<DIM>(cg, h) * (act.n * dofs) + act.idx[cls] * dofs + k];
         }
     }
     r0[t] = sum;
 }
 
-// prolongation: z[r] (+)= mask[r] * sum_slots Phi[r][slot] * z0[entity(home(r), class)][k]
+// prolongation: z[r] (+)= mask[r] * sum_slots Phi[slot][r] * z0[entity(home(r), class)][k]
 template <int DIM, bool ADD>
-__global__ void k_gd_prolong(CoarseGeom cg, const int32_t* __restrict__ ent, int dofs, int64_t n_rows,
-                             const double* __restrict__ phi, const double* __restrict__ mask,
+__global__ void k_gd_prolong(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int64_t n_rows, int64_t ldp,
+                             const double* __restrict__ phiT, const double* __restrict__ mask,
                              const double* __restrict__ z0, double* __restrict__ z) {
-    constexpr int NCLS = GdswCfg<DIM>::NCLS;
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     const int32_t node = (int32_t)(r / dofs);
@@ -618,34 +626,44 @@ __global__ void k_gd_prolong(CoarseGeom cg, const int32_t* __restrict__ ent, int
     gd_entity_coords<DIM>(cg, ent[node], e);
 #pragma unroll
     for (int d = 0; d < DIM; ++d) h[d] = e[d] >> 1;
-    const int nsd = NCLS * dofs;
     double sum = 0.0;
-    for (int cls = 0; cls < NCLS; ++cls) {
+    for (int ai = 0; ai < act.n; ++ai) {
         int ee[3] = {0, 0, 0};
-        if (!gd_entity_of<DIM>(cg, h, cls, ee)) continue;
+        if (!gd_entity_of<DIM>(cg, h, act.cls[ai], ee)) continue;
         const int64_t E = gd_coarse_id<DIM>(cg, ee);
         if (E < 0) continue;
-        for (int k = 0; k < dofs; ++k) sum = fma(phi[r * nsd + cls * dofs + k], z0[E * dofs + k], sum);
+        for (int k = 0; k < dofs; ++k) sum = fma(phiT[(int64_t)(ai * dofs + k) * ldp + r], z0[E * dofs + k], sum);
     }
     if (ADD) z[r] += sum * mask[r];
     else z[r] = sum * mask[r];
 }
 
-// z0 = sum of the unit vectors (E, k) over the interface entities E of one colour (e_d = col_d mod 5)
 struct GdCol { int c[3]; };
 
+// v = Phi z0 for z0 = the sum of the unit vectors (E, k) over the interface entities E of one colour (e_d = col_d mod 5):
+// a cell sees three consecutive entity coordinates per direction, so at most one entity of the colour, i.e. a row reads at
+// most ONE entry of Phi (the generic prolongation read all of them, 375 times per setup)
 template <int DIM>
-__global__ void k_gd_colour(CoarseGeom cg, int dofs, int64_t n_ent, int k, GdCol col, double* __restrict__ z0) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_ent * dofs) return;
-    const int32_t E = (int32_t)(t / dofs);
-    const int kk = (int)(t - (int64_t)E * dofs);
-    int e[3];
-    gd_coarse_coords<DIM>(cg, E, e);
-    bool on = kk == k && gd_class<DIM>(e) >= 0;
+__global__ void k_gd_prolong_colour(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int64_t n_rows, int64_t ldp,
+                                    const double* __restrict__ phiT, const double* __restrict__ mask, int k, GdCol col,
+                                    double* __restrict__ v) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int32_t node = (int32_t)(r / dofs);
+    int e[3], h[3] = {0, 0, 0};
+    gd_entity_coords<DIM>(cg, ent[node], e);
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) on = on && (e[d] % 5) == col.c[d];
-    z0[t] = on ? 1.0 : 0.0;
+    for (int d = 0; d < DIM; ++d) h[d] = e[d] >> 1;
+    double val = 0.0;
+    for (int ai = 0; ai < act.n; ++ai) {
+        int ee[3] = {0, 0, 0};
+        if (!gd_entity_of<DIM>(cg, h, act.cls[ai], ee)) continue;
+        bool on = gd_coarse_id<DIM>(cg, ee) >= 0;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) on = on && (ee[d] % 5) == col.c[d];
+        if (on) val = phiT[(int64_t)(ai * dofs + k) * ldp + r];
+    }
+    v[r] = val * mask[r];
 }
 
 // K0[(E, a)][(E', k)] = r0[(E, a)] with E' the entity of the colour within two lattice steps of E
@@ -797,30 +815,57 @@ __global__ void k_prolong_add(CoarseGeom cg, int dofs, int64_t n_rows, const dou
 
 
 // ---- GDSW: setup and application (kernels and definitions: "GDSW coarse space" above) ----
+static GdAct gdsw_active(const CoarseGeom& cg) {
+    GdAct act;
+    const int dim = cg.dim, ncls = dim == 3 ? 26 : 8;
+    act.n = 0;
+    for (int cls = 0; cls < 26; ++cls) act.idx[cls] = -1;
+    for (int cls = 0; cls < ncls; ++cls) {
+        bool on = true;
+        if (cg.reduced) {   // only the classes of coarse nodes carry functions: code 1 or 2 wherever there is more than one cell
+            int code = cls + 1;
+            for (int d = 0; d < dim; ++d) {
+                on = on && (cg.g[d] >= 2 ? code % 3 != 0 : code % 3 == 0);
+                code /= 3;
+            }
+        }
+        if (on) {
+            act.idx[cls] = (int8_t)act.n;
+            act.cls[act.n++] = (int8_t)cls;
+        }
+    }
+    return act;
+}
+
+static int64_t gdsw_ldp(const fedd_ctx* c) { return (c->n_rows + 15) & ~(int64_t)15; }
+
 static int gdsw_restrict(fedd_ctx* c, const double* d_rv, double* d_r0) {
     const int dim = c->dim, dofs = c->dofs;
     const CoarseGeom cg = c->co_geom;
-    const int ncls = dim == 3 ? 26 : 8, nsd = ncls * dofs;
+    const GdAct act = gdsw_active(cg);
+    const int nsa = act.n * dofs;
     const int64_t ncell = c->co_ncell, n_ent = c->co_nlat;
-    hipLaunchKernelGGL(k_gd_restrict_cells, dim3((unsigned)ncell, (unsigned)((nsd + 15) / 16)), dim3(256), 0, c->stream,
-                       (const int32_t*)c->d_co_cell_ptr.p, (const int32_t*)c->d_co_val[c->co_sorted].p, dofs, nsd,
+    if (nsa > 0)   // (RGDSW on a lattice without coarse nodes has no functions: r0 = 0 below)
+        hipLaunchKernelGGL(k_gd_restrict_cells, dim3((unsigned)ncell, (unsigned)((nsa + 7) / 8)), dim3(256), 0, c->stream,
+                       (const int32_t*)c->d_co_cell_ptr.p, (const int32_t*)c->d_co_val[c->co_sorted].p, dofs, nsa, gdsw_ldp(c),
                        (const double*)c->d_gd_phi.p, d_rv, c->d_co_part.p);
     const dim3 ge((unsigned)((n_ent * dofs + 255) / 256)), blk(256);
-    if (dim == 3) hipLaunchKernelGGL(k_gd_restrict_ent<3>, ge, blk, 0, c->stream, cg, dofs, n_ent, (const double*)c->d_co_part.p, d_r0);
-    else hipLaunchKernelGGL(k_gd_restrict_ent<2>, ge, blk, 0, c->stream, cg, dofs, n_ent, (const double*)c->d_co_part.p, d_r0);
+    if (dim == 3) hipLaunchKernelGGL(k_gd_restrict_ent<3>, ge, blk, 0, c->stream, cg, act, dofs, n_ent, (const double*)c->d_co_part.p, d_r0);
+    else hipLaunchKernelGGL(k_gd_restrict_ent<2>, ge, blk, 0, c->stream, cg, act, dofs, n_ent, (const double*)c->d_co_part.p, d_r0);
     return 0;
 }
 
 template <bool ADD>
 static int gdsw_prolong(fedd_ctx* c, const double* d_z0, double* d_z) {
     const CoarseGeom cg = c->co_geom;
+    const GdAct act = gdsw_active(cg);
     const dim3 gr((unsigned)((c->n_rows + 255) / 256)), blk(256);
     if (c->dim == 3)
-        hipLaunchKernelGGL((k_gd_prolong<3, ADD>), gr, blk, 0, c->stream, cg, (const int32_t*)c->d_gd_ent.p, c->dofs, c->n_rows,
-                           (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, d_z0, d_z);
+        hipLaunchKernelGGL((k_gd_prolong<3, ADD>), gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, c->dofs, c->n_rows,
+                           gdsw_ldp(c), (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, d_z0, d_z);
     else
-        hipLaunchKernelGGL((k_gd_prolong<2, ADD>), gr, blk, 0, c->stream, cg, (const int32_t*)c->d_gd_ent.p, c->dofs, c->n_rows,
-                           (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, d_z0, d_z);
+        hipLaunchKernelGGL((k_gd_prolong<2, ADD>), gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, c->dofs, c->n_rows,
+                           gdsw_ldp(c), (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, d_z0, d_z);
     return 0;
 }
 
@@ -881,7 +926,9 @@ static int gdsw_setup(fedd_ctx* c) {
     c->co_nlat = n_ent;     // (the coarse index space: entities of the doubled lattice)
     c->co_n0 = n0;
     c->co_ld = ld;
-    const int ncls = dim == 3 ? 26 : 8, nsd = ncls * dofs;
+    const GdAct act = gdsw_active(cg);
+    const int nsd = act.n * dofs;           // active slots (compact)
+    const int64_t ldp = gdsw_ldp(c);
     const dim3 blk(256), gn((n_own + 255) / 256), gr((unsigned)((n_rows + 255) / 256));
     // ---- entity and home cell of every owned node; nodes grouped by home cell (stable radix split) ----
     for (int q = 0; q < 2; ++q) {
@@ -917,7 +964,7 @@ static int gdsw_setup(fedd_ctx* c) {
     hipLaunchKernelGGL(k_mask, gr, blk, 0, c->stream, (const int32_t*)c->d_isdir.p, n_rows, c->d_co_mask.p, d_bad + 2);
     if (c->n_cols != c->n_rows || !c->halo.peers.empty()) FEDD_TRY(halo_import(c, c->d_co_mask.p, dofs));
     // ---- Phi_Gamma, then the harmonic extensions: one constrained solve per (class, component) ----
-    FEDD_TRY(c->d_gd_phi.ensure((size_t)n_rows * nsd));
+    FEDD_TRY(c->d_gd_phi.ensure((size_t)ldp * std::max(nsd, 1)));
     FEDD_TRY(c->d_gd_imask.ensure((size_t)n_rows));
     const int64_t nc = (std::max<int64_t>(n_rows, c->n_cols) + 15) & ~(int64_t)15;
     FEDD_TRY(c->d_gd_tmp.ensure((size_t)nc + 3 * (size_t)n_rows));
@@ -925,26 +972,17 @@ static int gdsw_setup(fedd_ctx* c) {
     double* w = v + nc;
     double* b = w + n_rows;
     double* x = b + n_rows;
-    if (dim == 3) hipLaunchKernelGGL(k_gd_phi_init<3>, gr, blk, 0, c->stream, cg, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, (const double*)c->d_co_mask.p, c->d_gd_phi.p, c->d_gd_imask.p);
-    else hipLaunchKernelGGL(k_gd_phi_init<2>, gr, blk, 0, c->stream, cg, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, (const double*)c->d_co_mask.p, c->d_gd_phi.p, c->d_gd_imask.p);
-    FEDD_TRY(c->d_co_part.ensure((size_t)ncell * nsd));
+    if (dim == 3) hipLaunchKernelGGL(k_gd_phi_init<3>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_co_mask.p, c->d_gd_phi.p, c->d_gd_imask.p);
+    else hipLaunchKernelGGL(k_gd_phi_init<2>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_co_mask.p, c->d_gd_phi.p, c->d_gd_imask.p);
+    FEDD_TRY(c->d_co_part.ensure((size_t)ncell * std::max(nsd, 1)));
     FEDD_TRY(c->d_co_r0.ensure(std::max<size_t>((size_t)ld, c->d_co_r0.cap)));
     FEDD_TRY(c->d_co_z0.ensure((size_t)ld));
     int its_max = 0;
     double rel_max = 0.0;
     for (int slot = 0; slot < nsd; ++slot) {
-        if (reduced) {   // only the classes of coarse nodes carry functions: code 1 or 2 wherever there is more than one cell
-            int code = slot / dofs + 1;
-            bool vertex_class = true;
-            for (int d = 0; d < dim; ++d) {
-                vertex_class = vertex_class && (cg.g[d] >= 2 ? code % 3 != 0 : code % 3 == 0);
-                code /= 3;
-            }
-            if (!vertex_class) continue;
-        }
         FEDD_HIP(hipMemsetAsync(v, 0, (size_t)nc * sizeof(double), c->stream));
-        hipLaunchKernelGGL(k_gd_gamma_col, gr, blk, 0, c->stream, (const double*)c->d_gd_phi.p, (const double*)c->d_gd_imask.p, n_rows,
-                           nsd, slot, (const double*)c->d_co_mask.p, v);
+        hipLaunchKernelGGL(k_gd_gamma_col, gr, blk, 0, c->stream, (const double*)(c->d_gd_phi.p + (int64_t)slot * ldp),
+                           (const double*)c->d_gd_imask.p, n_rows, (const double*)c->d_co_mask.p, v);
         FEDD_TRY(spmv_owned(c, v, w, true));
         hipLaunchKernelGGL(k_gd_rhs, gr, blk, 0, c->stream, (const double*)c->d_gd_imask.p, (const double*)w, n_rows, b);
         int its = 0;
@@ -960,7 +998,8 @@ static int gdsw_setup(fedd_ctx* c) {
         if (rc) return rc;
         its_max = std::max(its_max, its);
         rel_max = std::max(rel_max, rel);
-        hipLaunchKernelGGL(k_gd_store, gr, blk, 0, c->stream, (const double*)c->d_gd_imask.p, (const double*)x, n_rows, nsd, slot, c->d_gd_phi.p);
+        hipLaunchKernelGGL(k_gd_store, gr, blk, 0, c->stream, (const double*)c->d_gd_imask.p, (const double*)x, n_rows,
+                           c->d_gd_phi.p + (int64_t)slot * ldp);
     }
     c->gdsw_ext_its = its_max;
     c->gdsw_ext_rel = rel_max;
@@ -978,10 +1017,8 @@ static int gdsw_setup(fedd_ctx* c) {
                 for (int k = 0; k < dofs; ++k) {
                     GdCol col;
                     col.c[0] = c0; col.c[1] = c1; col.c[2] = c2;
-                    if (dim == 3) hipLaunchKernelGGL(k_gd_colour<3>, ge, blk, 0, c->stream, cg, dofs, n_ent, k, col, c->d_co_z0.p);
-                    else hipLaunchKernelGGL(k_gd_colour<2>, ge, blk, 0, c->stream, cg, dofs, n_ent, k, col, c->d_co_z0.p);
-                    FEDD_HIP(hipMemsetAsync(v, 0, (size_t)nc * sizeof(double), c->stream));
-                    FEDD_TRY(gdsw_prolong<false>(c, c->d_co_z0.p, v));
+                    if (dim == 3) hipLaunchKernelGGL(k_gd_prolong_colour<3>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, k, col, v);
+                    else hipLaunchKernelGGL(k_gd_prolong_colour<2>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, k, col, v);
                     FEDD_TRY(spmv_owned(c, v, w, true));
                     FEDD_TRY(gdsw_restrict(c, w, c->d_co_r0.p));
                     if (c->nranks > 1) FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, (int)n0));

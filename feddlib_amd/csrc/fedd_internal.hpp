@@ -295,7 +295,7 @@ struct fedd_ctx {
     fedd::DevBuf<int32_t> d_itmp0, d_itmp1, d_itmp2;
     fedd::DevBuf<int64_t> d_scan[3];            // block sums of the device scan, one per level
     fedd::DevBuf<double> d_dtmp0;
-    fedd::DevBuf<int32_t> d_flags;              // [16] device flags: 0 max scratch, 1 bad pivot, 2 DGKS gate
+    fedd::DevBuf<int32_t> d_flags;              // [16] device flags: 0 max scratch, 1 bad pivot, 2 DGKS gate, 3-5 coarse setup, 8-11 Schwarz setup counters, 12 s-step block length
 
     fedd::HaloPlan halo;
 

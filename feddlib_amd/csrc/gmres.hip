@@ -1379,7 +1379,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     double* axt = c->d_w.p + nc;  // A xt
     double* z = c->d_Z.p;         // M^-1 v
     double* r = c->d_Z.p + nc;    // residual / V y
-    int32_t* d_sa = c->d_flags.p + 4;
+    int32_t* d_sa = c->d_flags.p + 12;   // (0 max scratch, 1 bad pivot, 2 DGKS gate, 3-5 coarse setup, 8-11 Schwarz setup)
     const dim3 gn((unsigned)((n + 255) / 256)), blk(256);
     hipStream_t st = c->stream;
     const double chol_tol = c->gmres_chol_tol;
@@ -1389,9 +1389,19 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
         hipLaunchKernelGGL(k_reduce_cols, dim3(1), blk, 0, st, (const double*)c->d_part.p, out, nblk, (const int32_t*)nullptr);
         return allreduce_sum(c, out, 1);
     };
+    // c->gm_mask != nullptr: the constrained system of the GDSW extension solves, A^ = D A D + (I - D), M^^-1 = D M^-1 D + (I - D)
+    // (see gmres_solve_dcgs2); monomial blocks only (the shift would have to reach the held rows too)
+    const double* mk = c->gm_mask;
     // out = A M^-1 in - theta in  (basis columns: no ghost tail; the shift rides in the SpMV kernel's store)
     auto apply_B = [&](const double* in, double* out, double theta) -> int {
         if (use_prec) FEDD_TRY(schwarz_apply(c, in, z, false));
+        if (mk) {
+            if (use_prec) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)z, in, z, n);
+            else FEDD_HIP(hipMemcpyAsync(z, in, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            FEDD_TRY(spmv_owned(c, z, out, true));
+            hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)out, (const double*)z, out, n);
+            return 0;
+        }
         return spmv_owned(c, use_prec ? z : in, out, use_prec, theta != 0.0 ? in : nullptr, theta);
     };
 
@@ -1428,6 +1438,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
             hipLaunchKernelGGL(k_combine, gn, blk, 0, st, (const double*)V, ldv, n, cols, (const double*)(Sx + o.y), r);
             if (use_prec) {
                 FEDD_TRY(schwarz_apply(c, r, z, true));
+                if (mk) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)z, (const double*)r, z, n);
                 hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)z, xt, n);
             } else {
                 hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)r, xt, n);
@@ -1436,6 +1447,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
             FEDD_HIP(hipMemcpyAsync(xt, d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
         FEDD_TRY(spmv_owned(c, xt, axt, true));
+        if (mk) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)axt, (const double*)xt, axt, n);
         hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, d_b, -1.0, (const double*)axt, r, n);
         FEDD_TRY(norm2_into(r, Sx + o.nrm + 3));
         FEDD_HIP(hipMemcpyAsync(c->h_pinned, Sx + o.nrm + 3, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1457,7 +1469,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     // two vectors, 1e7 at s = 8): the Newton basis w_i = (B - theta_i) w_{i-1} with the Ritz values of the first s_goal
     // Arnoldi steps as shifts, Leja-ordered (Bai, Hu, Reichel, "A Newton basis GMRES implementation", 1994).  Until those
     // steps exist the blocks are monomial and at most 8 long.
-    const bool newton = c->gmres_newton && s_goal > 1;
+    const bool newton = c->gmres_newton && s_goal > 8 && !mk;
     bool have_shifts = false;
     std::vector<double> theta((size_t)S, 0.0);
     int s_cur = std::min(s_goal, 8);
@@ -1647,12 +1659,12 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
 
 int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart, int use_prec,
                 int* its_out, double* relres_out) {
-    if (c->gmres_kind == 2 && !c->gm_mask) {
+    if (c->gmres_kind == 2) {
         if (c->gmres_s <= 4) return gmres_solve_sstep<4>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
         if (c->gmres_s <= 8) return gmres_solve_sstep<8>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
         return gmres_solve_sstep<16>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
     }
-    if (c->gmres_kind == 0 || c->gmres_kind == 2 || c->gm_mask) return gmres_solve_dcgs2(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
+    if (c->gmres_kind == 0 || c->gmres_kind == 2) return gmres_solve_dcgs2(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
     const int64_t n = c->n_rows;
     const int m = std::min(restart, max_it);
     const int64_t ldv = (n + 15) & ~(int64_t)15;  // 128-byte aligned basis columns
