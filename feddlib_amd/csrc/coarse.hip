@@ -323,8 +323,8 @@ __global__ __launch_bounds__(256) void k_fix_diag(double* __restrict__ K, int64_
 //     (class, component) extends all entities of the class at once.  The solves run on the device with the
 //     library's own GMRES + one-level Schwarz on the constrained operator (gmres.hip, gm_mask) to `gdsw_tol`
 //     (default 1e-6): an iterative interior solver in place of FROSch's direct ExtensionSolver;
-//   * K0 = Phi^T K Phi, column by colour: entities whose coordinates agree modulo 5 in every direction have supports
-//     that no row couples, so one prolongation - SpMV - restriction gives one column of K0 for all of them;
+//   * K0 = Phi^T K Phi, column by colour: entities whose coordinates agree modulo 5 (RGDSW: coarse nodes, modulo 6) in every
+//     direction have supports that no row couples, so one prolongation - SpMV - restriction gives one column of K0 for all of them;
 //     K0 is inverted by the matrix-core sweep of dense.hip and replicated, exactly like the Q1 level.
 // Storage: Phi[row][slot], slot = class * dofs + k, 3^dim - 1 classes: for the rows of cell h the entry belongs to the
 // entity of that class that h sees; an interface row keeps its single 1 in the class of its own entity (home cell
@@ -640,6 +640,13 @@ __global__ void k_gd_prolong(CoarseGeom cg, GdAct act, const int32_t* __restrict
 
 struct GdCol { int c[3]; };
 
+// Colouring of the coarse dofs for the column-wise Galerkin product: entities whose coordinates agree modulo the period
+// in every direction have supports that no matrix row couples, and every entity couples with at most one of them.
+// GDSW: entities couple within two steps of the doubled lattice -> period 5.  RGDSW: only the coarse nodes (odd
+// coordinates) carry functions and couple with their lattice neighbours (two steps away), so same-coloured ones must be
+// three coarse nodes apart: period 6, and only the odd residues occur: 3^dim colours instead of 5^dim.
+__host__ __device__ __forceinline__ int gd_period(const CoarseGeom& cg) { return cg.reduced ? 6 : 5; }
+
 // v = Phi z0 for z0 = the sum of the unit vectors (E, k) over the interface entities E of one colour (e_d = col_d mod 5):
 // a cell sees three consecutive entity coordinates per direction, so at most one entity of the colour, i.e. a row reads at
 // most ONE entry of Phi (the generic prolongation read all of them, 375 times per setup)
@@ -660,7 +667,7 @@ __global__ void k_gd_prolong_colour(CoarseGeom cg, GdAct act, const int32_t* __r
         if (!gd_entity_of<DIM>(cg, h, act.cls[ai], ee)) continue;
         bool on = gd_coarse_id<DIM>(cg, ee) >= 0;
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) on = on && (ee[d] % 5) == col.c[d];
+        for (int d = 0; d < DIM; ++d) on = on && (ee[d] % gd_period(cg)) == col.c[d];
         if (on) val = phiT[(int64_t)(ai * dofs + k) * ldp + r];
     }
     v[r] = val * mask[r];
@@ -679,8 +686,9 @@ __global__ void k_gd_scatter_col(CoarseGeom cg, int dofs, int64_t n_ent, int k, 
     bool ok = true;
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
-        int dlt = (col.c[d] - e[d] % 5 + 5) % 5;   // 0 .. 4
-        if (dlt > 2) dlt -= 5;                     // -2 .. 2
+        const int P = gd_period(cg);
+        int dlt = (col.c[d] - e[d] % P + P) % P;   // 0 .. P - 1
+        if (dlt > P / 2) dlt -= P;                 // GDSW -2 .. 2; RGDSW (odd coordinates, odd colours) -2, 0, 2
         ep[d] = e[d] + dlt;
         ok = ok && ep[d] >= 0 && ep[d] <= 2 * cg.g[d] - 2;
     }
@@ -1010,11 +1018,14 @@ static int gdsw_setup(fedd_ctx* c) {
     FEDD_HIP(hipMemsetAsync(c->d_co_K.p, 0, (size_t)ld * ld * sizeof(double), c->stream));
     const dim3 ge((unsigned)((n0 + 255) / 256));
     int ncol[3] = {1, 1, 1};
-    for (int d = 0; d < dim; ++d) ncol[d] = std::min(5, 2 * cg.g[d] - 1);   // (RGDSW: colours without a coarse node give zero columns)
+    for (int d = 0; d < dim; ++d) ncol[d] = std::min(gd_period(cg), 2 * cg.g[d] - 1);
+    // RGDSW: coarse nodes have odd coordinates in every direction with >= 2 cells (and 0 in the others): only those residues
+    auto colour_used = [&](int d, int cc) { return !reduced || (cg.g[d] >= 2 ? (cc & 1) == 1 : cc == 0); };
     for (int c2 = 0; c2 < ncol[2]; ++c2)
         for (int c1 = 0; c1 < ncol[1]; ++c1)
             for (int c0 = 0; c0 < ncol[0]; ++c0)
                 for (int k = 0; k < dofs; ++k) {
+                    if (!(colour_used(0, c0) && (dim < 2 || colour_used(1, c1)) && (dim < 3 || colour_used(2, c2)))) continue;
                     GdCol col;
                     col.c[0] = c0; col.c[1] = c1; col.c[2] = c2;
                     if (dim == 3) hipLaunchKernelGGL(k_gd_prolong_colour<3>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, k, col, v);
