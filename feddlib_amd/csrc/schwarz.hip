@@ -974,6 +974,10 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
     int32_t cur = -1;
     bool direct = false;        // (the first batch of a workgroup reads its lists: soff is not loaded yet)
     double a[RT][KW];
+    // B fragments and output rows of a direct batch are gathered one batch ahead (while the current one is multiplied,
+    // exchanged and stored): the kernel is bound by the latency of these gathers, not by the matrix cores
+    double bv[KW];
+    int32_t od_p[RT];
     for (;;) {
         const int32_t rp = __builtin_amdgcn_readlane(hdr.y, pos);
         const int32_t packed = __builtin_amdgcn_readlane(hdr.z, pos);
@@ -1000,20 +1004,10 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
             soff_rep = rp;
         }
         // B fragments: entries of r at the dof ids of subdomain lj
-        double bv[KW];
         int32_t od[RT];     // the rows this lane writes at the end: result register w of tile t = row 16 t + lk + 4 w of subdomain lj
-        if (direct) {       // (uniform over the workgroup)
-            const int32_t a0 = __shfl(hdr.w, pos + lj, 64);
+        if (direct) {       // (uniform over the workgroup) bv was requested during the previous batch
 #pragma unroll
-            for (int kk = 0; kk < KW; ++kk) {
-                const int c = 4 * (w + 4 * kk) + lk;
-                bv[kk] = (lj < mb && c < n) ? r[a0 + soff[c]] : 0.0;
-            }
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                const int i = 16 * t + lk + 4 * w;
-                od[t] = (lj < mb && i < nrow) ? a0 + soff[i] : -1;
-            }
+            for (int t = 0; t < RT; ++t) od[t] = od_p[t];
         } else {
 #pragma unroll
             for (int kk = 0; kk < KW; ++kk) {
@@ -1058,6 +1052,23 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
 #pragma unroll
                 for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][kk], bv[kk], acc[t], 0, 0, 0);
             }
+        // (uniform) the next batch's entries of r and its output rows (first dof + offset): the fragments of this batch are
+        // spent, the gathers fly while the partial tiles are exchanged, added and stored
+        if (direct_n) {
+            const int32_t a0n = cross ? __shfl(hdr_n.w, pos_n + lj, 64) : __shfl(hdr.w, pos_n + lj, 64);
+            const int32_t pk = cross ? __builtin_amdgcn_readlane(hdr_n.z, pos_n) : __builtin_amdgcn_readlane(hdr.z, pos_n);
+            const int n_n = pk & 1023, nrow_n = (pk >> 10) & 1023;
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk) {
+                const int c = 4 * (w + 4 * kk) + lk;
+                bv[kk] = (lj < mb_n && c < n_n) ? r[a0n + soff[c]] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const int i = 16 * t + lk + 4 * w;
+                od_p[t] = (lj < mb_n && i < nrow_n) ? a0n + soff[i] : -1;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
