@@ -179,6 +179,12 @@ def cpu_baseline(a, full_cells, gpu_its, full=False, nthr=0):
                                 "gmres_iterations": r["its"]}}
 
 
+def env_options(c):
+    """development: FEDD_OPTIONS=key=value,... sets library options on every context of the run"""
+    for kv in filter(None, os.environ.get("FEDD_OPTIONS", "").split(",")):
+        c.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+
+
 def timed_passes(c, step, steps, warmup, stride=1):
     """`warmup` untimed and `steps` timed passes of step() on one context; wall ms per pass, the last pass' return value and the
     device-time table"""
@@ -210,6 +216,7 @@ def extra_per_gpu_share(capi, dev, a, its_headline):
     host round trips) -- which bounds the 8-GPU step from below."""
     m = capi.structured_mesh(3, (1, 1, 1), [107] * 3, 0)
     c = capi.Context(device=dev)
+    env_options(c)
     c.mesh_set_dict(m)
 
     def step():
@@ -243,6 +250,7 @@ def extra_cfg5_share(capi, dev, a):
     M = 94
     m = capi.structured_mesh(3, (1, 1, 1), [M] * 3, 0)
     c = capi.Context(device=dev)
+    env_options(c)
     c.mesh_set_dict(m)
     mu, nu = 2.0e6, 0.4
     lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
@@ -298,6 +306,7 @@ def extra_cfg4(capi, dev):
     n_p, nv = m1["xyz"].shape[0], mv["xyz"].shape[0]
     n = 3 * nv + n_p
     c = capi.Context(device=dev)
+    env_options(c)
     c.mesh_set_dict(mv)
     X, flag, H = mv["xyz"], mv["flag_uni"], 0.41
     nodes = np.nonzero(np.isin(flag, (1, 2, 4)))[0]

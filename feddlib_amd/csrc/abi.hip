@@ -731,8 +731,11 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
         FEDD_CHECK(value == 0 || value == 1 || value == 2, "fedd_set_option: gmres_kind %g", value);
         c->gmres_kind = (int)value;
     } else if (k == "gmres_s") {
-        FEDD_CHECK(value >= 1 && value <= 16, "fedd_set_option: gmres_s %g (1 ... 16)", value);
+        FEDD_CHECK(value >= 0 && value <= 16, "fedd_set_option: gmres_s %g (0 = automatic, 1 ... 16)", value);
         c->gmres_s = (int)value;
+    } else if (k == "gmres_spec") {
+        FEDD_CHECK(value >= 0 && value <= 16, "fedd_set_option: gmres_spec %g", value);
+        c->gmres_spec = (int)value;
     } else if (k == "gmres_newton") {
         c->gmres_newton = (int)value;
     } else if (k == "gmres_chol_tol") {
@@ -792,7 +795,7 @@ extern "C" int fedd_timing_get_sampled(fedd_ctx* c, int timer, double* sampled_m
 extern "C" int fedd_gmres_info(fedd_ctx* c, int* kind, int* s, int* blocks, int* cut_blocks) {
     FEDD_CHECK(c, "fedd_gmres_info: null context");
     if (kind) *kind = c->gmres_kind;
-    if (s) *s = c->gmres_s;
+    if (s) *s = c->gmres_s > 0 ? c->gmres_s : c->gmres_s_used;
     if (blocks) *blocks = c->gmres_blocks;
     if (cut_blocks) *cut_blocks = c->gmres_cut_blocks;
     return 0;

@@ -1427,7 +1427,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     } ev_guard{ev};
     // column groups in flight per row block of the dot kernel: one when the vectors are long (every workgroup then
     // reads its rows of W once), more to fill the GPU when they are short
-    const int gy_dot = (int)std::max<int64_t>(1, std::min<int64_t>(8, (1024 + nblkd - 1) / nblkd));
+    const int gy_dot = (int)std::max<int64_t>(1, std::min<int64_t>(8, (2048 + nblkd - 1) / nblkd));
     double* hout = c->h_pinned + 16;                                  // host mirror of the block result
     double* hout_dev = c->h_pinned_dev ? c->h_pinned_dev + 16 : nullptr;
 
@@ -1487,11 +1487,15 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
         hipLaunchKernelGGL(k_scale_to, gn, blk, 0, st, (const double*)r, (const double*)(Sx + o.misc + 1), V, n);
         int k = 1;                 // final basis vectors; k - 1 Hessenberg columns are final
         bool restart_now = false;
+        int spec_done = 0, spec_k = -1;   // operator applications of the block starting at spec_k that are already in the stream
         while (!done && !restart_now) {
             const int room = std::min(m - (k - 1), max_it - its - (k - 1));
             if (room <= 0) break;
             const int sa = std::min(s_cur, room);
-            for (int i = 0; i < sa; ++i)
+            const int i0 = spec_k == k ? std::min(spec_done, sa) : 0;
+            spec_done = 0;
+            spec_k = -1;
+            for (int i = i0; i < sa; ++i)
                 FEDD_TRY(apply_B(V + (int64_t)(k - 1 + i) * ldv, V + (int64_t)(k + i) * ldv, have_shifts ? theta[(size_t)i] : 0.0));
             {
                 ScopedTimer t(c, FEDD_T_ORTHO);
@@ -1537,6 +1541,20 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
                                        (const double*)(Sx + o3.cf2), (const double*)(Sx + o3.ri2));
                 }
                 t.stop();
+            }
+            // The head of the next block goes into the stream before the host waits for this block's outcome: the GPU works
+            // through the round trip.  It assumes the ordinary outcome (no cut, no convergence, same shifts); otherwise the
+            // two applications wrote columns nobody reads.
+            if (c->gmres_spec > 0 && !(newton && !have_shifts)) {
+                const int k_next = k + sa;
+                const int room_next = std::min(m - (k_next - 1), max_it - its - (k_next - 1));
+                const int ns = std::min(std::min(c->gmres_spec, s_cur), room_next);
+                for (int i = 0; i < ns; ++i)
+                    FEDD_TRY(apply_B(V + (int64_t)(k_next - 1 + i) * ldv, V + (int64_t)(k_next + i) * ldv, have_shifts ? theta[(size_t)i] : 0.0));
+                if (ns > 0) {
+                    spec_done = ns;
+                    spec_k = k_next;
+                }
             }
             FEDD_HIP(hipEventSynchronize(ev));
             const int sa_eff = (int)hout[0];
@@ -1660,6 +1678,27 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
 int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart, int use_prec,
                 int* its_out, double* relres_out) {
     if (c->gmres_kind == 2) {
+        // block length: "gmres_s" 0 = by the vector length per rank -- 16-vector (Newton-basis) blocks where the sweeps over the
+        // basis dominate, 8-vector blocks on short vectors, where the longer blocks' fixed costs (two monomial blocks first,
+        // a 16 x 16 Cholesky per pass, a register-heavier dot kernel) are not paid back.  Every rank must take the same one:
+        // the decision uses the global row count
+        if (c->gmres_s == 0) {
+            double ng = (double)c->n_rows;
+            if (c->nranks > 1) {
+                FEDD_TRY(c->d_small.ensure(std::max<size_t>(16, c->d_small.cap)));
+                FEDD_HIP(hipMemcpyAsync(c->d_small.p, &ng, sizeof(double), hipMemcpyHostToDevice, c->stream));
+                FEDD_HIP(hipStreamSynchronize(c->stream));
+                FEDD_TRY(allreduce_sum(c, c->d_small.p, 1));
+                FEDD_HIP(hipMemcpyAsync(&ng, c->d_small.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                FEDD_HIP(hipStreamSynchronize(c->stream));
+            }
+            c->gmres_s = ng / c->nranks >= 4.0e6 ? 16 : 8;
+            const int rc = gmres_solve(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
+            c->gmres_s_used = c->gmres_s;
+            c->gmres_s = 0;
+            return rc;
+        }
+        c->gmres_s_used = c->gmres_s;
         if (c->gmres_s <= 4) return gmres_solve_sstep<4>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
         if (c->gmres_s <= 8) return gmres_solve_sstep<8>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
         return gmres_solve_sstep<16>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);

@@ -326,14 +326,16 @@ int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_bloc
  * matrix, 0 = off; "spmv_pat_nu" / "spmv_win_nu" window sizes of the pattern / per-entry SpMV kernels (0 = default); "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
  * matrix cores, 2 = scalar-pivot without dropping rows;
  * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes, 2 = s-step GMRES: the
- * basis grows "gmres_s" (1 ... 16) vectors at a time -- blocks longer than 8 on the Newton block basis ("gmres_newton" 1, the
+ * basis grows "gmres_s" (1 ... 16; 0, the default: 16 from 4 million rows per rank, else 8) vectors at a time -- blocks longer than 8 on the Newton block basis ("gmres_newton" 1, the
  * default: shifts = Leja-ordered Ritz values of the first gmres_s Arnoldi steps, which run in monomial blocks of at most 8; 0 =
  * monomial basis, blocks of at most 8) -- and each block is orthogonalised by block Gram-Schmidt with two
  * passes (four sweeps over the basis and two reductions per block instead of two sweeps and one reduction per iteration; same
  * iterates as 0 / 1 in exact arithmetic; a block is cut where the squared sine of a new vector against its predecessors falls
  * to "gmres_chol_tol", default 1e-13; the convergence claim is checked against the true residual and the residual returned is
  * the true one; tolerances below 1e-9 / 1e-11 take blocks of at most 5 / 3 vectors, because the recurrence of a longer block
- * loses touch with the true residual there), see fedd_gmres_info;
+ * loses touch with the true residual there; "gmres_spec" n > 0: n operator applications of the next block are put into the
+ * stream before the host reads a block's outcome, so that the GPU works through that round trip -- default 0: on one GPU the
+ * round trip is not what the step waits for (tools/share_n8.py), an A/B switch for multi-GPU runs), see fedd_gmres_info;
  * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank;
  * "asm_lds_kb" (default 37) = LDS budget in KB of the assembly kernel's contribution park, i.e. rows per workgroup;
  * "spmv_nt" 1 = the window SpMV streams the matrix non-temporally (x then survives in L2 between node planes:

@@ -16,7 +16,7 @@ def ctx(fedd_lib):
     c = fedd_lib.Context(device=0)
     yield c
     c.set_option("gmres_kind", 2)
-    c.set_option("gmres_s", 16)
+    c.set_option("gmres_s", 0)
     c.close()
 
 
