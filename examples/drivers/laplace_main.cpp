@@ -136,7 +136,7 @@ static int run(int argc, char* argv[]) {
         auto data = exportSolution->getData(0);
         for (size_t i = 0; i < data.size(); ++i) out << map->getGlobalElement((LO)i) << " " << data[i] << "\n";
 
-        bool boolExportSolution = comm->getSize() == 1;     // (the facade's exporter writes one rank's piece)
+        bool boolExportSolution = true;     // (laplace/main.cpp:210-225; every rank writes its part of the global arrays)
         if (boolExportSolution) {
             Teuchos::RCP<ExporterParaView<SC, LO, GO, NO> > exPara(new ExporterParaView<SC, LO, GO, NO>());
             exPara->setup("solutionLaplace", domain->getMesh(), FEType);

@@ -127,7 +127,7 @@ static int run(int argc, char* argv[]) {
         auto data = exportSolution->getData(0);
         for (size_t i = 0; i < data.size(); ++i) out << map->getGlobalElement((LO)i) << " " << data[i] << "\n";
 
-        if (comm->getSize() == 1 && parameterListAll->sublist("General").get("ParaViewExport", false)) {       // main.cpp:228-240
+        if (parameterListAll->sublist("General").get("ParaViewExport", false)) {       // main.cpp:228-240 (every rank writes its part)
             Teuchos::RCP<ExporterParaView<SC, LO, GO, NO> > exPara(new ExporterParaView<SC, LO, GO, NO>());
             exPara->setup("displacements", domain->getMesh(), discType);
             exPara->addVariable(exportSolution, "values", "Vector", dim, domain->getMapUnique());

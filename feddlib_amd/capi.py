@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfedd_hip.so")
 
-FORM_LAPLACE, FORM_LAPLACE_VEC, FORM_MASS, FORM_MASS_VEC, FORM_LINELAS = range(5)
+FORM_LAPLACE, FORM_LAPLACE_VEC, FORM_MASS, FORM_MASS_VEC, FORM_LINELAS, FORM_BDSTAB = range(6)
 BLOCK_SCALAR, BLOCK_DIAG, BLOCK_FULL = range(3)
 COMBINE_RESTRICTED, COMBINE_AVERAGING, COMBINE_FULL = range(3)
 (T_SYMBOLIC, T_ASSEMBLE, T_RHS, T_DIRICHLET, T_SPMV, T_SCHWARZ_SETUP, T_SCHWARZ_APPLY, T_ORTHO, T_COARSE_SETUP,

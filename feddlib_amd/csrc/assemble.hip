@@ -158,6 +158,7 @@ __global__ void k_assemble(AsmArgs a) {
                 double v = 0.0;
                 for (int q = 0; q < nq; ++q) v += s_w[q] * s_phi[q * NEN + li] * s_phi[q * NEN + j];
                 v *= absdet;
+                v -= a.p0 * absdet * a.p1;   // assemblyBDStabilization (FE_def.hpp:2151-2220): p0 = |reference element|, p1 = its scale; mass: 0
                 const int slot = find_slot(cols, rn, nd[j] * dofs + comp);
                 acc[slot * BS + tid] += v;
             }
@@ -248,7 +249,9 @@ __device__ __forceinline__ void compute_pair(const AsmArgs& a, const double* __r
             double v = 0.0;
             for (int q = 0; q < nq; ++q) v += s_w[q] * s_phi[q * NEN + li] * s_phi[q * NEN + j];
             cols[j] = nd[j] * dofs + comp;
-            vals[j] = v * absdet;
+            // assemblyBDStabilization (FE_def.hpp:2204-2206): value *= absDetB; value -= refElementSize * absDetB * refElementScale
+            // (p0 = p1 = 0 for the plain mass matrix: x - 0 = x)
+            vals[j] = v * absdet - a.p0 * absdet * a.p1;
         }
     } else {
         // Quadrature loop outermost, the transformed gradient of the row's basis function once per point and that
@@ -1010,6 +1013,10 @@ int assemble_matrix(fedd_ctx* c, int form, const double* params) {
         case FEDD_FORM_MASS_VEC:
             FEDD_CHECK(c->dofs == dim && c->block_mode == FEDD_BLOCK_DIAG, "assemblyMass(Vector) needs a DIAG pattern with dim dofs per node");
             kform = F_MASS; degree = ds + ds; break;
+        case FEDD_FORM_BDSTAB:
+            FEDD_CHECK(c->dofs == 1, "assemblyBDStabilization needs a scalar pattern");
+            FEDD_CHECK(nen == dim + 1, "assemblyBDStabilization: only implemented for P1 (FE_def.hpp:2156)");
+            kform = F_MASS; degree = ds + ds; break;
         case FEDD_FORM_LINELAS:
             FEDD_CHECK(c->dofs == dim && c->block_mode == FEDD_BLOCK_FULL, "assemblyLinElasXDim needs a FULL pattern with dim dofs per node");
             FEDD_CHECK(params, "assemblyLinElasXDim needs params = {lambda, mu}");
@@ -1026,6 +1033,10 @@ int assemble_matrix(fedd_ctx* c, int form, const double* params) {
     a.nq = nq; a.n_rows = (int32_t)c->n_rows_ext; a.dofs = c->dofs;
     a.p0 = params ? params[0] : 0.0;
     a.p1 = params ? params[1] : 0.0;
+    if (kform == F_MASS) {   // the constant the Bochev-Dohrmann block takes off every mass entry: |ref. element| x scale (FE_def.hpp:2183-2192)
+        a.p0 = form == FEDD_FORM_BDSTAB ? (dim == 2 ? 0.5 : 1.0 / 6.0) : 0.0;
+        a.p1 = form == FEDD_FORM_BDSTAB ? (dim == 2 ? 1.0 / 9.0 : 1.0 / 16.0) : 0.0;
+    }
     c->have_schwarz = false;
     if (dim == 2 && nen == 3) return launch_assemble<2, 3>(c, kform, a, ntab);
     if (dim == 2 && nen == 6) return launch_assemble<2, 6>(c, kform, a, ntab);

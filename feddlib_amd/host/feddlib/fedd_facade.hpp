@@ -25,6 +25,7 @@
 #include <functional>
 #include <iostream>
 #include <fstream>
+#include <cstring>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -623,6 +624,11 @@ public:
         if (fieldType == "Scalar") assembleInto(checkFE(dim, FEType), 1, FEDD_BLOCK_SCALAR, FEDD_FORM_MASS, nullptr, A, callFillComplete);
         else if (fieldType == "Vector") assembleInto(checkFE(dim, FEType), dim, FEDD_BLOCK_DIAG, FEDD_FORM_MASS_VEC, nullptr, A, callFillComplete);
         else TEUCHOS_TEST_FOR_EXCEPTION(true, std::logic_error, "Specify valid vieldType for assembly of mass matrix.");
+    }
+    // FE::assemblyBDStabilization (FE_def.hpp:2151-2220): the Bochev-Dohrmann pressure block of P1/P1 Stokes
+    void assemblyBDStabilization(int dim, std::string FEType, MatrixPtr_Type& A, bool callFillComplete = true) {
+        TEUCHOS_TEST_FOR_EXCEPTION(FEType != "P1", std::logic_error, "Only implemented for P1. Q1 is equivalent but we need to adjust scaling for the reference element.");
+        assembleInto(checkFE(dim, FEType), 1, FEDD_BLOCK_SCALAR, FEDD_FORM_BDSTAB, nullptr, A, callFillComplete);
     }
     void assemblyLinElasXDim(int dim, std::string FEType, MatrixPtr_Type& A, double lambda, double mu, bool callFillComplete = true) {
         TEUCHOS_TEST_FOR_EXCEPTION(FEType == "P0", std::logic_error, "Not implemented for P0");
@@ -1287,9 +1293,21 @@ public:
         this->system_->addBlock(A, 0, 0);
         this->system_->addBlock(BT, 0, 1);
         this->system_->addBlock(B, 1, 0);
-        TEUCHOS_TEST_FOR_EXCEPTION(this->getFEType(0) == "P1", std::logic_error, "Stokes: the P1/P1 Bochev-Dohrmann block is not built");
-        // BlockMatrix::merge: system <- [A B^T; B 0] on the device
-        feddCheck(fedd_block_merge(dev->ctx, 0, 2, 1, -1), "fedd_block_merge");
+        int slotC = -1;
+        if (this->getFEType(0) == "P1") {       // Stokes_def.hpp:98-105: P1/P1 needs the stabilisation block C = -1/nu * BD
+            if (this->verbose_) std::cout << "C ... " << std::flush;
+            MatrixPtr_Type C(new Matrix_Type(pressureMap, this->getDomain(1)->getApproxEntriesPerRow()));
+            this->feFactory_->assemblyBDStabilization(this->dim_, "P1", C, true);
+            C->resumeFill();
+            feddCheck(fedd_matrix_scale(dev->ctx, -1, -1. / viscosity), "fedd_matrix_scale");   // C->scale(-1./viscosity)
+            feddCheck(fedd_matrix_store(dev->ctx, 3), "fedd_matrix_store");
+            C->bindSlot(dev, 3);
+            C->fillComplete(pressureMap, pressureMap);
+            this->system_->addBlock(C, 1, 1);
+            slotC = 3;
+        }
+        // BlockMatrix::merge: system <- [A B^T; B C] on the device (C empty for P2/P1)
+        feddCheck(fedd_block_merge(dev->ctx, 0, 2, 1, slotC), "fedd_block_merge");
         dev->generation++;
         this->system_->setMerged(dev);
         if (this->verbose_) std::cout << "done -- " << std::endl;
@@ -1339,32 +1357,55 @@ public:
     void setup(std::string filename, MeshPtr_Type mesh, std::string FEType, ParameterListPtr_Type parameterList = Teuchos::null) {
         setup(filename, mesh, FEType, 1, parameterList);
     }
+    // The exported arrays are GLOBAL arrays in files of their own, as in the reference's HDF5 file (ExporterParaView_def.hpp:
+    // 484-601: every rank writes its hyperslab): points and nodal values in global-id order, the connectivity in global ids.
+    // Rank 0 creates each file at its final size, then every rank writes its entries in place -- its unique nodes at
+    // position gid, the elements it exports (those whose vertex of smallest global id it owns: exactly one rank per element,
+    // and that rank holds the element among its own or ghost elements) behind those of the lower ranks.  The files do not
+    // depend on the number of ranks.
     void setup(std::string filename, MeshPtr_Type mesh, std::string FEType, int saveTimestep, ParameterListPtr_Type = Teuchos::null) {
         TEUCHOS_TEST_FOR_EXCEPTION(mesh.is_null(), std::runtime_error, "ExporterParaView::setup: null mesh");
-        TEUCHOS_TEST_FOR_EXCEPTION(mesh->getComm()->getSize() > 1, std::logic_error, "ExporterParaView: one rank only in this build");
         filename_ = filename; mesh_ = mesh; FEType_ = FEType; saveTimestep_ = std::max(1, saveTimestep);
+        comm_ = mesh->getComm();
+        const int size = comm_->getSize(), rank = comm_->getRank();
         const int dim = (int)mesh->getDimension(), nen = mesh->nodesPerElement(), nv = dim + 1;
         const auto& conn = mesh->connectivity();
         const size_t ne = conn.size() / nen;
-        // connectivity in unique-local ids (values live on the unique map), vertices only
-        std::vector<int32_t> uniOfRepInv(mesh->getMapRepeated()->getNodeNumElements(), -1);
-        const auto& uor = mesh->uniqueLocalOfRepeated();
-        for (size_t u = 0; u < uor.size(); ++u) uniOfRepInv[uor[u]] = (int32_t)u;
-        std::vector<int32_t> c(ne * nv);
-        for (size_t e = 0; e < ne; ++e)
-            for (int j = 0; j < nv; ++j) {
-                const int32_t u = uniOfRepInv.at(conn[e * nen + j]);
-                TEUCHOS_TEST_FOR_EXCEPTION(u < 0, std::logic_error, "ExporterParaView: a repeated node is not owned (several ranks)");
-                c[e * nv + j] = u;
-            }
-        writeBin(filename_ + ".conn.bin", c.data(), c.size() * sizeof(int32_t));
+        auto mapRep = mesh->getMapRepeated();
+        auto mapUni = mesh->getMapUnique();
+        nPoints_ = (size_t)mapUni->getGlobalNumElements();
+        TEUCHOS_TEST_FOR_EXCEPTION(size > 1 && (GO)nPoints_ <= mapUni->getMaxAllGlobalIndex(), std::logic_error,
+                                   "ExporterParaView: node ids are not 0 .. N-1");
+        std::vector<char> owned(mapRep->getNodeNumElements(), 0);
+        for (int32_t rl : mesh->uniqueLocalOfRepeated()) owned[rl] = 1;
+        // connectivity in global ids of the elements this rank exports, vertices only
+        std::vector<int32_t> c;
+        c.reserve(ne * nv);
+        for (size_t e = 0; e < ne; ++e) {
+            int jmin = 0;
+            for (int j = 1; j < nv; ++j)
+                if (mapRep->getGlobalElement(conn[e * nen + j]) < mapRep->getGlobalElement(conn[e * nen + jmin])) jmin = j;
+            if (!owned[conn[e * nen + jmin]]) continue;
+            for (int j = 0; j < nv; ++j) c.push_back((int32_t)mapRep->getGlobalElement(conn[e * nen + j]));
+        }
+        std::vector<int64_t> counts = gatherCounts((int64_t)(c.size() / nv));
+        int64_t before = 0, total = 0;
+        for (int r = 0; r < size; ++r) {
+            if (r < rank) before += counts[r];
+            total += counts[r];
+        }
+        nElements_ = (size_t)total;
+        createFile(filename_ + ".conn.bin", (size_t)total * nv * sizeof(int32_t));
+        writeAt(filename_ + ".conn.bin", (size_t)before * nv * sizeof(int32_t), c.data(), c.size() * sizeof(int32_t));
+        // points of the unique nodes, at their global positions
+        uniGid_.assign(mapUni->gids().begin(), mapUni->gids().end());
         auto pts = mesh->getPointsUnique();
-        nPoints_ = pts->size();
-        std::vector<double> xyz(nPoints_ * 3, 0.0);
-        for (size_t i = 0; i < nPoints_; ++i)
+        std::vector<double> xyz(uniGid_.size() * 3, 0.0);
+        for (size_t i = 0; i < uniGid_.size(); ++i)
             for (int d = 0; d < dim; ++d) xyz[i * 3 + d] = (*pts)[i][d];
-        writeBin(filename_ + ".xyz.bin", xyz.data(), xyz.size() * sizeof(double));
-        nElements_ = ne;
+        createFile(filename_ + ".xyz.bin", nPoints_ * 3 * sizeof(double));
+        writeRecords(filename_ + ".xyz.bin", xyz.data(), 3 * sizeof(double));
+        comm_->barrier();
         topology_ = dim == 3 ? "Tetrahedron" : "Triangle";
         nv_ = nv;
     }
@@ -1372,7 +1413,7 @@ public:
                      MapConstPtr_Type mapUnique = Teuchos::null, MapConstPtr_Type mapUniqueLeading = Teuchos::null) {
         (void)mapUnique; (void)mapUniqueLeading;
         TEUCHOS_TEST_FOR_EXCEPTION(varType != "Scalar" && varType != "Vector", std::logic_error, "Unknown variable type for exporter.");
-        TEUCHOS_TEST_FOR_EXCEPTION(u->getLocalLength() != nPoints_ * (size_t)dofPerNode, std::logic_error,
+        TEUCHOS_TEST_FOR_EXCEPTION(u->getLocalLength() != uniGid_.size() * (size_t)dofPerNode, std::logic_error,
                                    "ExporterParaView::addVariable: vector length does not match the mesh");
         vars_.push_back({u, varName, varType, dofPerNode});
     }
@@ -1383,24 +1424,66 @@ public:
             for (auto& v : vars_) {
                 const auto& x = v.u->raw();
                 const int comps = v.type == "Vector" ? 3 : 1;
-                std::vector<double> out(nPoints_ * comps, 0.0);
-                for (size_t i = 0; i < nPoints_; ++i)
+                const size_t nl = uniGid_.size();
+                std::vector<double> out(nl * comps, 0.0);
+                for (size_t i = 0; i < nl; ++i)
                     for (int d = 0; d < v.dofs && d < comps; ++d) out[i * comps + d] = x[i * v.dofs + d];
-                writeBin(filename_ + "." + v.name + "." + std::to_string(nSaved_) + ".bin", out.data(), out.size() * sizeof(double));
+                const std::string f = filename_ + "." + v.name + "." + std::to_string(nSaved_) + ".bin";
+                createFile(f, nPoints_ * comps * sizeof(double));
+                writeRecords(f, out.data(), comps * sizeof(double));
             }
+            comm_->barrier();
             times_.push_back(time);
             ++nSaved_;
-            writeXmf();
+            if (comm_->getRank() == 0) writeXmf();
         }
         ++timeIndex_;
     }
-    void closeExporter() { writeXmf(); }
+    void closeExporter() { if (comm_.is_null() || comm_->getRank() == 0) writeXmf(); }
 private:
     struct Var { MultiVecConstPtr_Type u; std::string name, type; int dofs; };
-    static void writeBin(const std::string& f, const void* p, size_t bytes) {
-        std::ofstream os(f, std::ios::binary);
+    std::vector<int64_t> gatherCounts(int64_t mine) const {
+        std::vector<char> all;
+        comm_->gatherAll(&mine, sizeof(mine), all);
+        std::vector<int64_t> out((size_t)comm_->getSize());
+        std::memcpy(out.data(), all.data(), out.size() * sizeof(int64_t));
+        return out;
+    }
+    // rank 0 creates the file at its final size; nobody writes before it exists
+    void createFile(const std::string& f, size_t bytes) const {
+        if (comm_->getRank() == 0) {
+            std::ofstream os(f, std::ios::binary | std::ios::trunc);
+            TEUCHOS_TEST_FOR_EXCEPTION(!os, std::runtime_error, "ExporterParaView: cannot write " << f);
+            if (bytes > 0) {
+                os.seekp((std::streamoff)bytes - 1);
+                os.put('\0');
+            }
+        }
+        comm_->barrier();
+    }
+    static void writeAt(const std::string& f, size_t offset, const void* p, size_t bytes) {
+        if (bytes == 0) return;
+        std::fstream os(f, std::ios::binary | std::ios::in | std::ios::out);
         TEUCHOS_TEST_FOR_EXCEPTION(!os, std::runtime_error, "ExporterParaView: cannot write " << f);
+        os.seekp((std::streamoff)offset);
         os.write((const char*)p, (std::streamsize)bytes);
+        TEUCHOS_TEST_FOR_EXCEPTION(!os, std::runtime_error, "ExporterParaView: short write to " << f);
+    }
+    // record i of `data` (one per unique node) to position gid(i): runs of consecutive global ids go out in one write
+    void writeRecords(const std::string& f, const double* data, size_t recBytes) const {
+        if (uniGid_.empty()) return;
+        std::fstream os(f, std::ios::binary | std::ios::in | std::ios::out);
+        TEUCHOS_TEST_FOR_EXCEPTION(!os, std::runtime_error, "ExporterParaView: cannot write " << f);
+        size_t i = 0;
+        const size_t n = uniGid_.size();
+        while (i < n) {
+            size_t j = i + 1;
+            while (j < n && uniGid_[j] == uniGid_[j - 1] + 1) ++j;
+            os.seekp((std::streamoff)((size_t)uniGid_[i] * recBytes));
+            os.write((const char*)data + i * recBytes, (std::streamsize)((j - i) * recBytes));
+            i = j;
+        }
+        TEUCHOS_TEST_FOR_EXCEPTION(!os, std::runtime_error, "ExporterParaView: short write to " << f);
     }
     static std::string base(const std::string& f) { const size_t p = f.find_last_of('/'); return p == std::string::npos ? f : f.substr(p + 1); }
     void writeXmf() const {
@@ -1428,6 +1511,8 @@ private:
     }
     std::string filename_, FEType_, topology_;
     MeshPtr_Type mesh_;
+    Teuchos::RCP<const Teuchos::Comm<int> > comm_;
+    std::vector<int64_t> uniGid_;
     std::vector<Var> vars_;
     std::vector<double> times_;
     size_t nPoints_ = 0, nElements_ = 0;

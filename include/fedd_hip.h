@@ -29,8 +29,11 @@ enum fedd_form {
     FEDD_FORM_LAPLACE_VEC = 1, /* FE::assemblyLaplaceVecField  FE_def.hpp:670-734   (dofs dim, diag)  */
     FEDD_FORM_MASS        = 2, /* FE::assemblyMass "Scalar"    FE_def.hpp:454-524   (dofs 1)          */
     FEDD_FORM_MASS_VEC    = 3, /* FE::assemblyMass "Vector"    FE_def.hpp:454-524   (dofs dim, diag)  */
-    FEDD_FORM_LINELAS     = 4  /* FE::assemblyLinElasXDim      FE_def.hpp:2739-3040 (dofs dim, full);
+    FEDD_FORM_LINELAS     = 4, /* FE::assemblyLinElasXDim      FE_def.hpp:2739-3040 (dofs dim, full);
                                   params = {lambda, mu}                                              */
+    FEDD_FORM_BDSTAB      = 5  /* FE::assemblyBDStabilization  FE_def.hpp:2151-2220 (dofs 1, P1 only): the Bochev-Dohrmann
+                                  pressure block of P1/P1 Stokes, C_ij = |det B| (sum_q w_q phi_i phi_j - |ref| scale),
+                                  scaled by -1/viscosity by the caller (Stokes_def.hpp:98-105)        */
 };
 
 /* ---- how the dofs of a node couple in the CSR pattern ---- */

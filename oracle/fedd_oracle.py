@@ -616,6 +616,29 @@ def assembly_mass(m: Mesh, field_type: str = "Scalar", fe: str | None = None) ->
     return fill_complete(r, c, v, m.dim * m.n_global)
 
 
+def assembly_bd_stabilization(m: Mesh) -> sp.csr_matrix:
+    """FE::assemblyBDStabilization (FE_def.hpp:2151-2220; P1 only, :2156): the mass matrix entry of every element pair minus
+    |det B| * refElementSize * refElementScale, with (1/2, 1/9) in 2D and (1/6, 1/16) in 3D (:2183-2192); the operation
+    order of :2204-2206 is kept (value *= absDetB; value -= refElementSize * absDetB * refElementScale)."""
+    assert m.fe == "P1", "Only implemented for P1"
+    dim = m.dim
+    deg = determine_degree("P1", "P1", "Std", "Std")
+    ph, w = get_phi(dim, "P1", deg)
+    absdet = np.abs(det_small(build_transformation(m)))
+    ref_size, ref_scale = (0.5, 1.0 / 9.0) if dim == 2 else (1.0 / 6.0, 1.0 / 16.0)
+    nen = dim + 1
+    base = np.zeros((nen, nen))
+    for i in range(nen):
+        for j in range(nen):
+            v = 0.0
+            for q in range(w.shape[0]):
+                v += w[q] * ph[q][i] * ph[q][j]
+            base[i, j] = v
+    K = base[None, :, :] * absdet[:, None, None]
+    K = K - (ref_size * absdet * ref_scale)[:, None, None]
+    return fill_complete(*_local_to_triplets(m, K), m.n_global)
+
+
 def assembly_rhs(m: Mesh, f_const, field_type: str = "Scalar", deg_func: int = 0,
                  fe: str | None = None) -> np.ndarray:
     """FE::assemblyRHS on the REPEATED vector (FE_def.hpp:4694-4766): f evaluated once (constant

@@ -156,9 +156,26 @@ def test_driver_on_several_ranks(driver, tmp_path, dim, ranks, hh):
     # cut at the rank boundaries (each rank inverts its part), which costs a few iterations
     prob1 = tmp_path / "p1.xml"
     prob1.write_text(txt.replace('name="H/h" type="int" value="%d"' % hh, 'name="H/h" type="int" value="%d"' % (n * hh)))
+    # the ParaView export of the several ranks (ExporterParaView_def.hpp:484-601: every rank writes its part of the global
+    # arrays): read back before the one-rank run overwrites it
+    nv = dim + 1
+    u_n = np.fromfile(str(tmp_path / "solutionLaplace.u.0.bin"), dtype="<f8")
+    pts_n = np.fromfile(str(tmp_path / "solutionLaplace.xyz.bin"), dtype="<f8").reshape(-1, 3)
+    conn_n = np.fromfile(str(tmp_path / "solutionLaplace.conn.bin"), dtype="<i4").reshape(-1, nv)
+    xmf_n = (tmp_path / "solutionLaplace.xmf").read_text()
+    np.testing.assert_array_equal(u_n, x)                   # the payload IS the solution, in global-id order
+    # (a rank's coordinates are r * h + offset * H, MeshStructured_def.hpp:727-734: an ulp off the one-rank r * h)
+    np.testing.assert_allclose(pts_n[:, :dim], m.xyz_uni if m.xyz_uni is not None else m.xyz, atol=1e-14)
     x1, its1, rel1, _ = run_driver(driver, tmp_path, prob1, prec, sol)
     assert (abs(its - its1) <= 2) if dim == 3 else (its1 - 2 <= its <= its1 + 12), (its, its1)
     np.testing.assert_allclose(x, x1, rtol=0, atol=1e-9 * np.abs(xd).max())
+    # ... and the one-rank export of the same grid: the same points, the same set of elements (every element exactly once)
+    pts_1 = np.fromfile(str(tmp_path / "solutionLaplace.xyz.bin"), dtype="<f8").reshape(-1, 3)
+    conn_1 = np.fromfile(str(tmp_path / "solutionLaplace.conn.bin"), dtype="<i4").reshape(-1, nv)
+    np.testing.assert_allclose(pts_n, pts_1, rtol=0, atol=1e-14)
+    key = lambda c: np.array(sorted(map(tuple, np.sort(c, axis=1).tolist())))
+    assert conn_n.shape == conn_1.shape and np.array_equal(key(conn_n), key(conn_1))
+    assert 'NumberOfElements="%d"' % conn_1.shape[0] in xmf_n and "solutionLaplace.u.0.bin" in xmf_n
 
 
 @pytest.mark.parametrize("ranks", [1, 3])

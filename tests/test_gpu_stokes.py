@@ -278,3 +278,69 @@ def test_cfg4_stokes_solve_on_the_6k_cylinder(fedd_lib):
         assert np.abs(x[3 * nv:] - xd[3 * nv:]).max() <= 1e-8 * np.abs(xd[3 * nv:]).max()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("dim,M", [(3, 5), (2, 12)])
+def test_bd_stabilization_and_p1p1_stokes(fedd_lib, ctx, dim, M):
+    """FE::assemblyBDStabilization (FE_def.hpp:2151-2220) and the P1/P1 Stokes system it completes
+    (Stokes_def.hpp:98-105: C = -1/nu * BD in block (1,1)): the block against the oracle, the merged system against the oracle's,
+    and its solution against a direct solve."""
+    m = fedd_lib.structured_mesh(dim, 1, M)
+    om = oracle_mesh(m)
+    nv = n_p = m["xyz"].shape[0]
+    nu = 0.7
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+    ctx.assemble(fedd_lib.FORM_BDSTAB)
+    Co = fo.assembly_bd_stabilization(om)
+    assert_matrix_close(csr_global(ctx, om.n_global)[0], Co)
+    # row sums: sum_j (M_ij - |K|/(dim+1)^2) over the elements = 0 for every row (the block annihilates constants)
+    assert np.abs(Co @ np.ones(n_p)).max() <= 1e-14 * np.abs(Co).max()
+    if dim == 3:        # FE_def.hpp:2156: "Only implemented for P1"
+        c2 = fedd_lib.Context(device=0)
+        try:
+            c2.mesh_set_dict(fedd_lib.p2_of_p1(m, volume_id=0))
+            c2.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+            with pytest.raises(fedd_lib.FeddError, match="only implemented for P1"):
+                c2.assemble(fedd_lib.FORM_BDSTAB)
+        finally:
+            c2.close()
+    # the P1/P1 system
+    ctx.pattern_build(dim, fedd_lib.BLOCK_DIAG)
+    ctx.assemble(fedd_lib.FORM_LAPLACE_VEC)
+    ctx.matrix_scale(-1, nu)
+    ctx.matrix_store(0)
+    ctx.assemble_div(n_p, 1, 2)
+    ctx.matrix_scale(1, -1.0)
+    ctx.matrix_scale(2, -1.0)
+    ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+    ctx.assemble(fedd_lib.FORM_BDSTAB)
+    ctx.matrix_scale(-1, -1.0 / nu)
+    ctx.matrix_store(3)
+    ctx.block_merge(0, 2, 1, 3)
+    Ao, BTo, Bo = fo.stokes_blocks(om, om, nu)
+    Mo = fo.block_merge(Ao, BTo, Bo, (-1.0 / nu) * Co)
+    n = dim * nv + n_p
+    X = m["xyz"]
+    inflow = X[:, 0] < 1e-12
+    wall = np.zeros(nv, dtype=bool)
+    for d in range(1, dim):
+        wall |= (X[:, d] < 1e-12) | (X[:, d] > 1 - 1e-12)
+    rows, vals = [], []
+    for node in np.nonzero(inflow | wall)[0]:
+        for d in range(dim):
+            rows.append(dim * node + d)
+            y = X[node, 1]
+            vals.append(4.0 * y * (1.0 - y) if (inflow[node] and not wall[node] and d == 0) else 0.0)
+    rows = np.array(rows); vals = np.array(vals)
+    ctx.rhs_set(np.zeros(n))
+    ctx.dirichlet_rows(rows, vals)
+    is_dir = np.zeros(n, dtype=bool); is_dir[rows] = True
+    g = np.zeros(n); g[rows] = vals
+    M_bc, rhs_bc = fo.set_dirichlet(Mo, np.zeros(n), is_dir, g)
+    rowptr, col, val, gid = ctx.csr_get()
+    assert_matrix_close(sp.csr_matrix((val, col, rowptr), shape=(n, n)), M_bc)
+    x, its, rel = ctx.gmres(None, rtol=1e-12, max_it=4 * n, restart=min(n, 1000), use_prec=False)
+    xd = fo.direct_solve(M_bc, rhs_bc)
+    assert rel <= 1e-12
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-8 * np.abs(xd).max())

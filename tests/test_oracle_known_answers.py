@@ -264,3 +264,19 @@ def test_coarse_level_invariants():
     assert co3.n0 == 375
     np.testing.assert_allclose(co3.K0[0::3, 0::3], co.K0, atol=1e-12 * abs(co.K0).max())
     assert abs(co3.K0[0::3, 1::3]).max() == 0
+
+
+def test_bd_stabilization_on_the_reference_tet():
+    """FE::assemblyBDStabilization (FE_def.hpp:2151-2220) on meshes/tetrahedron.mesh: P1 mass (1 + delta_ij) / 120 minus
+    |K| / 16 = 1 / 96 per entry: 1/60 - 1/96 = 1/160 on the diagonal, 1/120 - 1/96 = -1/480 off it; rows sum to zero."""
+    m = fo.read_mesh_file(os.path.join(GOLD, "tetrahedron.mesh"), 3, volume_id=0)
+    if m.conn.shape[0] != 1:
+        m = fo.read_mesh_file(os.path.join(GOLD, "tetrahedron.mesh"), 3, volume_id=int(m.elem_flag[0]))
+    C = fo.assembly_bd_stabilization(m).toarray()
+    expect = np.full((4, 4), -1.0 / 480.0) + np.eye(4) * (1.0 / 160.0 + 1.0 / 480.0)
+    np.testing.assert_allclose(C, expect, rtol=1e-13, atol=1e-17)
+    np.testing.assert_allclose(C.sum(axis=1), 0.0, atol=1e-16)
+    # 2D: the unit triangle, mass (1 + delta_ij) / 24, minus (1/2) (1/9)
+    m2 = fo.build_mesh_structured(2, 1, 1)
+    C2 = fo.assembly_bd_stabilization(m2)
+    np.testing.assert_allclose(C2 @ np.ones(4), 0.0, atol=1e-16)
