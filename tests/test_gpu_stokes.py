@@ -134,7 +134,7 @@ def test_small_stokes_solve(fedd_lib, ctx):
     x, its, rel = ctx.gmres(None, rtol=1e-12, max_it=3 * n, restart=n, use_prec=False)
     xd = fo.direct_solve(M_bc, rhs_bc)
     assert rel <= 1e-12 and np.linalg.norm(rhs_bc - M_bc @ x) <= 1e-11 * np.linalg.norm(rhs_bc)
-    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())      # north_star: 1e-10 on the solution (measured 2e-11)
 
 
 def test_cfg4_block_assembly_on_the_6k_cylinder(fedd_lib, ctx):
@@ -233,11 +233,11 @@ def test_stokes_monolithic_schwarz_matches_oracle_on_the_1k_cylinder(fedd_lib, w
         assert info["n_subdomains"] == nb and info["max_size"] == ras.max_size and 256 < ras.max_size <= 1024
         r = np.random.default_rng(9).standard_normal(n)
         z, zo = c.schwarz_apply(r), ras.apply(r)
-        np.testing.assert_allclose(z, zo, rtol=0, atol=1e-8 * np.abs(zo).max())
+        np.testing.assert_allclose(z, zo, rtol=0, atol=1e-10 * np.abs(zo).max())     # measured 3e-14
         x, its, rel = c.gmres(None, rtol=1e-12, max_it=1500, restart=300, use_prec=True)
         assert rel <= 1e-12
         xd = fo.direct_solve(M, b)
-        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())     # measured 7e-12
     finally:
         c.close()
 
@@ -273,9 +273,9 @@ def test_cfg4_stokes_solve_on_the_6k_cylinder(fedd_lib):
         assert xd.shape[0] == n and int(gold["nv"]) == nv
         assert np.linalg.norm(b - M @ xd) / np.linalg.norm(b) <= 1e-12
         err = np.abs(x - xd).max() / np.abs(xd).max()
-        assert err <= 1e-9, err
+        assert err <= 1e-10, err        # north_star: 1e-10 on the solution vector (measured 1.8e-11)
         # velocity and pressure separately (the pressure is the badly scaled part of the vector)
-        assert np.abs(x[3 * nv:] - xd[3 * nv:]).max() <= 1e-8 * np.abs(xd[3 * nv:]).max()
+        assert np.abs(x[3 * nv:] - xd[3 * nv:]).max() <= 1e-10 * np.abs(xd[3 * nv:]).max()
     finally:
         c.close()
 
@@ -340,7 +340,9 @@ def test_bd_stabilization_and_p1p1_stokes(fedd_lib, ctx, dim, M):
     M_bc, rhs_bc = fo.set_dirichlet(Mo, np.zeros(n), is_dir, g)
     rowptr, col, val, gid = ctx.csr_get()
     assert_matrix_close(sp.csr_matrix((val, col, rowptr), shape=(n, n)), M_bc)
-    x, its, rel = ctx.gmres(None, rtol=1e-12, max_it=4 * n, restart=min(n, 1000), use_prec=False)
+    x, its, rel = ctx.gmres(None, rtol=1e-13, max_it=6 * n, restart=min(n, 1000), use_prec=False)
     xd = fo.direct_solve(M_bc, rhs_bc)
-    assert rel <= 1e-12
-    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-8 * np.abs(xd).max())
+    assert rel <= 1e-13
+    # unpreconditioned GMRES on the stabilised saddle-point system: error <= cond x residual; measured 1e-9 (3D) / 1e-10 (2D) at a
+    # 1e-12 residual -- the 1e-10 bar is met in 2D, the 3D system is the worse conditioned one
+    np.testing.assert_allclose(x, xd, rtol=0, atol=(1e-10 if dim == 2 else 1e-9) * np.abs(xd).max())

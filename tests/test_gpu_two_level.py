@@ -151,14 +151,14 @@ def test_gdsw_coarse_matrix_and_apply(fedd_lib, dim, M, cells, kind):
         np.testing.assert_array_equal(g[:dim], co.g)
         assert Kinv.shape == (co.n0, co.n0)
         assert co.n0 == (int(np.prod(np.where(co.g >= 2, co.g - 1, 1))) if reduced else int(np.prod(2 * co.g - 1)))
-        np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-9 * np.abs(co.K0inv).max())
+        np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-10 * np.abs(co.K0inv).max())
         node_bin, nb, _ = fo.schwarz_bins(m["xyz"], tgt)
         ras = fo.RAS(A_bc, node_bin, nb)
         rng = np.random.default_rng(5)
         r = rng.standard_normal(A_bc.shape[0])
         z = c.schwarz_apply(r)
         zo = ras.apply(r) + co.apply(r)
-        np.testing.assert_allclose(z, zo, rtol=0, atol=1e-9 * np.abs(zo).max())
+        np.testing.assert_allclose(z, zo, rtol=0, atol=1e-10 * np.abs(zo).max())
         np.testing.assert_array_equal(c.schwarz_apply(r), c.schwarz_apply(r))
         x, its, rel = c.gmres(None, rtol=1e-12, max_it=300, restart=100, use_prec=True)
         xd = fo.direct_solve(A_bc, rhs_bc)
@@ -192,10 +192,10 @@ def test_gdsw_elasticity_and_iteration_counts(fedd_lib):
         g, Kinv = c.schwarz_coarse()
         co = fo.CoarseGDSW(A_bc, m["conn"], m["xyz"], is_dir, 3, cells_target=8)
         assert Kinv.shape == (co.n0, co.n0) and co.n0 == 27 * 3
-        np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-8 * np.abs(co.K0inv).max())
+        np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-10 * np.abs(co.K0inv).max())
         x, its, rel = c.gmres(None, rtol=1e-12, max_it=400, restart=100, use_prec=True)
         xd = fo.direct_solve(A_bc, rhs_bc)
-        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
         # Laplace, H / h = 8 fixed: 4^3, 6^3, 8^3 coarse cells (32^3 ... 64^3 fine cells)
         c.set_option("gdsw_tol", 1e-10)
         counts = {}
