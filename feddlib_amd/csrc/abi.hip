@@ -712,6 +712,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
         FEDD_CHECK(value > 0.0 && value < 1.0, "fedd_set_option: gdsw_tol %g", value);
         c->gdsw_tol = value;
     } else if (k == "schwarz_dedupe") c->sw_dedupe = (int)value;
+    else if (k == "schwarz_fp_kind") { c->sw_fp_kind = (int)value; c->have_schwarz = false; }
     else if (k == "apply_span") c->apply_span = (int)value;
     else if (k == "md2_gy") c->md2_gy = (int)value;
     else if (k == "gmres_hostwrite") c->h_pinned_dev = value != 0 ? c->h_pinned_map : nullptr;

@@ -244,6 +244,7 @@ struct fedd_ctx {
     int64_t sw_nint = -1;                       // subdomains without ghost dofs at the front of d_sw_order (-1: not split)
     int apply_span = 0;                         // grouped apply: subdomains per workgroup (0 = 64)
     int sw_dedupe = 1;                          // option "schwarz_dedupe": subdomains with the same local matrix share one slab
+    int sw_fp_kind = 0;                         // option "schwarz_fp_kind": fingerprints from row hashes (0) or entry by entry (1)
     int64_t sw_nrep = 0;                        // distinct local matrices (= slabs) of the last setup
     fedd::DevBuf<double> d_sw_rmax;             // [n_rows_ext] largest magnitude of every stored row
     fedd::DevBuf<uint64_t> d_sw_fp;             // fingerprints [2 nsub] | hash table keys [2 tsize]

@@ -300,6 +300,100 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
+// Row maxima and ROW hashes in one coalesced pass over the stored rows (16 lanes per row): 128 bits, order-independent, over
+// (column - row, value quantised to 2^-44 of the row's largest magnitude) of every entry that does not quantise to zero.
+// A subdomain's fingerprint is then built from the hashes of its rows (k_sub_fingerprint_rows below): 31 M row hashes to
+// gather at the 214^3 grid instead of 460 M matrix entries to look up (3.4 ms -> well under 1 ms).
+__global__ void k_row_hash(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, const double* __restrict__ val,
+                           int32_t n_rows, double* __restrict__ rmax, uint64_t* __restrict__ rh) {
+    const int32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int e = threadIdx.x & 15;
+    double m = 0.0;
+    int32_t p0 = 0, p_end = 0;
+    if (r < n_rows) {
+        p0 = rowptr[r];
+        p_end = rowptr[r + 1];
+        for (int32_t p = p0 + e; p < p_end; p += 16) m = fmax(m, fabs(val[p]));
+    }
+    for (int off = 8; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 16));
+    const double scale = m > 0.0 ? 17592186044416.0 / m : 0.0;   // 2^44 / row max
+    uint64_t h1 = 0, h2 = 0;
+    for (int32_t p = p0 + e; p < p_end; p += 16) {
+        const int64_t q = (int64_t)llrint(val[p] * scale);
+        if (q == 0) continue;
+        const uint64_t key = (uint64_t)(uint32_t)(colind[p] - r);
+        h1 += mix64((key + 0x2545f4914f6cdd1dull) * 0x9e3779b97f4a7c15ull + (uint64_t)q);
+        h2 += mix64((key + 0x632be59bd9b4e019ull) * 0xd6e8feb86659fd93ull ^ ((uint64_t)q * 0xa0761d6478bd642full));
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+        h1 += __shfl_xor(h1, off, 16);
+        h2 += __shfl_xor(h2, off, 16);
+    }
+    if (r < n_rows && e == 0) {
+        rmax[r] = m;
+        rh[2 * (int64_t)r] = h1;
+        rh[2 * (int64_t)r + 1] = h2;
+    }
+}
+
+// Fingerprint of every subdomain from the hashes of its rows: one wave per subdomain, a lane per local row.  Equal fingerprints
+// = the same number of dofs at the same positions relative to the first one, and in every local row the same entries at the
+// same column offsets (entries that leave the subdomain included: stricter than the local matrix needs, which costs
+// nothing on a mesh of repeated cells) = equal local matrices.  The scale is part of the identity (see below).
+template <int NM>
+__global__ __launch_bounds__(64) void k_sub_fingerprint_rows(const int32_t* __restrict__ sub_n, const int32_t* __restrict__ sub_nown,
+                                                             const int32_t* __restrict__ sub_dofs, const double* __restrict__ rmax,
+                                                             const uint64_t* __restrict__ rh, int32_t n_stored, int32_t p_off,
+                                                             uint64_t* __restrict__ fp) {
+    constexpr int T = NM / 64;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = sub_n[b], no = sub_nown[b];
+    int32_t g[T];
+    double rm[T];
+    double smax = 0.0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int i = lane + 64 * t;
+        g[t] = i < n ? sub_dofs[(int64_t)b * NM + i] : -1;
+        rm[t] = (g[t] >= 0 && g[t] < n_stored) ? rmax[g[t]] : 0.0;
+        smax = fmax(smax, rm[t]);
+    }
+    for (int off = 32; off > 0; off >>= 1) smax = fmax(smax, __shfl_xor(smax, off, 64));
+    const int32_t s0 = __shfl(g[0], 0, 64);
+    const double sscale = smax > 0.0 ? 17592186044416.0 / smax : 0.0;
+    uint64_t h1 = 0, h2 = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int i = lane + 64 * t;
+        if (g[t] < 0) continue;
+        if (g[t] >= n_stored) {   // ghost row without a stored row: identity
+            h1 += mix64(((uint64_t)i << 32) ^ 0x9e3779b97f4a7c15ull);
+            h2 += mix64(((uint64_t)i << 20) ^ 0xd1b54a32d192ed03ull);
+            continue;
+        }
+        // pressure rows of a merged system are pivoted after the velocities: part of the matrix' identity
+        const uint64_t tag = g[t] >= p_off ? 0x5851f42d4c957f2dull : 0ull;
+        const uint64_t rel = (uint64_t)(uint32_t)(g[t] - s0);
+        const uint64_t qs = (uint64_t)llrint(rm[t] * sscale);
+        const uint64_t a = rh[2 * (int64_t)g[t]], c2 = rh[2 * (int64_t)g[t] + 1];
+        h1 += mix64((a ^ ((uint64_t)i << 48)) + mix64(rel * 0x9fb21c651e98df25ull + qs) + tag);
+        h2 += mix64((c2 + ((uint64_t)i << 40)) ^ mix64((rel + 0x94d049bb133111ebull) * 0xbf58476d1ce4e5b9ull ^ qs) ^ tag);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        h1 += __shfl_down(h1, off, 64);
+        h2 += __shfl_down(h2, off, 64);
+    }
+    if (lane == 0) {
+        const uint64_t sbits = ((uint64_t)__double_as_longlong(smax) + (1ull << 11)) & ~((1ull << 12) - 1ull);
+        h1 = mix64(h1 + (uint64_t)n * 1000003ull + (uint64_t)no + mix64(sbits));
+        h2 += mix64(sbits ^ 0xbf58476d1ce4e5b9ull);
+        if (h1 == 0) h1 = 1;   // 0 marks an empty table slot
+        fp[2 * (int64_t)b] = h1;
+        fp[2 * (int64_t)b + 1] = h2;
+    }
+}
+
+// (the entry-by-entry form of the fingerprint, kept for option "schwarz_fp_kind" 1: hashes only the entries inside the subdomain)
 // one wave per subdomain: 16 lanes per local row (four rows at a time), the lanes of a group read consecutive entries of the
 // CSR row (with a lane per row every load instruction touched 64 different cache lines: address-bound, 10.7 ms at cfg 3)
 template <int NM>
@@ -1338,10 +1432,16 @@ int schwarz_setup(fedd_ctx* c) {
     if (c->sw_dedupe) {
         const dim3 gs((unsigned)((nsub + 255) / 256));
         FEDD_TRY(c->d_sw_rmax.ensure((size_t)n_stored));
-        hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)((n_stored + 15) / 16)), blk, 0, c->stream, (const int32_t*)c->d_rowptr.p,
-                           (const double*)c->d_val.p, n_stored, c->d_sw_rmax.p);
         const int64_t tsize = 2 * nsub + 64;
-        FEDD_TRY(c->d_sw_fp.ensure((size_t)(2 * nsub + 2 * tsize)));
+        const bool by_rows = c->sw_fp_kind == 0;
+        FEDD_TRY(c->d_sw_fp.ensure((size_t)(2 * nsub + 2 * tsize) + (by_rows ? 2 * (size_t)n_stored : 0)));
+        uint64_t* row_hash = c->d_sw_fp.p + 2 * nsub + 2 * tsize;
+        if (by_rows)
+            hipLaunchKernelGGL(k_row_hash, dim3((unsigned)((n_stored + 15) / 16)), blk, 0, c->stream, (const int32_t*)c->d_rowptr.p,
+                               (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, n_stored, c->d_sw_rmax.p, row_hash);
+        else
+            hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)((n_stored + 15) / 16)), blk, 0, c->stream, (const int32_t*)c->d_rowptr.p,
+                               (const double*)c->d_val.p, n_stored, c->d_sw_rmax.p);
         FEDD_TRY(c->d_sw_rep.ensure((size_t)(3 * nsub + tsize + 4)));
         uint64_t* fp = c->d_sw_fp.p;
         uint64_t* tkey = fp + 2 * nsub;
@@ -1353,9 +1453,14 @@ int schwarz_setup(fedd_ctx* c) {
         FEDD_HIP(hipMemsetAsync(tkey, 0, (size_t)(2 * tsize) * sizeof(uint64_t), c->stream));
         FEDD_HIP(hipMemsetAsync(tmin, 0x7f, (size_t)tsize * sizeof(int32_t), c->stream));
         FEDD_HIP(hipMemsetAsync(n_rep, 0, sizeof(int32_t), c->stream));
-        hipLaunchKernelGGL((k_sub_fingerprint<NMAX>), dim3((unsigned)nsub), dim3(64), 0, c->stream, (const int32_t*)c->d_sub_n.p,
-                           (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const int32_t*)c->d_rowptr.p,
-                           (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, (const double*)c->d_sw_rmax.p, n_stored, p_off, fp);
+        if (by_rows)
+            hipLaunchKernelGGL((k_sub_fingerprint_rows<NMAX>), dim3((unsigned)nsub), dim3(64), 0, c->stream, (const int32_t*)c->d_sub_n.p,
+                               (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const double*)c->d_sw_rmax.p,
+                               (const uint64_t*)row_hash, n_stored, p_off, fp);
+        else
+            hipLaunchKernelGGL((k_sub_fingerprint<NMAX>), dim3((unsigned)nsub), dim3(64), 0, c->stream, (const int32_t*)c->d_sub_n.p,
+                               (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p, (const int32_t*)c->d_rowptr.p,
+                               (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, (const double*)c->d_sw_rmax.p, n_stored, p_off, fp);
         hipLaunchKernelGGL(k_fp_insert, gs, blk, 0, c->stream, (const uint64_t*)fp, (int32_t)nsub, tkey, tmin, tsize, slot_of);
         hipLaunchKernelGGL(k_fp_resolve, gs, blk, 0, c->stream, (const int32_t*)slot_of, (const int32_t*)tmin,
                            (const int32_t*)c->d_sub_n.p, (int32_t)nsub, rep, n_inv, n_rep);

@@ -356,6 +356,9 @@ int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_bloc
  * compacted stream (tests and measurements of those kernels);
  * "schwarz_dedupe" 1 (default) = subdomains with the same local matrix share one inverse (see fedd_schwarz_unique), 0 = every
  * subdomain is inverted and stored on its own;
+ * "schwarz_fp_kind" 0 (default) = the fingerprints of that sharing are built from one hash per matrix ROW (column offsets and
+ * quantised values of all its entries) and the rows' positions in the subdomain, 1 = entry by entry over the entries inside the
+ * subdomain (the round-2 form; finds the same classes on the structured grids, four times slower);
  * "halo_overlap" 1 = several ranks, restricted combine: the subdomains that hold no dof of another rank are applied while the
  * ghost entries of r are imported on a second stream, the others after the import (same operator bit for bit); 0 (default) =
  * import, then all subdomains.  An A/B switch for multi-GPU runs: on one GPU there is nothing to hide;

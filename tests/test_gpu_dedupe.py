@@ -176,3 +176,21 @@ def test_scaled_copies_of_a_local_matrix_do_not_share_an_inverse(fedd_lib, ctx):
         assert info["n_subdomains"] == nb
         np.testing.assert_allclose(out[(dedupe, kind)], zo, rtol=0, atol=1e-10 * np.abs(zo).max())
     assert info["n_unique"] < info["n_subdomains"]          # sharing still happens where the matrices ARE equal
+
+
+@pytest.mark.parametrize("kind,dim,M,target", [("laplace", 3, 20, 27), ("laplace", 2, 60, 27), ("linelas", 3, 12, 8)])
+def test_row_hash_fingerprints_find_the_classes_of_the_entry_fingerprints(fedd_lib, ctx, kind, dim, M, target):
+    """schwarz_fp_kind 0 (one hash per matrix row, the default) against 1 (entry by entry inside the subdomain): the same
+    number of distinct local matrices on the structured meshes, and the same operator."""
+    m, A_bc, dofs = problem(fedd_lib, ctx, kind, dim, M)
+    r = np.random.default_rng(M).standard_normal(A_bc.shape[0])
+    ctx.schwarz_set_target(target, 1.0)
+    ctx.set_option("schwarz_dedupe", 1)
+    ctx.set_option("apply_kind", 4)
+    out = {}
+    for fp_kind in (1, 0):
+        ctx.set_option("schwarz_fp_kind", fp_kind)
+        ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+        out[fp_kind] = (ctx.schwarz_info()["n_unique"], ctx.schwarz_apply(r))
+    assert out[0][0] == out[1][0] and out[0][0] * 4 <= ctx.schwarz_info()["n_subdomains"]
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-12 * np.abs(out[1][1]).max())
