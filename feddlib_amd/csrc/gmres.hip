@@ -265,14 +265,34 @@ __global__ __launch_bounds__(256) void k_backsolve(double* __restrict__ S, Off o
     }
 }
 
-// u = sum_c y[c] V_c
+// u = sum_c y[c] V_c : one double2 of u per lane, the column loop unrolled 8x (8 x 16 B non-temporal loads in flight per lane;
+// the first version, a scalar load per lane and column, ran at half the bandwidth: 1.1 ms for 45 columns at 9.9 M rows)
 __global__ __launch_bounds__(256) void k_combine(const double* __restrict__ V, int64_t ldv, int64_t n, int k,
                                                  const double* __restrict__ y, double* __restrict__ u) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double v = 0.0;
-    for (int c = 0; c < k; ++c) v += y[c] * V[(int64_t)c * ldv + i];
-    u[i] = v;
+    __shared__ double sh_y[1024];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < k; c += 256) sh_y[c] = y[c];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * AX_ROWS + 2 * tid;
+    double2 v = {0.0, 0.0};
+    int c = 0;
+    for (; c + 8 <= k; c += 8) {
+        double2 t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = ld2(V + (int64_t)(c + q) * ldv, r, n);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v.x += sh_y[c + q] * t[q].x;
+            v.y += sh_y[c + q] * t[q].y;
+        }
+    }
+    for (; c < k; ++c) {
+        const double2 t = ld2(V + (int64_t)c * ldv, r, n);
+        v.x += sh_y[c] * t.x;
+        v.y += sh_y[c] * t.y;
+    }
+    if (r + 1 < n) *reinterpret_cast<double2*>(u + r) = v;
+    else if (r < n) u[r] = v.x;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -737,7 +757,7 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
         }
         // x += M^-1 (V y) with the kfin finalised columns
         hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(kfin + 1) * sizeof(double), st, S, o, kfin, m);
-        hipLaunchKernelGGL(k_combine, gn, blk, 0, st, (const double*)V, ldv, n, kfin, (const double*)(S + o.y), r);
+        hipLaunchKernelGGL(k_combine, dim3((unsigned)((n + AX_ROWS - 1) / AX_ROWS)), blk, 0, st, (const double*)V, ldv, n, kfin, (const double*)(S + o.y), r);
         if (use_prec) {
             FEDD_TRY(schwarz_apply(c, r, z, true));
             if (mk) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)z, (const double*)r, z, n);
@@ -865,10 +885,10 @@ constexpr int SS_LDS_GROUPS = 32;   // column groups whose wave totals are parke
 // (W_j = V_{k+j}); the W tile stays in registers across the column groups, every basis column is read once.
 // The four wave totals of a column group are parked in LDS and added (fixed order) once per SS_LDS_GROUPS groups:
 // no barrier between the loads of consecutive groups.
-template <int S>
+template <int S, int NCH, int SS_CG>
 __global__ __launch_bounds__(256) void k_blockdot(const double* __restrict__ V, int64_t ldv, int64_t n, int k, int sa_req,
                                                   const int32_t* __restrict__ d_sa, double* __restrict__ partial, int nblk) {
-    constexpr int NCH = 2, SS_CG = ss_cg(S), NV = SS_CG * S;
+    constexpr int NV = SS_CG * S;
     static_assert(NV == 16 || NV == 32 || NV == 64, "block size");
     __shared__ double sh[SS_LDS_GROUPS][4][NV];
     const int sa = d_sa ? min(*d_sa, sa_req) : sa_req;
@@ -1332,7 +1352,11 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     const int64_t ldv = (n + 15) & ~(int64_t)15;
     FEDD_CHECK(m + 2 <= 1024, "gmres: restart length above 1022 is not supported");
     const int nblk = (int)((n + MD_ROWS - 1) / MD_ROWS), nblk2 = (int)((n + AX_ROWS - 1) / AX_ROWS);
-    const int nblkd = (int)((n + 1023) / 1024);
+    // block dot kernel: 512 NCH rows per workgroup, CG columns per transpose reduction (option "gmres_dotv": 0 = 2 chunks x ss_cg
+    // columns; 1 = 1 chunk x ss_cg; 2 = 1 chunk x 2 ss_cg)
+    const int dotv = c->gmres_dotv;
+    const int dot_nch = dotv == 0 ? 2 : 1, dot_cg = dotv == 2 ? std::min(64 / S, 2 * ss_cg(S)) : ss_cg(S);
+    const int nblkd = (int)((n + 512 * dot_nch - 1) / (512 * dot_nch));
     {
         // the block kernels read whole 16-byte row pairs and rely on the padding rows [n, ldv) of every column being zero
         // (and on finite data everywhere): a freshly (re)allocated basis, or one last used with another vector length, is cleared
@@ -1435,7 +1459,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     auto trial = [&](int cols, double* true_abs) -> int {
         if (cols > 0) {
             hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(cols + 1) * sizeof(double), st, Sx, o, cols, m);
-            hipLaunchKernelGGL(k_combine, gn, blk, 0, st, (const double*)V, ldv, n, cols, (const double*)(Sx + o.y), r);
+            hipLaunchKernelGGL(k_combine, dim3((unsigned)((n + AX_ROWS - 1) / AX_ROWS)), blk, 0, st, (const double*)V, ldv, n, cols, (const double*)(Sx + o.y), r);
             if (use_prec) {
                 FEDD_TRY(schwarz_apply(c, r, z, true));
                 if (mk) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)z, (const double*)r, z, n);
@@ -1499,14 +1523,22 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
                 FEDD_TRY(apply_B(V + (int64_t)(k - 1 + i) * ldv, V + (int64_t)(k + i) * ldv, have_shifts ? theta[(size_t)i] : 0.0));
             {
                 ScopedTimer t(c, FEDD_T_ORTHO);
-                const int ncg = (k + sa + ss_cg(S) - 1) / ss_cg(S);
+                const int ncg = (k + sa + dot_cg - 1) / dot_cg;
                 const dim3 gd(nblkd, std::min(gy_dot, ncg));
+                auto launch_dot = [&](const dim3& g, const int32_t* dsa) {
+                    constexpr int CG0 = ss_cg(S), CG2 = (64 / S < 2 * CG0) ? 64 / S : 2 * CG0;
+                    if (dotv == 0)
+                        hipLaunchKernelGGL((k_blockdot<S, 2, CG0>), g, blk, 0, st, (const double*)V, ldv, n, k, sa, dsa, c->d_part.p, nblkd);
+                    else if (dotv == 1)
+                        hipLaunchKernelGGL((k_blockdot<S, 1, CG0>), g, blk, 0, st, (const double*)V, ldv, n, k, sa, dsa, c->d_part.p, nblkd);
+                    else
+                        hipLaunchKernelGGL((k_blockdot<S, 1, CG2>), g, blk, 0, st, (const double*)V, ldv, n, k, sa, dsa, c->d_part.p, nblkd);
+                };
                 const double dot_bytes = 8.0 * (double)n * (k + 2 * sa), upd_bytes = 8.0 * (double)n * (k + 2 * sa);
                 {
                     ScopedTimer td(c, FEDD_T_GS_DOT);
                     td.bytes(dot_bytes);
-                    hipLaunchKernelGGL(k_blockdot<S>, gd, blk, 0, st, (const double*)V, ldv, n, k, sa, (const int32_t*)nullptr,
-                                       c->d_part.p, nblkd);
+                    launch_dot(gd, (const int32_t*)nullptr);
                 }
                 hipLaunchKernelGGL(k_reduce_cols, dim3((k + sa) * S), blk, 0, st, (const double*)c->d_part.p, Sx + o3.P, nblkd,
                                    (const int32_t*)nullptr);
@@ -1521,8 +1553,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
                 {
                     ScopedTimer td(c, FEDD_T_GS_DOT);
                     td.bytes(dot_bytes);
-                    hipLaunchKernelGGL(k_blockdot<S>, gd, blk, 0, st, (const double*)V, ldv, n, k, sa, (const int32_t*)d_sa,
-                                       c->d_part.p, nblkd);
+                    launch_dot(gd, (const int32_t*)d_sa);
                 }
                 hipLaunchKernelGGL(k_reduce_cols, dim3((k + sa) * S), blk, 0, st, (const double*)c->d_part.p, Sx + o3.P, nblkd,
                                    (const int32_t*)nullptr);
@@ -1845,7 +1876,7 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
         }
         // x += M^-1 (V y)
         hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(k + 1) * sizeof(double), st, S, o, k, m);
-        hipLaunchKernelGGL(k_combine, gn, blk, 0, st, (const double*)V, ldv, n, k, (const double*)(S + o.y), r);
+        hipLaunchKernelGGL(k_combine, dim3((unsigned)((n + AX_ROWS - 1) / AX_ROWS)), blk, 0, st, (const double*)V, ldv, n, k, (const double*)(S + o.y), r);
         if (use_prec) {
             FEDD_TRY(schwarz_apply(c, r, z));
             hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)z, d_x, n);
