@@ -173,6 +173,7 @@ static int mesh_set_impl(fedd_ctx* c, int dim, int nen, int64_t n_elem, const in
     c->n_own = n_uni;
     c->n_rowg = 0;
     c->have_adj = c->have_pattern = c->have_schwarz = c->have_coarse = false;
+    c->tl_state = 0;     // the assembly's tile structures belong to the old mesh
     c->halo.reset();
 
     // column-local numbering: owned nodes in unique-map order, then ghosts sorted by global id
@@ -724,6 +725,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "schwarz_big") c->sw_big = (int)value;
     else if (k == "schwarz_big_target") c->sw_big_target = (int)value;
     else if (k == "asm_kind") c->asm_kind = (int)value;
+    else if (k == "asm_tiles") c->asm_tiles = (int)value;
     else if (k == "asm_u") c->asm_u = (int)value;
     else if (k == "asm_dbg") c->asm_dbg = (int)value;
     else if (k == "apply_kind") c->apply_kind = (int)value;

@@ -17,6 +17,9 @@
 // workgroup.
 #include "fedd_internal.hpp"
 #include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <thread>
 
 namespace fedd {
 namespace {
@@ -811,6 +814,492 @@ int launch_slots(fedd_ctx* c, const AsmArgs& a, int ntab, int64_t n_rows, int ro
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Element-major tiles (asm_kind 4; P1 simplices, Laplace / vector Laplace / linear elasticity).
+// FE::assemblyLaplace / assemblyLinElasXDim loop over ELEMENTS (FE_def.hpp:637-665, 2894-3031); the pair kernels above turn
+// that inside out (one lane per (row, element) pair re-derives the element's geometry, ~4x per element, through a chain of
+// three dependent gathers).  Here a workgroup owns a TILE: a compact cluster of ~27 nodes (a cell of a coordinate lattice) and
+// every element that touches it.
+//   phase 0: the coordinates of the tile's nodes and of their neighbours (the tile's "extended" node list) -> LDS
+//            (independent loads: no chain); the tile's gather lists -> LDS;
+//   phase 1: one lane per DISTINCT element of the tile: vertices by their extended-local ids (one 4-byte record), affine
+//            map, transformed gradients; Laplace parks the 4 x 4 element matrix, elasticity the gradients and |det B|, in LDS.
+//            Every element is evaluated once per tile it touches (~2.4x overall for 3^3-node tiles of the Kuhn cube);
+//   phase 2: one lane per (row, CSR slot): adds the contributions of its GATHER LIST -- (element of the tile, local row,
+//            local column) triples in the order of the node's sorted adjacency, i.e. the summation order of the pair
+//            kernels -- and writes the slot.  No search, no sweep over the row's other contributions, no atomics:
+//            bitwise reproducible.
+// The tile structures (node lists, extended lists, element records, gather lists) depend on the mesh only, like the node ->
+// element adjacency: they are built once per mesh, on the host from the adjacency the device built (build_tiles below,
+// threads over tiles), at the first assembly that uses them.  Meshes whose tiles do not fit the limits (more than 255
+// extended nodes or 448 elements after splitting), P2 elements and the other forms stay on the pair kernels.
+// ---------------------------------------------------------------------------------------------
+constexpr int TL_RMAX = 64;       // nodes of a tile
+constexpr int TL_ELMAX = 448;     // distinct elements of a tile
+constexpr int TL_EXTMAX = 255;    // extended nodes (8-bit local ids)
+
+// Everything a tile needs lies in ONE contiguous blob of 32-bit words (a single streaming read per tile, no pointer chasing):
+//   ext[NE]   extended node list: the tile's R nodes first (ascending), then the other vertices of its elements
+//   nb[R]     node-level row start of every tile node (the pattern is a function of the mesh: symbolic.hip lays the dof rows
+//             out in closed form from it, k_expand_pattern)
+//   el[EL]    element records: NEN extended-local ids, one byte each
+//   gp[R+1]   start of every node's gather entries within the tile's list
+//   sp[R+1]   start of every node's slot offsets within the tile's slot array
+//   gslot     16-bit: per node nslot + 1 offsets into its entries (padded to a word)
+//   glist     16-bit: gather entries, element-of-tile << 4 | local row << 2 | local column (padded to a word)
+struct TileHdr {
+    uint32_t off;          // first word of the blob
+    uint16_t R, NE, EL, NS;    // nodes, extended nodes, elements, 16-bit slot offsets
+    uint16_t GN, MAXS;         // gather entries, most slots of a node
+};
+
+constexpr int TL_BLOBMAX = 4096;  // words of the largest blob this path takes (the next tile's blob waits in registers: BLOBMAX / BS per lane)
+
+template <int DIM, int FORM, int BS>
+__global__ __launch_bounds__(BS) void k_assemble_tiles(AsmArgs a, const TileHdr* __restrict__ hdr, const uint32_t* __restrict__ blob,
+                                                        int32_t ntile, int tiles_per_wg, int block_mode, int lds_el, int lds_blob, int dbg) {
+    constexpr int NEN = DIM + 1, TL_PFW = (TL_BLOBMAX + BS - 1) / BS;
+    constexpr int PARK = FORM == F_LAPLACE ? NEN * NEN : NEN * DIM + 1;     // element matrix | transformed gradients and |det B|
+    extern __shared__ double sm[];
+    const int ntab = a.nq * (1 + NEN + NEN * DIM + DIM + 1);
+    double* s_w = sm;
+    double* s_dphi = s_w + a.nq + a.nq * NEN;
+    double* park = sm + ntab + (ntab & 1);                      // [lds_el][PARK]
+    uint32_t* sb = reinterpret_cast<uint32_t*>(park + (size_t)lds_el * PARK);    // [lds_blob] the tile's blob (8-byte aligned)
+    int32_t* pre = reinterpret_cast<int32_t*>(sb + lds_blob);   // [TL_RMAX + 1] prefix of the nodes' slot counts
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ntab; i += BS) sm[i] = a.tab[i];
+    // park index of value c of element e: Laplace (16 values: a 128-byte element stride would put all lanes of a store on one
+    // bank) value-major, elasticity (13 values, odd stride) element-major
+    auto pix = [&](int e, int cidx) { return FORM == F_LAPLACE ? cidx * lds_el + e : e * PARK + cidx; };
+    // A workgroup walks a contiguous run of tiles; the NEXT tile's blob is requested (into registers) before the current one is
+    // worked on, its header one tile earlier still: nothing in the loop waits for a chain of dependent global loads.
+    const int32_t t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntile, t_begin + tiles_per_wg);
+    if (t_begin >= t_end) return;
+    TileHdr h = hdr[t_begin];
+    TileHdr h_next = t_begin + 1 < t_end ? hdr[t_begin + 1] : h;
+    auto blob_words = [&](const TileHdr& q) {
+        return 2 * DIM * (int)q.NE + (int)q.NE + (int)q.R + (int)q.EL + 2 * ((int)q.R + 1) + (((int)q.NS + 1) >> 1) + (int)((q.GN + 1) >> 1);
+    };
+    uint32_t pf[TL_PFW];
+    {
+        const int nw = blob_words(h);
+#pragma unroll
+        for (int u = 0; u < TL_PFW; ++u) pf[u] = tid + BS * u < nw ? blob[(size_t)h.off + tid + BS * u] : 0u;
+    }
+    const int dofs = a.dofs;
+    const bool full = block_mode == FEDD_BLOCK_FULL;
+    const int ncomp = dofs == 1 ? 1 : (full ? dofs * dofs : dofs);
+    const double w0 = a.tab[0];
+    for (int32_t tile = t_begin; tile < t_end; ++tile) {
+        const int R = h.R, NE = h.NE, EL = h.EL;
+        __syncthreads();        // the previous tile is done with sb / park / pre
+#pragma unroll
+        for (int u = 0; u < TL_PFW; ++u)
+            if (tid + BS * u < lds_blob) sb[tid + BS * u] = pf[u];
+        // request the next tile's blob, and the header of the one after it
+        const bool more = tile + 1 < t_end;
+        const TileHdr hn = h_next;
+        if (more) {
+            const int nw = blob_words(hn);
+#pragma unroll
+            for (int u = 0; u < TL_PFW; ++u) pf[u] = tid + BS * u < nw ? blob[(size_t)hn.off + tid + BS * u] : 0u;
+            if (tile + 2 < t_end) h_next = hdr[tile + 2];
+        }
+        const double* xs = reinterpret_cast<const double*>(sb);                  // [NE][DIM] coordinates of the extended nodes
+        const int32_t* nbv = reinterpret_cast<const int32_t*>(sb) + 2 * DIM * NE + NE;
+        const uint32_t* el = sb + 2 * DIM * NE + NE + R;
+        const uint32_t* gp = el + EL;
+        const uint32_t* sp = gp + R + 1;
+        const uint16_t* gslot = reinterpret_cast<const uint16_t*>(sp + R + 1);
+        const uint16_t* glist = gslot + 2 * ((h.NS + 1) >> 1);
+        __syncthreads();
+        // slots before node p: sp[p] counts nslot + 1 offsets per node, so pre[p] = sp[p] - p (no prefix sum in the kernel)
+        if (tid <= R) pre[tid] = (int)sp[tid] - tid;
+        // ---- phase 1: the elements of the tile, once each ----
+        for (int e = tid; e < ((dbg & 1) ? 0 : EL); e += BS) {
+            const uint32_t rec = el[e];
+            double X[NEN][DIM];
+#pragma unroll
+            for (int v = 0; v < NEN; ++v) {
+                const int li = (rec >> (8 * v)) & 255;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) X[v][d] = xs[li * DIM + d];
+            }
+            double Binv[DIM][DIM];
+            const double absdet = fabs(affine<DIM>(X, Binv));
+            double G[NEN][DIM];
+#pragma unroll
+            for (int j = 0; j < NEN; ++j) grad_t<DIM, NEN>(s_dphi, 0, j, Binv, G[j]);
+            // parked value-major / element-minor: consecutive lanes (elements) write consecutive words (an element-major park
+            // with its 128-byte stride put all 64 lanes of a store on one bank: phase 1 took 3.7 instead of 0.7 ms at cfg 3)
+            double* pk = park;
+            if constexpr (FORM == F_LAPLACE) {
+                // row i of the element matrix as compute_pair forms it (FE_def.hpp:637-656): wg = w g_i, v_j = sum_d wg_d g_jd
+#pragma unroll
+                for (int i = 0; i < NEN; ++i) {
+                    double wg[DIM];
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) wg[d] = w0 * G[i][d];
+#pragma unroll
+                    for (int j = 0; j < NEN; ++j) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) v += wg[d] * G[j][d];
+                        pk[pix(e, i * NEN + j)] = v * absdet;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NEN; ++j)
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) pk[pix(e, j * DIM + d)] = G[j][d];
+                pk[pix(e, NEN * DIM)] = absdet;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: one lane per (node, slot[, row component, column component]) ----
+        // item -> (node, slot): 16 slot places per node where no node of the tile has more (the structured grids: 15), else
+        // through the prefix of the slot counts
+        const bool direct = h.MAXS <= 16;
+        const int nitem = (direct ? R * 16 : pre[R]) * ncomp;
+        for (int item = tid; item < nitem; item += BS) {
+            const int q = item / ncomp, ab = item - q * ncomp;
+            int p, sl;
+            if (direct) {
+                p = q >> 4;
+                sl = q & 15;
+                if (sl >= pre[p + 1] - pre[p]) continue;
+            } else {
+                int lo = 0, hi = R - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (pre[mid] <= q) lo = mid;
+                    else hi = mid - 1;
+                }
+                p = lo;
+                sl = q - pre[p];
+            }
+            const int nslot = pre[p + 1] - pre[p];
+            const int ca = ncomp == 1 ? 0 : (full ? ab / dofs : ab);        // row component
+            const int cb = ncomp == 1 ? 0 : (full ? ab - ca * dofs : ab);   // column component
+            const uint32_t b = gp[p] + gslot[sp[p] + sl], eend = (dbg & 2) ? b : gp[p] + gslot[sp[p] + sl + 1];
+            double acc = 0.0;
+            // eight gather entries at a time: their ids, then their values, as independent LDS reads; added in list order
+            for (uint32_t k = b; k < eend; k += 8) {
+                uint32_t en[8];
+                double val[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) en[u] = k + u < eend ? glist[k + u] : 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t e8 = en[u] == 0xffffffffu ? 0u : en[u];
+                    const int eloc = e8 >> 4, li = (e8 >> 2) & 3, j = e8 & 3;
+                    const double* pk = park;
+                    if constexpr (FORM == F_LAPLACE) {
+                        val[u] = pk[pix(eloc, li * NEN + j)];
+                    } else {
+                        // 2 mu eps_i:eps_j + lam tr(eps_i) tr(eps_j), compute_pair's expression (FE_def.hpp:2894-3031; :4931-4944)
+                        const double lam = a.p0, mu = a.p1;
+                        double dot = 0.0;
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) dot += pk[pix(eloc, li * DIM + d)] * pk[pix(eloc, j * DIM + d)];
+                        const double gia = pk[pix(eloc, li * DIM + ca)], gja = pk[pix(eloc, j * DIM + ca)];
+                        const double gib = pk[pix(eloc, li * DIM + cb)], gjb = pk[pix(eloc, j * DIM + cb)];
+                        const double vb = w0 * (mu * ((cb == ca ? dot : 0.0) + gib * gja) + lam * gia * gjb);
+                        val[u] = pk[pix(eloc, NEN * DIM)] * vb;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += en[u] == 0xffffffffu ? 0.0 : val[u];
+            }
+            // the row's place in the CSR arrays, closed form from the node-level row start (symbolic.hip k_expand_pattern)
+            const int32_t nb = nbv[p];
+            const int32_t start = dofs == 1 ? nb : (full ? nb * dofs * dofs + ca * nslot * dofs : nb * dofs + ca * nslot);
+            a.val[start + (full ? sl * dofs + cb : sl)] = acc;
+        }
+        h = hn;
+    }
+}
+
+// the tile structures of the current mesh (host; threads over tiles).  c->tl_state = -1 when the mesh does not fit.
+static int build_tiles(fedd_ctx* c) {
+    const int dim = c->dim, nen = c->nen;
+    const int64_t nn = c->n_own + c->n_rowg;          // nodes with rows
+    c->tl_state = -1;
+    if (nen != dim + 1 || nn <= 0 || c->n_elem <= 0) return 0;
+    std::vector<int32_t> conn((size_t)c->n_elem * nen), n2e_ptr((size_t)nn + 1);
+    std::vector<double> xyz((size_t)c->n_node * dim);
+    FEDD_HIP(hipMemcpyAsync(conn.data(), c->d_conn.p, conn.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipMemcpyAsync(n2e_ptr.data(), c->d_n2e_ptr.p, n2e_ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipMemcpyAsync(xyz.data(), c->d_xyz.p, xyz.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    std::vector<int32_t> n2e((size_t)n2e_ptr[(size_t)nn]);
+    FEDD_HIP(hipMemcpyAsync(n2e.data(), c->d_n2e.p, n2e.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    // ---- nodes -> cells of a coordinate lattice with ~27 nodes each ----
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = 0; i < nn; ++i)
+        for (int d = 0; d < dim; ++d) {
+            lo[d] = std::min(lo[d], xyz[(size_t)i * dim + d]);
+            hi[d] = std::max(hi[d], xyz[(size_t)i * dim + d]);
+        }
+    double V = 1.0;
+    for (int d = 0; d < dim; ++d) V *= std::max(hi[d] - lo[d], 1e-300);
+    const double target = dim == 3 ? 27.0 : 25.0;
+    const double w = std::pow(V * target / (double)nn, 1.0 / dim);
+    int g[3] = {1, 1, 1};
+    for (int d = 0; d < dim; ++d) g[d] = std::max(1, (int)std::floor((hi[d] - lo[d]) / w + 0.5));
+    const int64_t ncell = (int64_t)g[0] * g[1] * g[2];
+    if (ncell > ((int64_t)1 << 31) - 2) return 0;
+    std::vector<int32_t> cell((size_t)nn), cnt((size_t)ncell + 1, 0);
+    for (int64_t i = 0; i < nn; ++i) {
+        int64_t id = 0, mul = 1;
+        for (int d = 0; d < dim; ++d) {
+            const double L = hi[d] - lo[d];
+            int k = L > 0 ? (int)std::floor((xyz[(size_t)i * dim + d] - lo[d]) / L * g[d]) : 0;
+            k = std::min(g[d] - 1, std::max(0, k));
+            id += mul * k;
+            mul *= g[d];
+        }
+        cell[(size_t)i] = (int32_t)id;
+        ++cnt[(size_t)id + 1];
+    }
+    for (int64_t k = 0; k < ncell; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+    std::vector<int32_t> order((size_t)nn);
+    {
+        std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1);
+        for (int64_t i = 0; i < nn; ++i) order[(size_t)pos[(size_t)cell[(size_t)i]]++] = (int32_t)i;   // ascending within a cell
+    }
+    // node-level row starts: the pattern's row of a node holds its distinct neighbours (itself included)
+    std::vector<int32_t> nslot_of((size_t)nn), nb_of((size_t)nn + 1, 0);
+    const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto parallel = [&](int64_t n, auto&& body) {
+        std::vector<std::thread> th;
+        const int64_t chunk = (n + nthr - 1) / nthr;
+        for (unsigned q = 0; q < nthr; ++q) {
+            const int64_t t0 = (int64_t)q * chunk, t1 = std::min(n, t0 + chunk);
+            if (t0 < t1) th.emplace_back(body, t0, t1);
+        }
+        for (auto& x : th) x.join();
+    };
+    parallel(nn, [&](int64_t i0, int64_t i1) {
+        std::vector<int32_t> nbr;
+        for (int64_t i = i0; i < i1; ++i) {
+            nbr.clear();
+            for (int32_t q = n2e_ptr[(size_t)i]; q < n2e_ptr[(size_t)i + 1]; ++q) {
+                const int32_t el = n2e[(size_t)q] / nen;
+                for (int j = 0; j < nen; ++j) nbr.push_back(conn[(size_t)el * nen + j]);
+            }
+            std::sort(nbr.begin(), nbr.end());
+            nslot_of[(size_t)i] = (int32_t)(std::unique(nbr.begin(), nbr.end()) - nbr.begin());
+        }
+    });
+    for (int64_t i = 0; i < nn; ++i) nb_of[(size_t)i + 1] = nb_of[(size_t)i] + nslot_of[(size_t)i];
+    // ---- tiles: non-empty cells, cut into pieces that respect the limits ----
+    struct Piece { int32_t b, e; };
+    std::vector<Piece> pieces;
+    auto distinct = [&](int32_t b, int32_t e, std::vector<int32_t>& els, std::vector<int32_t>& ext) {
+        els.clear();
+        for (int32_t k = b; k < e; ++k) {
+            const int32_t nd = order[(size_t)k];
+            for (int32_t p = n2e_ptr[(size_t)nd]; p < n2e_ptr[(size_t)nd + 1]; ++p) els.push_back(n2e[(size_t)p] / nen);
+        }
+        std::sort(els.begin(), els.end());
+        els.erase(std::unique(els.begin(), els.end()), els.end());
+        ext.clear();
+        for (int32_t el : els)
+            for (int j = 0; j < nen; ++j) ext.push_back(conn[(size_t)el * nen + j]);
+        std::sort(ext.begin(), ext.end());
+        ext.erase(std::unique(ext.begin(), ext.end()), ext.end());
+    };
+    {
+        // (cells in parallel; the pieces of a cell stay together and in order)
+        std::vector<std::vector<Piece>> per_thread(nthr);
+        std::atomic<int> bad{0};
+        std::vector<int64_t> bounds(nthr + 1, 0);
+        for (unsigned q = 0; q <= nthr; ++q) bounds[q] = std::min<int64_t>(ncell, (int64_t)q * ((ncell + nthr - 1) / nthr));
+        std::vector<std::thread> th;
+        for (unsigned q = 0; q < nthr; ++q)
+            th.emplace_back([&, q]() {
+                std::vector<int32_t> els, ext;
+                std::vector<Piece> stack;
+                for (int64_t k = bounds[q]; k < bounds[q + 1]; ++k) {
+                    if (cnt[(size_t)k + 1] == cnt[(size_t)k]) continue;
+                    stack.push_back({cnt[(size_t)k], cnt[(size_t)k + 1]});
+                    while (!stack.empty()) {
+                        const Piece pc = stack.back();
+                        stack.pop_back();
+                        bool ok = pc.e - pc.b <= TL_RMAX;
+                        if (ok) {
+                            distinct(pc.b, pc.e, els, ext);
+                            ok = (int)els.size() <= TL_ELMAX && (int)ext.size() <= TL_EXTMAX;
+                        }
+                        if (ok) per_thread[q].push_back(pc);
+                        else if (pc.e - pc.b == 1) { bad = 1; }      // a single node that does not fit: pair kernels
+                        else {
+                            const int32_t mid = pc.b + (pc.e - pc.b) / 2;
+                            stack.push_back({mid, pc.e});
+                            stack.push_back({pc.b, mid});
+                        }
+                    }
+                }
+            });
+        for (auto& x : th) x.join();
+        if (bad) return 0;
+        for (auto& v : per_thread) pieces.insert(pieces.end(), v.begin(), v.end());
+    }
+    const int64_t ntile = (int64_t)pieces.size();
+    // ---- per tile: sizes, then the blobs (two parallel passes over the tiles) ----
+    std::vector<TileHdr> hdr((size_t)ntile);
+    std::vector<uint64_t> woff((size_t)ntile + 1, 0);
+    std::vector<uint32_t> blob;
+    std::atomic<int> failed{0};
+    auto run_pass = [&](bool fill) {
+        parallel(ntile, [&](int64_t t0, int64_t t1) {
+            std::vector<int32_t> els, ext, extl, nbr;
+            std::vector<uint16_t> ent, slots;
+            std::vector<uint32_t> scount, gpv, spv;
+            for (int64_t tI = t0; tI < t1; ++tI) {
+                const Piece pc = pieces[(size_t)tI];
+                const int R = pc.e - pc.b;
+                distinct(pc.b, pc.e, els, ext);
+                extl.assign(order.begin() + pc.b, order.begin() + pc.e);
+                for (int32_t nd : ext)
+                    if (!std::binary_search(order.begin() + pc.b, order.begin() + pc.e, nd)) extl.push_back(nd);
+                auto ext_local = [&](int32_t nd) -> uint32_t {
+                    auto it = std::lower_bound(order.begin() + pc.b, order.begin() + pc.e, nd);
+                    if (it != order.begin() + pc.e && *it == nd) return (uint32_t)(it - (order.begin() + pc.b));
+                    return (uint32_t)(std::lower_bound(extl.begin() + R, extl.end(), nd) - extl.begin());
+                };
+                const int NE = (int)extl.size(), EL = (int)els.size();
+                uint32_t NS = 0, GN = 0, MAXS = 0;
+                for (int p = 0; p < R; ++p) {
+                    const int32_t nd = order[(size_t)pc.b + p];
+                    MAXS = std::max<uint32_t>(MAXS, (uint32_t)nslot_of[(size_t)nd]);
+                    NS += (uint32_t)nslot_of[(size_t)nd] + 1;
+                    GN += (uint32_t)(n2e_ptr[(size_t)nd + 1] - n2e_ptr[(size_t)nd]) * nen;
+                }
+                if (NS > 65535 || GN > 65535 || EL > 4095) failed = 1;     // 16-bit offsets, 12-bit element-of-tile ids
+                const uint64_t nw_raw = (uint64_t)2 * dim * NE + NE + R + EL + 2 * (uint64_t)(R + 1) + ((NS + 1) >> 1) + ((GN + 1) >> 1);
+                const uint64_t nw = (nw_raw + 1) & ~(uint64_t)1;     // blobs start 8-byte aligned (the coordinates lead)
+                if (nw_raw > TL_BLOBMAX) failed = 1;
+                if (!fill) {
+                    hdr[(size_t)tI] = TileHdr{0, (uint16_t)R, (uint16_t)NE, (uint16_t)EL, (uint16_t)NS, (uint16_t)GN, (uint16_t)MAXS};
+                    woff[(size_t)tI + 1] = nw;
+                    continue;
+                }
+                if (failed) return;
+                uint32_t* wb0 = blob.data() + woff[(size_t)tI];
+                double* cw = reinterpret_cast<double*>(wb0);
+                for (int i = 0; i < NE; ++i)
+                    for (int d = 0; d < dim; ++d) cw[(size_t)i * dim + d] = xyz[(size_t)extl[(size_t)i] * dim + d];
+                uint32_t* wb = wb0 + 2 * dim * NE;
+                for (int i = 0; i < NE; ++i) wb[i] = (uint32_t)extl[(size_t)i];
+                for (int p = 0; p < R; ++p) wb[NE + p] = (uint32_t)nb_of[(size_t)order[(size_t)pc.b + p]];
+                uint32_t* elw = wb + NE + R;
+                for (int q = 0; q < EL; ++q) {
+                    uint32_t rec = 0;
+                    for (int j = 0; j < nen; ++j) rec |= ext_local(conn[(size_t)els[(size_t)q] * nen + j]) << (8 * j);
+                    elw[q] = rec;
+                }
+                uint32_t* gpw = elw + EL;
+                uint32_t* spw = gpw + R + 1;
+                uint16_t* gsw = reinterpret_cast<uint16_t*>(spw + R + 1);
+                uint16_t* glw = gsw + 2 * ((NS + 1) >> 1);
+                uint32_t gpos = 0, spos = 0;
+                for (int p = 0; p < R; ++p) {
+                    const int32_t nd = order[(size_t)pc.b + p];
+                    const int32_t pb = n2e_ptr[(size_t)nd], pe = n2e_ptr[(size_t)nd + 1];
+                    nbr.clear();
+                    for (int32_t q = pb; q < pe; ++q) {
+                        const int32_t el = n2e[(size_t)q] / nen;
+                        for (int j = 0; j < nen; ++j) nbr.push_back(conn[(size_t)el * nen + j]);
+                    }
+                    std::sort(nbr.begin(), nbr.end());
+                    nbr.erase(std::unique(nbr.begin(), nbr.end()), nbr.end());
+                    const int nslot = (int)nbr.size();
+                    scount.assign((size_t)nslot + 1, 0);
+                    for (int32_t q = pb; q < pe; ++q) {
+                        const int32_t el = n2e[(size_t)q] / nen;
+                        for (int j = 0; j < nen; ++j)
+                            ++scount[(size_t)(std::lower_bound(nbr.begin(), nbr.end(), conn[(size_t)el * nen + j]) - nbr.begin()) + 1];
+                    }
+                    for (int sI = 0; sI < nslot; ++sI) scount[(size_t)sI + 1] += scount[(size_t)sI];
+                    gpw[p] = gpos;
+                    spw[p] = spos;
+                    for (int sI = 0; sI <= nslot; ++sI) gsw[spos + sI] = (uint16_t)scount[(size_t)sI];
+                    for (int32_t q = pb; q < pe; ++q) {       // adjacency order, then local column order: the pair kernels' order
+                        const int32_t idx = n2e[(size_t)q], el = idx / nen, li = idx - el * nen;
+                        const uint32_t eloc = (uint32_t)(std::lower_bound(els.begin(), els.end(), el) - els.begin());
+                        for (int j = 0; j < nen; ++j) {
+                            const size_t sI = (size_t)(std::lower_bound(nbr.begin(), nbr.end(), conn[(size_t)el * nen + j]) - nbr.begin());
+                            glw[gpos + scount[sI]++] = (uint16_t)((eloc << 4) | ((uint32_t)li << 2) | (uint32_t)j);
+                        }
+                    }
+                    gpos += (uint32_t)(pe - pb) * nen;
+                    spos += (uint32_t)nslot + 1;
+                }
+                gpw[R] = gpos;
+                spw[R] = spos;
+            }
+        });
+    };
+    run_pass(false);
+    if (failed) return 0;
+    int max_el = 0, max_ext = 0;
+    uint64_t max_blob = 0;
+    for (int64_t tI = 0; tI < ntile; ++tI) {
+        max_el = std::max<int>(max_el, hdr[(size_t)tI].EL);
+        max_ext = std::max<int>(max_ext, hdr[(size_t)tI].NE);
+        max_blob = std::max(max_blob, woff[(size_t)tI + 1]);
+        woff[(size_t)tI + 1] += woff[(size_t)tI];
+    }
+    if (woff[(size_t)ntile] >= ((uint64_t)1 << 32)) return 0;      // 32-bit word offsets
+    for (int64_t tI = 0; tI < ntile; ++tI) hdr[(size_t)tI].off = (uint32_t)woff[(size_t)tI];
+    blob.assign((size_t)woff[(size_t)ntile] + 1, 0u);
+    run_pass(true);
+    FEDD_TRY(c->tl_hdr.ensure(std::max<size_t>(1, (size_t)ntile * sizeof(TileHdr) / sizeof(uint32_t))));
+    FEDD_TRY(c->tl_blob.ensure(blob.size()));
+    FEDD_HIP(hipMemcpyAsync(c->tl_hdr.p, hdr.data(), (size_t)ntile * sizeof(TileHdr), hipMemcpyHostToDevice, c->stream));
+    FEDD_HIP(hipMemcpyAsync(c->tl_blob.p, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    c->tl_ntile = ntile;
+    c->tl_max_el = max_el;
+    c->tl_max_ext = max_ext;
+    c->tl_max_blob = (int)max_blob;
+    c->tl_state = 1;
+    return 0;
+}
+
+template <int DIM, int FORM>
+int launch_tiles(fedd_ctx* c, const AsmArgs& a, int ntab) {
+    if (c->tl_state == 0) FEDD_TRY(build_tiles(c));
+    if (c->tl_state != 1) return -1;
+    constexpr int NEN = DIM + 1, PARK = FORM == F_LAPLACE ? NEN * NEN : NEN * DIM + 1;
+    static_assert(sizeof(TileHdr) == 16, "tile header");
+    const int lds_el = c->tl_max_el, lds_blob = (c->tl_max_blob + 1) & ~1;
+    const size_t lds = ((size_t)ntab + 1 + (size_t)lds_el * PARK) * sizeof(double) + ((size_t)lds_blob + TL_RMAX + 2) * sizeof(uint32_t);
+    if (lds > 96 * 1024 || lds_blob > TL_BLOBMAX) return -1;
+    // Laplace: 448 lanes, the 324 elements and the 405 slots of a 3^3-node tile of the Kuhn cube each take one pass (4.27 -> 4.12 ms
+    // at cfg 3); elasticity (9 items per slot: several passes anyway) is faster with 256 (94^3 cells: 2.86 against 3.34 ms)
+    constexpr int BS = FORM == F_LAPLACE ? 448 : 256;
+    auto kern = k_assemble_tiles<DIM, FORM, BS>;
+    if (lds > 64 * 1024) FEDD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // persistent workgroups: as many as fit the GPU at once (256 CUs x what the LDS allows), each a contiguous run of tiles
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+    const int64_t nwg = std::min<int64_t>(c->tl_ntile, (int64_t)256 * per_cu * (c->asm_u > 1 ? c->asm_u : 1));
+    const int tiles_per_wg = (int)((c->tl_ntile + nwg - 1) / nwg);
+    const int64_t grid = (c->tl_ntile + tiles_per_wg - 1) / tiles_per_wg;
+    ScopedTimer tm(c, FEDD_T_ASSEMBLE);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BS), lds, c->stream, a, (const TileHdr*)c->tl_hdr.p,
+                       (const uint32_t*)c->tl_blob.p, (int32_t)c->tl_ntile, tiles_per_wg, c->block_mode, lds_el, lds_blob, c->asm_dbg);
+    tm.stop();
+    if (c->asm_dbg & 64) fprintf(stderr, "[tiles] %lld tiles, max elements %d, blob words %d, LDS %zu bytes, %lld workgroups x %d tiles\n", (long long)c->tl_ntile, lds_el, lds_blob, lds, (long long)grid, tiles_per_wg);
+    FEDD_HIP(hipGetLastError());
+    return 0;
+}
+
 // asm_kind 0: slot-addressed kernel, falling back to the pair-parallel sweep where it does not fit; 2: the sweep
 template <int DIM, int NEN, int FORM>
 int launch_matrix(fedd_ctx* c, const AsmArgs& a, int ntab, int64_t n_rows, int rowcap) {
@@ -827,6 +1316,13 @@ int launch_matrix(fedd_ctx* c, const AsmArgs& a, int ntab, int64_t n_rows, int r
 
 template <int DIM, int NEN>
 int launch_assemble(fedd_ctx* c, int kform, const AsmArgs& a, int ntab) {
+    if constexpr (NEN == DIM + 1) {
+        // element-major tiles for the P1 forms they cover (asm_kind 4; 0: by default for those forms), else the pair kernels
+        if ((c->asm_kind == 4 || (c->asm_kind == 0 && c->asm_tiles)) && a.nq == 1 && (kform == F_LAPLACE || kform == F_LINELAS)) {
+            const int rc = kform == F_LAPLACE ? launch_tiles<DIM, F_LAPLACE>(c, a, ntab) : launch_tiles<DIM, F_LINELAS>(c, a, ntab);
+            if (rc >= 0) return rc;
+        }
+    }
     if (c->asm_kind != 1) {
         if (kform == F_LAPLACE) return launch_matrix<DIM, NEN, F_LAPLACE>(c, a, ntab, c->n_rows_ext, c->max_row_nnz);
         if (kform == F_MASS) return launch_matrix<DIM, NEN, F_MASS>(c, a, ntab, c->n_rows_ext, c->max_row_nnz);

@@ -180,6 +180,11 @@ struct fedd_ctx {
     int asm_dbg = 0;                            // ablation switches of the assembly kernel (development)
     int asm_u = 1;                              // slot-addressed assembly: pairs per lane with their loads in flight together (P1)
     int asm_kind = 0;                           // 0 = slot-addressed pair-parallel assembly, 2 = pair-parallel with slot sweep, 1 = lane-per-row gather
+    // element-major tile structures of the current mesh (assemble.hip build_tiles): 0 = not built, 1 = ready, -1 = mesh does not fit
+    int tl_state = 0, asm_tiles = 1;            // option "asm_tiles": the P1 Laplace / elasticity forms take the element-major tile kernel (0: pair kernels)
+    int64_t tl_ntile = 0;
+    int tl_max_el = 0, tl_max_ext = 0, tl_max_blob = 0;
+    fedd::DevBuf<uint32_t> tl_hdr, tl_blob;     // per-tile headers (16 bytes each) and blobs (assemble.hip TileHdr)
     fedd::DevBuf<int32_t> d_pat_stash;          // pattern build: merged node lists of the count pass, [k][node]
     fedd::DevBuf<int32_t> d_spmv_rows;          // CSR-stream: first row of every nnz window
     bool spmv_rows_ready = false;

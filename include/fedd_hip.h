@@ -315,7 +315,9 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
 int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_blocks);
 
 /* tuning knobs (A/B tests), 0 is the default of each: "spmv_kind" 0 = CSR-window (CSR-stream when a row has more than 256 entries), 1 = row-per-lane-group, 2 = CSR-stream;
- * "asm_kind" 0 = pair-parallel assembly (slot-addressed accumulation for the block forms -- elasticity, B / B^T --, slot sweep for
+ * "asm_tiles" 1 (default) = the P1 Laplace / vector-Laplace / elasticity forms are assembled element-major over tiles of ~27 nodes
+ * (every element of a tile evaluated once, contributions gathered per CSR slot from lists built once per mesh), 0 = the pair
+ * kernels; "asm_kind" 4 = tiles whatever "asm_tiles" says, 0 = pair-parallel assembly (slot-addressed accumulation for the block forms -- elasticity, B / B^T --, slot sweep for
  * the scalar forms), 1 = lane-per-row gather, 2 = slot sweep always, 3 = slot-addressed always; "asm_u" pairs per lane whose
  * loads are in flight together in the slot-addressed kernel (P1; default 1); "asm_dbg" ablation switches (development); "apply_kind" 0 = restricted Schwarz
  * apply by the setup's outcome (batched matrix-core kernel when at most a quarter of at least 4096 subdomains have distinct
