@@ -465,6 +465,12 @@ def main():
             "assemble": 4.0 * m["conn"].size + 8.0 * 3 * m["xyz"].shape[0] + 12.0 * nnz + 4.0 * (nr + 1),
         }
         kern = {}
+        # the Newton block basis of the s-step solver rides in the SpMV's store (y = A z - theta v): those launches read one
+        # more vector.  All but the applications of the monomial blocks that come before the shifts exist (2 x 8) carry it.
+        gk0 = tm.get("_gmres", {})
+        if gk0.get("kind") == 2 and gk0.get("s", 0) > 8 and tm["spmv"][1]:
+            per_step = tm["spmv"][1] / a.steps
+            models["spmv"] += 8.0 * nr * max(0.0, per_step - 16 - 4) / per_step
         for k, b in models.items():
             ms, nl = tm[k]
             if nl:

@@ -881,31 +881,40 @@ __device__ __forceinline__ double2 ldp(const double* __restrict__ p, const RowPa
 
 constexpr int SS_LDS_GROUPS = 32;   // column groups whose wave totals are parked in LDS between two workgroup barriers
 
-// partial[(col * S + j) * nblk + blk] = sum over the workgroup's 1024 rows of V_col . W_j, col < k + sa
+// partial[(col * S + j) * nblk + blk] = sum over the workgroup's rows of V_col . W_j, col < k + sa
 // (W_j = V_{k+j}); the W tile stays in registers across the column groups, every basis column is read once.
-// The four wave totals of a column group are parked in LDS and added (fixed order) once per SS_LDS_GROUPS groups:
+// The wave totals of a column group are parked in LDS and added (fixed order) once per SS_LDS_GROUPS groups:
 // no barrier between the loads of consecutive groups.
-template <int S, int NCH, int SS_CG>
+// HV = 2 ("split"): the two halves of the workgroup take the SAME rows and one half of the block's columns each (S / 2 per
+// lane): a basis value is then loaded by two lanes of the workgroup (the second finds it in the L1), but a lane's register
+// tile and reduction are those of the 8-column kernel, which runs at 0.69 of peak where the 16-column tile (232 VGPRs, two
+// FMAs and two exchanges per byte) reaches 0.59.
+template <int S, int NCH, int SS_CG, int HV = 1>
 __global__ __launch_bounds__(256) void k_blockdot(const double* __restrict__ V, int64_t ldv, int64_t n, int k, int sa_req,
                                                   const int32_t* __restrict__ d_sa, double* __restrict__ partial, int nblk) {
-    constexpr int NV = SS_CG * S;
+    constexpr int SW = S / HV;              // block columns per lane
+    constexpr int NV = SS_CG * SW;
+    constexpr int LH = 256 / HV;            // lanes of a half
+    constexpr int WPH = 4 / HV;             // waves of a half
     static_assert(NV == 16 || NV == 32 || NV == 64, "block size");
     __shared__ double sh[SS_LDS_GROUPS][4][NV];
     const int sa = d_sa ? min(*d_sa, sa_req) : sa_req;
     if (sa <= 0) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = tid / LH, th = tid % LH;
     RowPair rp[NCH];
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) rp[ch] = row_pair((int64_t)blockIdx.x * (512 * NCH) + 512 * ch + 2 * tid, n);
-    double2 w[S][NCH];
+    for (int ch = 0; ch < NCH; ++ch)
+        rp[ch] = row_pair((int64_t)blockIdx.x * (2 * LH * NCH) + 2 * LH * ch + 2 * th, n);
+    double2 w[SW][NCH];
 #pragma unroll
-    for (int j = 0; j < S; ++j)
+    for (int j = 0; j < SW; ++j)
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             // (columns past sa: any readable column, zeroed by the select)
-            const double2 t = ldp<false>(V + (int64_t)(k + (j < sa ? j : 0)) * ldv, rp[ch]);
-            w[j][ch].x = j < sa ? t.x : 0.0;
-            w[j][ch].y = j < sa ? t.y : 0.0;
+            const int jj = half * SW + j;
+            const double2 t = ldp<false>(V + (int64_t)(k + (jj < sa ? jj : 0)) * ldv, rp[ch]);
+            w[j][ch].x = jj < sa ? t.x : 0.0;
+            w[j][ch].y = jj < sa ? t.y : 0.0;
         }
     const int ncol = k + sa;
     const int ncg = (ncol + SS_CG - 1) / SS_CG;
@@ -913,11 +922,15 @@ __global__ __launch_bounds__(256) void k_blockdot(const double* __restrict__ V, 
     constexpr int GRP = 64 / NV;
     auto flush = [&](int count) {
         __syncthreads();
-        for (int e = tid; e < count * NV; e += 256) {
-            const int g = e / NV, idx = e % NV;
-            const int col = (first_cg + g * (int)gridDim.y) * SS_CG + idx / S;
-            if (col < ncol)
-                partial[((int64_t)col * S + (idx % S)) * nblk + blockIdx.x] = sh[g][0][idx] + sh[g][1][idx] + sh[g][2][idx] + sh[g][3][idx];
+        for (int e = tid; e < count * NV * HV; e += 256) {
+            const int g = e / (NV * HV), rem = e % (NV * HV), hv = rem / NV, idx = rem % NV;
+            const int col = (first_cg + g * (int)gridDim.y) * SS_CG + idx / SW;
+            if (col < ncol) {
+                double tsum = sh[g][hv * WPH][idx];
+#pragma unroll
+                for (int q = 1; q < WPH; ++q) tsum += sh[g][hv * WPH + q][idx];
+                partial[((int64_t)col * S + hv * SW + (idx % SW)) * nblk + blockIdx.x] = tsum;
+            }
         }
         __syncthreads();
     };
@@ -943,11 +956,11 @@ __global__ __launch_bounds__(256) void k_blockdot(const double* __restrict__ V, 
 #pragma unroll
         for (int cc = 0; cc < SS_CG; ++cc)
 #pragma unroll
-            for (int j = 0; j < S; ++j) {
+            for (int j = 0; j < SW; ++j) {
                 double s = 0.0;
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) s += v[cc][ch].x * w[j][ch].x + v[cc][ch].y * w[j][ch].y;
-                acc[cc * S + j] = s;
+                acc[cc * SW + j] = s;
             }
         // the next group's loads are in flight while this one is reduced
         if (cg + (int)gridDim.y < ncg) load_group(cg + gridDim.y);
@@ -1198,13 +1211,13 @@ __global__ __launch_bounds__(256) void k_ss_pass2(double* __restrict__ Sx, Off o
             double x[S];
 #pragma unroll
             for (int cidx = 0; cidx < S; ++cidx) x[cidx] = 0.0;
-            if (r <= k) {
-                // y = (Hbar_k C)(r, :) over the nonzero part of row r
-                for (int q = r > 0 ? r - 1 : 0; q < k; ++q) {
-                    const double h = Hraw[(int64_t)q * ldh + r];
+            // y = (Hbar_k C)(r, :): the same q for every lane, so that the coefficients C(q, :) are wave-uniform (scalar loads)
+            // and only Hbar(r, q) is a per-lane load (coalesced over r); entries below the sub-diagonal are zero by structure
+            // (with a per-lane loop start every lane fetched its own 15 coefficients per step: 89 us per block at k ~ 60)
+            for (int q = 0; q < k; ++q) {
+                const double h = (r <= k && q + 1 >= r) ? Hraw[(int64_t)q * ldh + r] : 0.0;
 #pragma unroll
-                    for (int cidx = 0; cidx < S - 1; ++cidx) x[cidx] -= h * Sx[o3.Cc + q * S + cidx];
-                }
+                for (int cidx = 0; cidx < S - 1; ++cidx) x[cidx] -= h * Sx[o3.Cc + q * S + cidx];
             }
 #pragma unroll
             for (int cidx = 0; cidx < S - 1; ++cidx) {
@@ -1355,8 +1368,11 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     // block dot kernel: 512 NCH rows per workgroup, CG columns per transpose reduction (option "gmres_dotv": 0 = 2 chunks x ss_cg
     // columns; 1 = 1 chunk x ss_cg; 2 = 1 chunk x 2 ss_cg)
     const int dotv = c->gmres_dotv;
-    const int dot_nch = dotv == 0 ? 2 : 1, dot_cg = dotv == 2 ? std::min(64 / S, 2 * ss_cg(S)) : ss_cg(S);
-    const int nblkd = (int)((n + 512 * dot_nch - 1) / (512 * dot_nch));
+    // ("gmres_dotv" 3: S = 16 as two 8-column halves per workgroup over the same rows -- measured slower, 1.12 against 1.08 ms per
+    // sweep at cfg 3: the second half's loads do not all hit the L1)
+    const bool dot_split = S == 16 && dotv == 3;
+    const int dot_nch = dot_split ? 2 : (dotv == 0 ? 2 : 1), dot_cg = dot_split ? 4 : (dotv == 2 ? std::min(64 / S, 2 * ss_cg(S)) : ss_cg(S));
+    const int nblkd = dot_split ? (int)((n + 511) / 512) : (int)((n + 512 * dot_nch - 1) / (512 * dot_nch));
     {
         // the block kernels read whole 16-byte row pairs and rely on the padding rows [n, ldv) of every column being zero
         // (and on finite data everywhere): a freshly (re)allocated basis, or one last used with another vector length, is cleared
@@ -1527,7 +1543,13 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
                 const dim3 gd(nblkd, std::min(gy_dot, ncg));
                 auto launch_dot = [&](const dim3& g, const int32_t* dsa) {
                     constexpr int CG0 = ss_cg(S), CG2 = (64 / S < 2 * CG0) ? 64 / S : 2 * CG0;
-                    if (dotv == 0)
+                    if constexpr (S == 16) {
+                        if (dot_split) {
+                            hipLaunchKernelGGL((k_blockdot<S, 2, 4, 2>), g, blk, 0, st, (const double*)V, ldv, n, k, sa, dsa, c->d_part.p, nblkd);
+                            return;
+                        }
+                    }
+                    if (dotv == 0 || dotv == 4)
                         hipLaunchKernelGGL((k_blockdot<S, 2, CG0>), g, blk, 0, st, (const double*)V, ldv, n, k, sa, dsa, c->d_part.p, nblkd);
                     else if (dotv == 1)
                         hipLaunchKernelGGL((k_blockdot<S, 1, CG0>), g, blk, 0, st, (const double*)V, ldv, n, k, sa, dsa, c->d_part.p, nblkd);
