@@ -739,6 +739,8 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     } else if (k == "gmres_spec") {
         FEDD_CHECK(value >= 0 && value <= 16, "fedd_set_option: gmres_spec %g", value);
         c->gmres_spec = (int)value;
+    } else if (k == "gmres_tol_blocks") {
+        c->gmres_tol_blocks = (int)value;
     } else if (k == "gmres_dotv") {
         c->gmres_dotv = (int)value;
     } else if (k == "gmres_newton") {

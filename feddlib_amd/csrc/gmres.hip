@@ -1503,7 +1503,8 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     // the recurrence residual of a block basis of condition kappa is good to about eps * kappa; measured on the Laplace cubes
     // (monomial basis): it parts from the true residual near 1e-11 for s = 8 and near 2e-13 for s = 4.  Below those floors a
     // claim fails its check and costs a restart, so tight tolerances take shorter blocks from the start.
-    const int s_tol = rtol >= 1e-9 ? 16 : (rtol >= 1e-11 ? 5 : 3);
+    // (option "gmres_tol_blocks" 0 lifts the cap: runs that are held to an iteration count instead of a tolerance)
+    const int s_tol = !c->gmres_tol_blocks || rtol >= 1e-9 ? 16 : (rtol >= 1e-11 ? 5 : 3);
     const int s_goal = std::max(1, std::min(std::min(c->gmres_s, S), s_tol));
     // Blocks longer than 8 need a better conditioned block basis than the monomial one (its condition grows tenfold every
     // two vectors, 1e7 at s = 8): the Newton basis w_i = (B - theta_i) w_{i-1} with the Ritz values of the first s_goal
@@ -1733,8 +1734,9 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
     if (c->gmres_kind == 2) {
         // block length: "gmres_s" 0 = by the vector length per rank -- 16-vector (Newton-basis) blocks where the sweeps over the
         // basis dominate, 8-vector blocks on short vectors, where the longer blocks' fixed costs (two monomial blocks first,
-        // a 16 x 16 Cholesky per pass, a register-heavier dot kernel) are not paid back.  Every rank must take the same one:
-        // the decision uses the global row count
+        // a 16 x 16 Cholesky per pass, one more vector per SpMV) are not paid back.  Measured: 1.03 M rows / 71 iterations (cfg 2)
+        // 11.8 ms with 8, 12.2 with 16; 1.26 M rows / 145 iterations (one GPU's share of cfg 3) 24.4 against 22.5; 9.9 M rows
+        // 122.5 against 108.0.  Every rank must take the same one: the decision uses the global row count
         if (c->gmres_s == 0) {
             double ng = (double)c->n_rows;
             if (c->nranks > 1) {
@@ -1745,7 +1747,7 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
                 FEDD_HIP(hipMemcpyAsync(&ng, c->d_small.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
                 FEDD_HIP(hipStreamSynchronize(c->stream));
             }
-            c->gmres_s = ng / c->nranks >= 4.0e6 ? 16 : 8;
+            c->gmres_s = ng / c->nranks >= 1.2e6 ? 16 : 8;
             const int rc = gmres_solve(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
             c->gmres_s_used = c->gmres_s;
             c->gmres_s = 0;

@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
     // XCD-contiguous ranges (neighbouring boxes gather overlapping parts of r: one L2)
     const int nwg = gridDim.x, q_ = nwg >> 3, rem_ = nwg & 7, xcd_ = blockIdx.x & 7, within_ = blockIdx.x >> 3;
     const int wg = (xcd_ < rem_ ? xcd_ * (q_ + 1) : rem_ * (q_ + 1) + (xcd_ - rem_) * q_) + within_;
-    const int32_t p_end = min(nsub, (wg + 1) * span);   // span = a multiple of 64
+    const int32_t p_end = min(nsub, (wg + 1) * span);   // span = a multiple of 16
     int32_t p_chunk = wg * span;
     if (p_chunk >= p_end) return;
     // chunk = 64 places: lane = place; record = (subdomain, representative, columns | owned rows << 10 | conforming << 20,
@@ -1636,8 +1636,9 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
             if (count <= 0) return;
             if (shared) {
                 // ranges of whole 64-place chunks (measured on the 214^3 grid, 389017 subdomains: 64: 195 us, 128: 187, 256: 191, 512: 233)
-                int span = c->apply_span > 0 ? c->apply_span : (count >= 256 * 1024 ? 128 : 64);
-                span = std::max(64, (span + 63) / 64 * 64);
+                // (19683 subdomains, the share of one GPU of eight: 64: 40.8 us, 48: 37.0, 32: 34.9, 16: 36.2)
+                int span = c->apply_span > 0 ? c->apply_span : (count >= 256 * 1024 ? 128 : (count >= 48 * 1024 ? 64 : 32));
+                span = std::max(16, (span + 15) / 16 * 16);     // whole 16-place batches
                 const int nwg = (int)((count + span - 1) / span);
 #define APPLY_MFMA(RT, KW)                                                                                                   \
     hipLaunchKernelGGL((k_apply_mfma<RT, KW>), dim3((unsigned)nwg), blk, 0, c->stream, records + p0,                          \

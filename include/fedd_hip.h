@@ -323,7 +323,7 @@ int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_bloc
  * apply by the setup's outcome (batched matrix-core kernel when at most a quarter of at least 4096 subdomains have distinct
  * local matrices, else the flat streaming kernel), 1 = strided, 2 = flat without the compact LDS layout, 4 = matrix-core
  * kernel whenever the inverses are shared (any number of subdomains); "apply_span" places per workgroup of that kernel
- * (multiples of 64; 0 = 64 / 128 by the number of subdomains); "md2_gy" column groups in flight per row block of the
+ * (multiples of 16; 0 = 32 / 64 / 128 by the number of subdomains); "md2_gy" column groups in flight per row block of the
  * Gram-Schmidt dot sweep (0 = by vector length), "md2_nch" its 512-row chunks per workgroup (2 or 4; default 4);
  * "gmres_hostwrite" 1 (default) = the solver's small kernel writes the three numbers of the host's lagged convergence test
  * into mapped pinned memory itself, 0 = an asynchronous copy per iteration;
@@ -331,14 +331,15 @@ int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_bloc
  * matrix, 0 = off; "spmv_pat_nu" / "spmv_win_nu" window sizes of the pattern / per-entry SpMV kernels (0 = default); "inv_kind" 0 = scalar-pivot local inverses that drop finished overlap rows, 1 = rank-4 block sweep on the
  * matrix cores, 2 = scalar-pivot without dropping rows;
  * "gmres_kind" 0 = two-pass Gram-Schmidt with the second pass delayed (DCGS2), 1 = plain two passes, 2 = s-step GMRES: the
- * basis grows "gmres_s" (1 ... 16; 0, the default: 16 from 4 million rows per rank, else 8) vectors at a time -- blocks longer than 8 on the Newton block basis ("gmres_newton" 1, the
+ * basis grows "gmres_s" (1 ... 16; 0, the default: 16 from 1.2 million rows per rank, else 8) vectors at a time -- blocks longer than 8 on the Newton block basis ("gmres_newton" 1, the
  * default: shifts = Leja-ordered Ritz values of the first gmres_s Arnoldi steps, which run in monomial blocks of at most 8; 0 =
  * monomial basis, blocks of at most 8) -- and each block is orthogonalised by block Gram-Schmidt with two
  * passes (four sweeps over the basis and two reductions per block instead of two sweeps and one reduction per iteration; same
  * iterates as 0 / 1 in exact arithmetic; a block is cut where the squared sine of a new vector against its predecessors falls
  * to "gmres_chol_tol", default 1e-13; the convergence claim is checked against the true residual and the residual returned is
  * the true one; tolerances below 1e-9 / 1e-11 take blocks of at most 5 / 3 vectors, because the recurrence of a longer block
- * loses touch with the true residual there; "gmres_spec" n > 0: n operator applications of the next block are put into the
+ * loses touch with the true residual there ("gmres_tol_blocks" 0 lifts that cap: measurements held to an iteration count
+ * instead of a tolerance); "gmres_spec" n > 0: n operator applications of the next block are put into the
  * stream before the host reads a block's outcome, so that the GPU works through that round trip -- default 0: on one GPU the
  * round trip is not what the step waits for (tools/share_n8.py), an A/B switch for multi-GPU runs), see fedd_gmres_info;
  * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank;
