@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfedd_hip.so")
-SOURCES = ["abi.hip", "scan.hip", "symbolic.hip", "assemble.hip", "blocks.hip", "spmv.hip", "schwarz.hip", "schwarz_big.hip", "invert_mfma.hip", "dense.hip", "coarse.hip", "gmres.hip",
+SOURCES = ["abi.hip", "scan.hip", "symbolic.hip", "assemble.hip", "blocks.hip", "spmv.hip", "schwarz.hip", "schwarz_big.hip", "invert_mfma.hip", "dense.hip", "coarse.hip", "gmres.hip", "multi.hip",
            "halo.hip", "mesh_structured.cpp", "mesh_io.cpp", "mesh_partition.cpp", "fe_tables.cpp"]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",

@@ -549,6 +549,34 @@ __global__ void k_gd_store(const double* __restrict__ imask, const double* __res
     if (r < n_rows && imask[r] != 0.0) phi_col[r] = x[r];
 }
 
+// ... the same three steps for MULTI_NR columns at a time on stacked vectors X[r * MULTI_NR + j] (multi.hip): column j is slot
+// slot0 + j, columns j >= nb are zero
+__global__ void k_gd_gamma_cols(const double* __restrict__ phiT, int64_t ldp, int slot0, int nb, const double* __restrict__ imask,
+                                int64_t n_rows, const double* __restrict__ mask, double* __restrict__ V) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t / MULTI_NR;
+    const int j = (int)(t % MULTI_NR);
+    if (r >= n_rows) return;
+    V[t] = (j < nb && imask[r] == 0.0 && mask[r] != 0.0) ? phiT[(int64_t)(slot0 + j) * ldp + r] : 0.0;
+}
+
+__global__ void k_gd_rhs_cols(const double* __restrict__ imask, const double* __restrict__ W, int64_t n_rows, double* __restrict__ B) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_rows * MULTI_NR) B[t] = imask[t / MULTI_NR] != 0.0 ? -W[t] : 0.0;
+}
+
+// (tiles of 16 rows x 16 columns through LDS: the stacked vector is read and the Phi columns are written in whole lines)
+__global__ __launch_bounds__(256) void k_gd_store_cols(const double* __restrict__ imask, const double* __restrict__ X, int64_t n_rows,
+                                                       double* __restrict__ phiT, int64_t ldp, int slot0, int nb) {
+    __shared__ double tile[16][MULTI_NR + 1];
+    const int64_t r0 = (int64_t)blockIdx.x * 16;
+    const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
+    if (r0 + a < n_rows) tile[a][b] = X[(r0 + a) * MULTI_NR + b];
+    __syncthreads();
+    const int64_t r = r0 + b;       // column a, row r0 + b
+    if (r < n_rows && a < nb && imask[r] != 0.0) phiT[(int64_t)(slot0 + a) * ldp + r] = tile[b][a];
+}
+
 // restriction, step 1: per home cell the sums over its rows of Phi[r][slot] * rv[r], slot chunk `blockIdx.y` of 16,
 // fixed-order workgroup reduction (same pattern as k_restrict_cells)
 __global__ __launch_bounds__(256) void k_gd_restrict_cells(const int32_t* __restrict__ cell_ptr,
@@ -987,7 +1015,45 @@ static int gdsw_setup(fedd_ctx* c) {
     FEDD_TRY(c->d_co_z0.ensure((size_t)ld));
     int its_max = 0;
     double rel_max = 0.0;
-    for (int slot = 0; slot < nsd; ++slot) {
+    // all columns solve with the same constrained operator: MULTI_NR of them at a time as one stacked system (multi.hip) -- the
+    // matrix and the local inverses are read once per sweep for all of them; the stacked GMRES minimises the residual of the
+    // whole block with one polynomial, columns that are zero stay zero
+    const bool stacked = c->gdsw_block && c->gmres_kind == 2 && nsd > 1 && multi_rhs_ok(c);
+    if (stacked) {
+        const int nbatch = (nsd + MULTI_NR - 1) / MULTI_NR, nb_max = (nsd + nbatch - 1) / nbatch;
+        const int64_t ns = n_rows * MULTI_NR, ncs = ((std::max<int64_t>(n_rows, c->n_cols) * MULTI_NR) + 15) & ~(int64_t)15;
+        FEDD_TRY(c->d_gd_stack.ensure((size_t)ncs + 3 * (size_t)ns));
+        double* Vs = c->d_gd_stack.p;       // [ncs] with the ghost rows behind the owned ones
+        double* Ws = Vs + ncs;
+        double* Bs = Ws + ns;
+        double* Xs = Bs + ns;
+        const dim3 gs((unsigned)((ns + 255) / 256));
+        // the Krylov basis of a stacked solve: restart length by the memory it may take (16 GB), at least 24
+        const int restart_s = (int)std::max<int64_t>(24, std::min<int64_t>(100, (int64_t)(16.0e9 / (8.0 * (double)ns)) - 1));
+        for (int slot0 = 0; slot0 < nsd; slot0 += nb_max) {
+            const int nb = std::min(nb_max, nsd - slot0);
+            hipLaunchKernelGGL(k_gd_gamma_cols, gs, blk, 0, c->stream, (const double*)c->d_gd_phi.p, ldp, slot0, nb,
+                               (const double*)c->d_gd_imask.p, n_rows, (const double*)c->d_co_mask.p, Vs);
+            FEDD_TRY(spmm_owned(c, Vs, Ws, nullptr, nullptr));
+            hipLaunchKernelGGL(k_gd_rhs_cols, gs, blk, 0, c->stream, (const double*)c->d_gd_imask.p, (const double*)Ws, n_rows, Bs);
+            int its = 0;
+            double rel = 0.0;
+            c->gm_mask = c->d_gd_imask.p;
+            c->gm_nr = MULTI_NR;
+            const bool timing = c->timing;
+            c->timing = false;
+            const int rc = gmres_solve(c, Bs, Xs, c->gdsw_tol, 1000, restart_s, 1, &its, &rel);
+            c->timing = timing;
+            c->gm_mask = nullptr;
+            c->gm_nr = 0;
+            if (rc) return rc;
+            its_max = std::max(its_max, its);
+            rel_max = std::max(rel_max, rel);
+            hipLaunchKernelGGL(k_gd_store_cols, dim3((unsigned)((n_rows + 15) / 16)), blk, 0, c->stream, (const double*)c->d_gd_imask.p,
+                               (const double*)Xs, n_rows, c->d_gd_phi.p, ldp, slot0, nb);
+        }
+    }
+    for (int slot = 0; slot < (stacked ? 0 : nsd); ++slot) {
         FEDD_HIP(hipMemsetAsync(v, 0, (size_t)nc * sizeof(double), c->stream));
         hipLaunchKernelGGL(k_gd_gamma_col, gr, blk, 0, c->stream, (const double*)(c->d_gd_phi.p + (int64_t)slot * ldp),
                            (const double*)c->d_gd_imask.p, n_rows, (const double*)c->d_co_mask.p, v);

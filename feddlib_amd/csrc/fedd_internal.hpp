@@ -288,6 +288,7 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_gd_phi;              // [n_rows * (3^dim - 1) * dofs] coarse basis, row-wise by class of the home cell
     fedd::DevBuf<double> d_gd_imask;            // [n_rows] 1 = free interior dof
     fedd::DevBuf<double> d_gd_tmp;
+    fedd::DevBuf<double> d_gd_stack;            // stacked vectors of the extension solves (gdsw_block)
 
     // ---- GMRES workspace ----
     fedd::DevBuf<double> d_V, d_Z;              // [(m+1)*n_rows], [n_cols] scratch
@@ -299,6 +300,9 @@ struct fedd_ctx {
     double* h_pinned = nullptr;                 // small pinned host mirror
     int gm_restart_alloc = 0;
     int64_t gm_V_ldv = -1;                      // leading dimension the zeroed padding rows of d_V belong to (s-step solver)
+    int gm_nr = 0;                              // > 1: GMRES runs on stacked vectors X[row * gm_nr + j] (multi.hip; the GDSW extension solves)
+    int multi_ch = 4;                           // option "multi_ch": matrix-core steps per flight of gathers in k_apply_multi (4, 8, 16)
+    int gdsw_block = 1;                         // option "gdsw_block": 1 = extension solves sixteen columns at a time, 0 = one by one
     const double* gm_mask = nullptr;            // != nullptr: GMRES solves the constrained system (dofs with mask 0 held), see gmres.hip
 
     // ---- generic scratch ----
@@ -423,6 +427,12 @@ int dense_invert_batched(fedd_ctx* c, double* K, int64_t ld, int batch, int64_t 
 // coarse.hip
 int coarse_setup(fedd_ctx* c);
 int coarse_apply_add(fedd_ctx* c, const double* d_r_owned, double* d_z_owned);   // z += Phi K0^-1 Phi^T r
+
+// multi.hip: operator and one-level Schwarz preconditioner on sixteen stacked right-hand sides, X[row * MULTI_NR + j]
+constexpr int MULTI_NR = 16;
+bool multi_rhs_ok(const fedd_ctx* c);
+int spmm_owned(fedd_ctx* c, double* d_X, double* d_Y, const double* mk, const double* alt);
+int schwarz_apply_multi(fedd_ctx* c, double* d_R, double* d_Z, const double* mk);
 
 // gmres.hip
 int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart,

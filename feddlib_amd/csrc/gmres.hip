@@ -1360,7 +1360,11 @@ static void leja_order(double* v, int n) {
 template <int S>
 static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart,
                              int use_prec, int* its_out, double* relres_out) {
-    const int64_t n = c->n_rows;
+    // c->gm_nr > 1: stacked vectors X[row * nr + j] (nr right-hand sides with one matrix: the GDSW extension solves); the
+    // operator and the preconditioner are the stacked ones of multi.hip, everything else sees vectors nr times as long
+    const int nr = c->gm_nr > 1 ? c->gm_nr : 1;
+    FEDD_CHECK(nr == 1 || (nr == MULTI_NR && use_prec && multi_rhs_ok(c)), "gmres: stacked solve with %d right-hand sides", nr);
+    const int64_t n = c->n_rows * nr;
     const int m = std::min(restart, max_it);
     const int64_t ldv = (n + 15) & ~(int64_t)15;
     FEDD_CHECK(m + 2 <= 1024, "gmres: restart length above 1022 is not supported");
@@ -1378,14 +1382,15 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
         // (and on finite data everywhere): a freshly (re)allocated basis, or one last used with another vector length, is cleared
         const double* before = c->d_V.p;
         FEDD_TRY(c->d_V.ensure((size_t)(m + 1) * ldv));
-        if (c->d_V.p != before || c->gm_V_ldv != ldv) {
-            FEDD_HIP(hipMemsetAsync(c->d_V.p, 0, c->d_V.cap * sizeof(double), c->stream));
-            c->gm_V_ldv = ldv;
-        }
+        // (a buffer that another vector length used holds finite values everywhere: only its padding rows need the clearing)
+        if (c->d_V.p != before) FEDD_HIP(hipMemsetAsync(c->d_V.p, 0, c->d_V.cap * sizeof(double), c->stream));
+        else if (c->gm_V_ldv != ldv && ldv != n) FEDD_HIP(hipMemsetAsync(c->d_V.p, 0, (size_t)(m + 1) * ldv * sizeof(double), c->stream));
+        c->gm_V_ldv = ldv;
     }
-    const int64_t nc = (std::max<int64_t>(n, c->n_cols) + 15) & ~(int64_t)15;
+    const int64_t nc = (std::max<int64_t>(c->n_rows, c->n_cols) * nr + 15) & ~(int64_t)15;
+    const bool ghosts = c->n_cols != c->n_rows || !c->halo.peers.empty();
     FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)2 * nc, c->d_w.cap)));   // x trial | A x trial
-    FEDD_TRY(c->d_Z.ensure((size_t)nc * 2));
+    FEDD_TRY(c->d_Z.ensure((size_t)nc * (nr > 1 && ghosts ? 3 : 2)));      // (stacked, several ranks: + a copy with a ghost tail)
     FEDD_TRY(c->d_part.ensure(std::max((size_t)(m + 1 + S) * S * nblkd, (size_t)std::max(nblk, nblk2))));
     FEDD_TRY(c->d_flags.ensure(16));
     Off o;
@@ -1434,6 +1439,15 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     const double* mk = c->gm_mask;
     // out = A M^-1 in - theta in  (basis columns: no ghost tail; the shift rides in the SpMV kernel's store)
     auto apply_B = [&](const double* in, double* out, double theta) -> int {
+        if (nr > 1) {       // masks ride in the kernels' stores
+            double* src = const_cast<double*>(in);
+            if (ghosts) {
+                src = c->d_Z.p + 2 * nc;
+                FEDD_HIP(hipMemcpyAsync(src, in, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            }
+            FEDD_TRY(schwarz_apply_multi(c, src, z, mk));
+            return spmm_owned(c, z, out, mk, z);
+        }
         if (use_prec) FEDD_TRY(schwarz_apply(c, in, z, false));
         if (mk) {
             if (use_prec) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)z, in, z, n);
@@ -1476,7 +1490,10 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
         if (cols > 0) {
             hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(cols + 1) * sizeof(double), st, Sx, o, cols, m);
             hipLaunchKernelGGL(k_combine, dim3((unsigned)((n + AX_ROWS - 1) / AX_ROWS)), blk, 0, st, (const double*)V, ldv, n, cols, (const double*)(Sx + o.y), r);
-            if (use_prec) {
+            if (nr > 1) {
+                FEDD_TRY(schwarz_apply_multi(c, r, z, mk));
+                hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)z, xt, n);
+            } else if (use_prec) {
                 FEDD_TRY(schwarz_apply(c, r, z, true));
                 if (mk) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)z, (const double*)r, z, n);
                 hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)z, xt, n);
@@ -1486,8 +1503,12 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
         } else {
             FEDD_HIP(hipMemcpyAsync(xt, d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
-        FEDD_TRY(spmv_owned(c, xt, axt, true));
-        if (mk) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)axt, (const double*)xt, axt, n);
+        if (nr > 1) {
+            FEDD_TRY(spmm_owned(c, xt, axt, mk, xt));
+        } else {
+            FEDD_TRY(spmv_owned(c, xt, axt, true));
+            if (mk) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)axt, (const double*)xt, axt, n);
+        }
         hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, d_b, -1.0, (const double*)axt, r, n);
         FEDD_TRY(norm2_into(r, Sx + o.nrm + 3));
         FEDD_HIP(hipMemcpyAsync(c->h_pinned, Sx + o.nrm + 3, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1510,7 +1531,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     // two vectors, 1e7 at s = 8): the Newton basis w_i = (B - theta_i) w_{i-1} with the Ritz values of the first s_goal
     // Arnoldi steps as shifts, Leja-ordered (Bai, Hu, Reichel, "A Newton basis GMRES implementation", 1994).  Until those
     // steps exist the blocks are monomial and at most 8 long.
-    const bool newton = c->gmres_newton && s_goal > 8 && !mk;
+    const bool newton = c->gmres_newton && s_goal > 8 && !mk && nr == 1;
     bool have_shifts = false;
     std::vector<double> theta((size_t)S, 0.0);
     int s_cur = std::min(s_goal, 8);
@@ -1754,6 +1775,8 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
             return rc;
         }
         c->gmres_s_used = c->gmres_s;
+        // (the constrained solves run monomial blocks of at most eight vectors: the 8-column kernels)
+        if (c->gm_mask && c->gmres_s > 8) return gmres_solve_sstep<8>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
         if (c->gmres_s <= 4) return gmres_solve_sstep<4>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
         if (c->gmres_s <= 8) return gmres_solve_sstep<8>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
         return gmres_solve_sstep<16>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);

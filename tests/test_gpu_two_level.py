@@ -220,3 +220,49 @@ def test_gdsw_elasticity_and_iteration_counts(fedd_lib):
         assert counts[8][1] < counts[8][0]
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("problem,kind", [("laplace", "gdsw"), ("laplace", "rgdsw"), ("elasticity", "gdsw"), ("elasticity", "rgdsw")])
+def test_extension_solves_sixteen_columns_at_a_time(fedd_lib, problem, kind):
+    """option "gdsw_block": the harmonic extensions solved as stacked systems of sixteen columns (multi.hip: the matrix and the
+    local inverses read once per sweep) against the same columns solved one by one -- the same K0^-1 and operator to 1e-10 when
+    both are driven to 1e-13, the same outer iteration count at the default extension tolerance; 26 (Laplace) and 78 (elasticity)
+    GDSW columns: several batches, the last one partly filled"""
+    c = fedd_lib.Context(device=0)
+    try:
+        M = 12
+        m = fedd_lib.structured_mesh(3, 1, M)
+        c.mesh_set_dict(m)
+        if problem == "laplace":
+            c.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+            c.assemble(fedd_lib.FORM_LAPLACE)
+            c.assemble_rhs([1.0])
+            c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+        else:
+            mu, nu = 2.0e6, 0.4
+            c.pattern_build(3, fedd_lib.BLOCK_FULL)
+            c.assemble(fedd_lib.FORM_LINELAS, [2.0 * mu * nu / (1.0 - 2.0 * nu), mu])
+            c.assemble_rhs([0.0, 1.0, 0.0])
+            c.dirichlet([2], [0.0, 0.0, 0.0])
+        c.schwarz_set_target(8, 1.0)
+        c.schwarz_set_coarse(27)
+        ck = fedd_lib.COARSE_RGDSW if kind == "rgdsw" else fedd_lib.COARSE_GDSW
+        rng = np.random.default_rng(11)
+        r = rng.standard_normal(c.csr_sizes()[0])
+        out = {}
+        for block in (0, 1):
+            c.set_option("gdsw_block", block)
+            c.set_option("gdsw_tol", 1e-13)
+            c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=ck)
+            Kinv = c.schwarz_coarse()[1]
+            z = c.schwarz_apply(r)
+            c.set_option("gdsw_tol", 1e-6)
+            c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=ck)
+            x, its, rel = c.gmres(None, rtol=1e-8, max_it=400, restart=100, use_prec=True)
+            out[block] = (Kinv, z, its, x)
+        np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=1e-10 * np.abs(out[0][0]).max())
+        np.testing.assert_allclose(out[1][1], out[0][1], rtol=0, atol=1e-10 * np.abs(out[0][1]).max())
+        assert abs(out[1][2] - out[0][2]) <= 1, (out[0][2], out[1][2])
+        np.testing.assert_allclose(out[1][3], out[0][3], rtol=0, atol=1e-6 * np.abs(out[0][3]).max())
+    finally:
+        c.close()
