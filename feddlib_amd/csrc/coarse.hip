@@ -726,6 +726,145 @@ __global__ void k_gd_scatter_col(CoarseGeom cg, int dofs, int64_t n_ent, int k, 
     K[t * ld + Ep * dofs + k] = r0[t];
 }
 
+// ---- the Galerkin product MULTI_NR columns at a time (stacked vectors X[r * MULTI_NR + j], multi.hip) ----
+struct GdCols {
+    int nb;
+    int8_t c[MULTI_NR][3];   // colour of column j
+    int8_t k[MULTI_NR];      // component of column j
+};
+
+// V[r][j] = the prolongation of the unit vectors (E, k_j) over the entities E of colour j (k_gd_prolong_colour for each column)
+template <int DIM>
+__global__ void k_gd_prolong_colours(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int64_t n_rows, int64_t ldp,
+                                     const double* __restrict__ phiT, const double* __restrict__ mask, GdCols cols,
+                                     double* __restrict__ V) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t / MULTI_NR;
+    const int j = (int)(t % MULTI_NR);
+    if (r >= n_rows) return;
+    double val = 0.0;
+    if (j < cols.nb) {
+        const int32_t node = (int32_t)(r / dofs);
+        int e[3], h[3] = {0, 0, 0};
+        gd_entity_coords<DIM>(cg, ent[node], e);
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) h[d] = e[d] >> 1;
+        for (int ai = 0; ai < act.n; ++ai) {
+            int ee[3] = {0, 0, 0};
+            if (!gd_entity_of<DIM>(cg, h, act.cls[ai], ee)) continue;
+            bool on = gd_coarse_id<DIM>(cg, ee) >= 0;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) on = on && (ee[d] % gd_period(cg)) == cols.c[j][d];
+            if (on) val = phiT[(int64_t)(ai * dofs + cols.k[j]) * ldp + r];
+        }
+        val *= mask[r];
+    }
+    V[t] = val;
+}
+
+// restriction of MULTI_NR columns, step 1: per (home cell, chunk of its rows, tile of 16 slots) the 16 x 16 block
+//   part[slot][j] = sum over the chunk's rows of Phi[slot][r] W[r][j]
+// on the f64 matrix cores (M = slots, N = columns, K = rows): Phi is read once for sixteen columns.  The four waves take the
+// chunk's row quadruples in turn; their partial tiles are added in wave order (fixed order: reproducible).
+__global__ __launch_bounds__(256) void k_gd_restrict_cells_cols(const int32_t* __restrict__ cell_ptr, const int32_t* __restrict__ cell_nodes,
+                                                                int dofs, int nsd, int nch, int64_t ldp, const double* __restrict__ phiT,
+                                                                const double* __restrict__ W, double* __restrict__ part) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    __shared__ double red[4][4][64];
+    const int cell = blockIdx.x, st = blockIdx.y, ch = blockIdx.z;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lj = lane & 15, lk = lane >> 4;
+    const int64_t items = (int64_t)(cell_ptr[cell + 1] - cell_ptr[cell]) * dofs, i0 = (int64_t)cell_ptr[cell] * dofs;
+    const int64_t per = ((items + nch - 1) / nch + 3) & ~(int64_t)3;
+    const int64_t b = min(items, per * ch), e = min(items, per * (ch + 1));
+    const int slot = 16 * st + lj;
+    const double* __restrict__ prow = phiT + (int64_t)min(slot, nsd - 1) * ldp;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t q = b + 4 * w; q < e; q += 16) {
+        const int64_t item = q + lk;
+        const bool on = item < e;
+        const int64_t it = i0 + (on ? item : b);
+        const int32_t node = cell_nodes[it / dofs];
+        const int64_t r = (int64_t)node * dofs + it % dofs;
+        double a = prow[r], x = W[r * MULTI_NR + lj];
+        a = (on && slot < nsd) ? a : 0.0;
+        x = on ? x : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[w][q][lane] = acc[q];
+    __syncthreads();
+    // register q at lane (lk, lj): slot 16 st + lk + 4 q, column lj; wave w adds register w
+    const int so = 16 * st + lk + 4 * w;
+    if (so < nsd)
+        part[(((int64_t)cell * nch + ch) * nsd + so) * MULTI_NR + lj] = ((red[0][w][lane] + red[1][w][lane]) + red[2][w][lane]) + red[3][w][lane];
+}
+
+// step 2: r0[(E, a)][j] = sum over the cells that see E and their chunks (fixed order) of the class(E) partial sums
+template <int DIM>
+__global__ void k_gd_restrict_ent_cols(CoarseGeom cg, GdAct act, int dofs, int64_t n_ent, int nch, const double* __restrict__ part,
+                                       double* __restrict__ r0) {
+    const int64_t tt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tt >= n_ent * dofs * MULTI_NR) return;
+    const int j = (int)(tt % MULTI_NR);
+    const int64_t t = tt / MULTI_NR;
+    const int32_t E = (int32_t)(t / dofs);
+    const int k = (int)(t - (int64_t)E * dofs);
+    int e[3];
+    gd_coarse_coords<DIM>(cg, E, e);
+    const int cls = gd_class<DIM>(e);
+    double sum = 0.0;
+    if (cls >= 0 && act.idx[cls] >= 0) {
+        const int nsd = act.n * dofs;
+        for (int a = 0; a < (1 << DIM); ++a) {
+            int h[3] = {0, 0, 0};
+            bool ok = true;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) {
+                const int bit = (a >> d) & 1;
+                if (e[d] & 1) h[d] = (e[d] - 1) / 2 + bit;
+                else {
+                    h[d] = e[d] / 2;
+                    ok = ok && bit == 0;
+                }
+                ok = ok && h[d] >= 0 && h[d] < cg.g[d];
+            }
+            if (ok) {
+                const int64_t cell = cell_of<DIM>(cg, h);
+                for (int ch = 0; ch < nch; ++ch) sum += part[((cell * nch + ch) * nsd + act.idx[cls] * dofs + k) * MULTI_NR + j];
+            }
+        }
+    }
+    r0[tt] = sum;
+}
+
+// K0[(E, a)][(E', k_j)] = r0[(E, a)][j] with E' the entity of column j's colour within two lattice steps of E
+template <int DIM>
+__global__ void k_gd_scatter_cols(CoarseGeom cg, int dofs, int64_t n_ent, GdCols cols, const double* __restrict__ r0,
+                                  double* __restrict__ K, int64_t ld) {
+    const int64_t tt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tt >= n_ent * dofs * MULTI_NR) return;
+    const int j = (int)(tt % MULTI_NR);
+    if (j >= cols.nb) return;
+    const int64_t t = tt / MULTI_NR;
+    const int32_t E = (int32_t)(t / dofs);
+    int e[3], ep[3] = {0, 0, 0};
+    gd_coarse_coords<DIM>(cg, E, e);
+    if (gd_class<DIM>(e) < 0) return;
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        const int P = gd_period(cg);
+        int dlt = (cols.c[j][d] - e[d] % P + P) % P;
+        if (dlt > P / 2) dlt -= P;
+        ep[d] = e[d] + dlt;
+        ok = ok && ep[d] >= 0 && ep[d] <= 2 * cg.g[d] - 2;
+    }
+    if (!ok || gd_class<DIM>(ep) < 0) return;
+    const int64_t Ep = gd_coarse_id<DIM>(cg, ep);
+    if (Ep < 0) return;
+    K[t * ld + Ep * dofs + cols.k[j]] = r0[tt];
+}
+
 // ---- apply ----
 template <int DIM, int DOFS>
 __global__ __launch_bounds__(256) void k_restrict_cells(CoarseGeom cg, const int32_t* __restrict__ cell_ptr,
@@ -1087,13 +1226,53 @@ static int gdsw_setup(fedd_ctx* c) {
     for (int d = 0; d < dim; ++d) ncol[d] = std::min(gd_period(cg), 2 * cg.g[d] - 1);
     // RGDSW: coarse nodes have odd coordinates in every direction with >= 2 cells (and 0 in the others): only those residues
     auto colour_used = [&](int d, int cc) { return !reduced || (cg.g[d] >= 2 ? (cc & 1) == 1 : cc == 0); };
+    std::vector<GdCol> colours;
     for (int c2 = 0; c2 < ncol[2]; ++c2)
         for (int c1 = 0; c1 < ncol[1]; ++c1)
-            for (int c0 = 0; c0 < ncol[0]; ++c0)
+            for (int c0 = 0; c0 < ncol[0]; ++c0) {
+                if (!(colour_used(0, c0) && (dim < 2 || colour_used(1, c1)) && (dim < 3 || colour_used(2, c2)))) continue;
+                GdCol col;
+                col.c[0] = c0; col.c[1] = c1; col.c[2] = c2;
+                colours.push_back(col);
+            }
+    if (stacked) {
+        // MULTI_NR (colour, component) columns per sweep: one SpMM, and Phi read once per sweep by the restriction
+        const int64_t ns = n_rows * MULTI_NR;
+        double* Vs = c->d_gd_stack.p;
+        double* Ws = Vs + (((std::max<int64_t>(n_rows, c->n_cols) * MULTI_NR) + 15) & ~(int64_t)15);
+        // chunks per cell: about 2048 rows each, so that few large cells still spread over the device
+        const int nch = (int)std::min<int64_t>(64, std::max<int64_t>(1, (n_rows / std::max<int64_t>(ncell, 1) + 2047) / 2048));
+        FEDD_TRY(c->d_co_part.ensure((size_t)ncell * nch * std::max(nsd, 1) * MULTI_NR));
+        FEDD_TRY(c->d_co_r0.ensure(std::max<size_t>((size_t)n0 * MULTI_NR, c->d_co_r0.cap)));
+        FEDD_CHECK(n0 * MULTI_NR < ((int64_t)1 << 31), "GDSW setup: coarse space too large for the stacked Galerkin product");
+        const dim3 gs((unsigned)((ns + 255) / 256)), ges((unsigned)((n0 * MULTI_NR + 255) / 256));
+        const int64_t npairs = (int64_t)colours.size() * dofs;
+        for (int64_t p0 = 0; p0 < npairs; p0 += MULTI_NR) {
+            GdCols cols;
+            cols.nb = (int)std::min<int64_t>(MULTI_NR, npairs - p0);
+            for (int j = 0; j < MULTI_NR; ++j) {
+                const int64_t pj = std::min(p0 + j, npairs - 1);
+                for (int d = 0; d < 3; ++d) cols.c[j][d] = (int8_t)colours[(size_t)(pj / dofs)].c[d];
+                cols.k[j] = (int8_t)(pj % dofs);
+            }
+            if (dim == 3) hipLaunchKernelGGL(k_gd_prolong_colours<3>, gs, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, cols, Vs);
+            else hipLaunchKernelGGL(k_gd_prolong_colours<2>, gs, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, cols, Vs);
+            FEDD_TRY(spmm_owned(c, Vs, Ws, nullptr, nullptr));
+            hipLaunchKernelGGL(k_gd_restrict_cells_cols, dim3((unsigned)ncell, (unsigned)((nsd + 15) / 16), (unsigned)nch), blk, 0, c->stream,
+                               (const int32_t*)c->d_co_cell_ptr.p, (const int32_t*)c->d_co_val[c->co_sorted].p, dofs, nsd, nch, ldp,
+                               (const double*)c->d_gd_phi.p, (const double*)Ws, c->d_co_part.p);
+            if (dim == 3) hipLaunchKernelGGL(k_gd_restrict_ent_cols<3>, ges, blk, 0, c->stream, cg, act, dofs, n_ent, nch, (const double*)c->d_co_part.p, c->d_co_r0.p);
+            else hipLaunchKernelGGL(k_gd_restrict_ent_cols<2>, ges, blk, 0, c->stream, cg, act, dofs, n_ent, nch, (const double*)c->d_co_part.p, c->d_co_r0.p);
+            if (c->nranks > 1) FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, (int)(n0 * MULTI_NR)));
+            if (dim == 3) hipLaunchKernelGGL(k_gd_scatter_cols<3>, ges, blk, 0, c->stream, cg, dofs, n_ent, cols, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
+            else hipLaunchKernelGGL(k_gd_scatter_cols<2>, ges, blk, 0, c->stream, cg, dofs, n_ent, cols, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
+        }
+        // (the per-column restriction of the apply takes its own layout of the partial sums)
+        FEDD_TRY(c->d_co_part.ensure((size_t)ncell * std::max(nsd, 1)));
+    }
+    for (size_t ci = 0; ci < (stacked ? 0 : colours.size()); ++ci)
                 for (int k = 0; k < dofs; ++k) {
-                    if (!(colour_used(0, c0) && (dim < 2 || colour_used(1, c1)) && (dim < 3 || colour_used(2, c2)))) continue;
-                    GdCol col;
-                    col.c[0] = c0; col.c[1] = c1; col.c[2] = c2;
+                    const GdCol col = colours[ci];
                     if (dim == 3) hipLaunchKernelGGL(k_gd_prolong_colour<3>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, k, col, v);
                     else hipLaunchKernelGGL(k_gd_prolong_colour<2>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, k, col, v);
                     FEDD_TRY(spmv_owned(c, v, w, true));
