@@ -717,6 +717,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "apply_span") c->apply_span = (int)value;
     else if (k == "gdsw_block") c->gdsw_block = value != 0.0;
     else if (k == "multi_ch") c->multi_ch = (int)value;
+    else if (k == "pat_hash") c->pat_hash = value != 0.0;
     else if (k == "md2_gy") c->md2_gy = (int)value;
     else if (k == "gmres_hostwrite") c->h_pinned_dev = value != 0 ? c->h_pinned_map : nullptr;
     else if (k == "spmv_pattern") { c->spmv_pattern = (int)value; c->cs_valid = false; }

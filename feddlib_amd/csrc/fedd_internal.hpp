@@ -302,6 +302,7 @@ struct fedd_ctx {
     int64_t gm_V_ldv = -1;                      // leading dimension the zeroed padding rows of d_V belong to (s-step solver)
     int gm_nr = 0;                              // > 1: GMRES runs on stacked vectors X[row * gm_nr + j] (multi.hip; the GDSW extension solves)
     int multi_ch = 4;                           // option "multi_ch": matrix-core steps per flight of gathers in k_apply_multi (4, 8, 16)
+    int pat_hash = 1;                           // option "pat_hash": 1 = hashed node-pattern merge for vertex-only elements (symbolic.hip)
     int gdsw_block = 1;                         // option "gdsw_block": 1 = extension solves sixteen columns at a time, 0 = one by one
     const double* gm_mask = nullptr;            // != nullptr: GMRES solves the constrained system (dofs with mask 0 held), see gmres.hip
 
