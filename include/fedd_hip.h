@@ -271,7 +271,9 @@ int fedd_spmv_info(fedd_ctx* ctx, int64_t* nnz_pattern, int64_t* nnz_streamed);
  * (constants per dof component: what FROSch has without node coordinates, parametersPrec.xml:5 "Use node lists" = false)
  * restricted to each interface component and extended discrete-harmonically into the cell interiors (device GMRES +
  * one-level Schwarz on the constrained operator, option "gdsw_tol", default 1e-6: the outer iteration count is that of exact extensions down to about 1e-4, see
- * profiles/r02_gdsw_tol_sweep.txt; the parity tests ask for 1e-13), K0 = Phi^T A Phi inverted on the
+ * profiles/r02_gdsw_tol_sweep.txt; the parity tests ask for 1e-13; option "gdsw_block" 1 (default) = sixteen columns at a
+ * time as one stacked system over an SpMM and a matrix-core Schwarz apply, multi.hip, 0 = column by column; "multi_ch" 4 / 8 / 16 = matrix-core
+ * steps per flight of gathers of that apply), K0 = Phi^T A Phi inverted on the
  * matrix cores.  (2g - 1)^dim * dofs coarse dofs for g cells per direction. */
 #define FEDD_COARSE_GDSW 2
 /* FEDD_COARSE_RGDSW: the reduced GDSW space (FROSch RGDSWCoarseOperator, the one steadyLinElas_Perf/parametersPrec.xml:18
@@ -315,6 +317,7 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
 int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_blocks);
 
 /* tuning knobs (A/B tests), 0 is the default of each: "spmv_kind" 0 = CSR-window (CSR-stream when a row has more than 256 entries), 1 = row-per-lane-group, 2 = CSR-stream;
+ * "pat_hash" 1 (default) = node pattern of vertex-only elements merged through a hash table of list positions (symbolic.hip), 0 = ordered insertion;
  * "asm_tiles" 1 (default) = the P1 Laplace / vector-Laplace / elasticity forms are assembled element-major over tiles of ~27 nodes
  * (every element of a tile evaluated once, contributions gathered per CSR slot from lists built once per mesh), 0 = the pair
  * kernels; "asm_kind" 4 = tiles whatever "asm_tiles" says, 0 = pair-parallel assembly (slot-addressed accumulation for the block forms -- elasticity, B / B^T --, slot sweep for
