@@ -1055,7 +1055,10 @@ static int gdsw_setup(fedd_ctx* c) {
     double lo[3], hi[3], n_global = 0.0;
     FEDD_TRY(global_box(c, n_own, lo, hi, &n_global));
     // ---- the coarse decomposition: cells of a regular lattice, g_d = max(1, floor(L_d / H + 0.5)) ----
-    // default: one cell per 1000 nodes, at most 8^3 (scalar) / 5^3 (vector) cells: (2 g - 1)^dim * dofs coarse dofs
+    // default: one cell per 1000 nodes, at most as many as the dense coarse solver takes ((2 g - 1)^dim * dofs coarse dofs: 10^3
+    // cells for scalar problems in 3D, 7^3 for three dofs per node).  cfg 5's share (94^3-cell elasticity), setup + solve:
+    // 5^3 cells 1199 + 294 ms (224 iterations), 6^3 900 + 246 (190), 7^3 869 + 215 (162): smaller interiors take fewer
+    // extension iterations, and the Galerkin product no longer costs a sweep per coarse column
     const bool reduced = c->co_kind == FEDD_COARSE_RGDSW;
     double target = c->co_cells_target;
     // RGDSW has (g - 1)^dim * dofs coarse dofs only: one cell per 400 nodes, as many as the dense coarse solver takes
@@ -1066,7 +1069,8 @@ static int gdsw_setup(fedd_ctx* c) {
             const int gmax = (int)std::floor(std::pow((double)COARSE_MAX_DOFS / dofs, 1.0 / dim)) + 1;
             target = std::min(std::pow((double)std::min(gmax, 20), (double)dim), std::max(1.0, std::floor(n_global / 400.0)));
         } else {
-            target = std::min(dofs == 1 ? 512.0 : 125.0, std::max(1.0, std::floor(n_global / 1000.0)));
+            const int gmax = std::max(1, ((int)std::floor(std::pow((double)COARSE_MAX_DOFS / dofs, 1.0 / dim)) + 1) / 2);
+            target = std::min(std::pow((double)gmax, (double)dim), std::max(1.0, std::floor(n_global / 1000.0)));
         }
     }
     CoarseGeom cg;

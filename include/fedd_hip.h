@@ -266,7 +266,7 @@ int fedd_spmv_info(fedd_ctx* ctx, int64_t* nnz_pattern, int64_t* nnz_streamed);
  * K0 = Phi^T A Phi is formed and inverted on the device, replicated on every rank. */
 #define FEDD_COARSE_Q1 1
 /* FEDD_COARSE_GDSW: FROSch's GDSWCoarseOperator on a second, coarse decomposition -- the cells of the same regular lattice
- * (fedd_schwarz_set_coarse; default one cell per 1000 nodes, at most 8^3 cells for scalar and 5^3 for vector problems):
+ * (fedd_schwarz_set_coarse; default one cell per 1000 nodes, at most what the dense coarse solver takes: 10^3 cells for scalar, 7^3 for 3-dof problems in 3D):
  * interface nodes are classified into the faces / edges / vertices between the cells, the coarse basis is the null space
  * (constants per dof component: what FROSch has without node coordinates, parametersPrec.xml:5 "Use node lists" = false)
  * restricted to each interface component and extended discrete-harmonically into the cell interiors (device GMRES +

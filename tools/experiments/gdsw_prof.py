@@ -24,6 +24,8 @@ c.assemble(capi.FORM_LINELAS, [lam, mu])
 c.assemble_rhs([0.0, 1.0, 0.0])
 c.dirichlet([2], [0.0, 0.0, 0.0])
 c.schwarz_set_target(8, 1.0)
+if os.environ.get("GD_CELLS"):
+    c.schwarz_set_coarse(int(os.environ["GD_CELLS"]))
 for s in range(steps):
     c.timing_reset()
     t0 = time.perf_counter()
@@ -31,5 +33,8 @@ for s in range(steps):
     c.sync()
     t1 = time.perf_counter()
     print("setup %.1f ms" % ((t1 - t0) * 1e3), c.schwarz_coarse_sizes(), flush=True)
+c.sync()
+t0 = time.perf_counter()
 its, rel = c.gmres(None, rtol=1e-6, max_it=2000, restart=100, use_prec=True, want_x=False)[1:]
-print("solve", its, rel, {k: round(v[0], 2) for k, v in c.timing_get().items() if v[0] > 0})
+c.sync()
+print("solve %.1f ms" % ((time.perf_counter() - t0) * 1e3), its, rel, {k: round(v[0], 2) for k, v in c.timing_get().items() if v[0] > 0})
