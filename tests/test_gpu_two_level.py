@@ -2,6 +2,8 @@
 level that stands in for FROSch's GDSWCoarseOperator, parametersPrec.xml:13, 62-122): lattice,
 dense K0^-1 (Galerkin product + blocked Gauss-Jordan on the f64 matrix cores), operator apply,
 iteration counts, elasticity, 2D, and the misuse messages."""
+import os
+
 import numpy as np
 import pytest
 
@@ -222,7 +224,8 @@ def test_gdsw_elasticity_and_iteration_counts(fedd_lib):
         c.close()
 
 
-@pytest.mark.parametrize("problem,kind", [("laplace", "gdsw"), ("laplace", "rgdsw"), ("elasticity", "gdsw"), ("elasticity", "rgdsw")])
+@pytest.mark.parametrize("problem,kind", [("laplace", "gdsw"), ("laplace", "rgdsw"), ("elasticity", "gdsw"), ("elasticity", "rgdsw"),
+                                          ("cylinder", "gdsw"), ("cylinder", "rgdsw")])
 def test_extension_solves_sixteen_columns_at_a_time(fedd_lib, problem, kind):
     """option "gdsw_block": the harmonic extensions solved as stacked systems of sixteen columns (multi.hip: the matrix and the
     local inverses read once per sweep) against the same columns solved one by one -- the same K0^-1 and operator to 1e-10 when
@@ -231,9 +234,17 @@ def test_extension_solves_sixteen_columns_at_a_time(fedd_lib, problem, kind):
     c = fedd_lib.Context(device=0)
     try:
         M = 12
-        m = fedd_lib.structured_mesh(3, 1, M)
+        if problem == "cylinder":       # unstructured: every subdomain its own inverse (no slab shared through LDS), ragged boxes
+            m = fedd_lib.read_mesh(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "DFG3DCylinder_1k.mesh"), 3)
+        else:
+            m = fedd_lib.structured_mesh(3, 1, M)
         c.mesh_set_dict(m)
-        if problem == "laplace":
+        if problem == "cylinder":
+            c.pattern_build(3, fedd_lib.BLOCK_DIAG)
+            c.assemble(fedd_lib.FORM_LAPLACE_VEC)
+            c.assemble_rhs([0.0, 1.0, 0.0])
+            c.dirichlet([1, 2], [0.0, 0.0, 0.0])
+        elif problem == "laplace":
             c.pattern_build(1, fedd_lib.BLOCK_SCALAR)
             c.assemble(fedd_lib.FORM_LAPLACE)
             c.assemble_rhs([1.0])
