@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_fix_diag(double* __restrict__ K, int64_
 //     3^dim - 1 CLASSES (per direction: e_d even / e_d = 1 mod 4 / e_d = 3 mod 4), so one constrained solve per
 //     (class, component) extends all entities of the class at once.  The solves run on the device with the
 //     library's own GMRES + one-level Schwarz on the constrained operator (gmres.hip, gm_mask) to `gdsw_tol`
-//     (default 1e-6): an iterative interior solver in place of FROSch's direct ExtensionSolver;
+//     (default 1e-4): an iterative interior solver in place of FROSch's direct ExtensionSolver;
 //   * K0 = Phi^T K Phi, column by colour: entities whose coordinates agree modulo 5 (RGDSW: coarse nodes, modulo 6) in every
 //     direction have supports that no row couples, so one prolongation - SpMV - restriction gives one column of K0 for all of them;
 //     K0 is inverted by the matrix-core sweep of dense.hip and replicated, exactly like the Q1 level.

@@ -267,7 +267,7 @@ def test_extension_solves_sixteen_columns_at_a_time(fedd_lib, problem, kind):
             c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=ck)
             Kinv = c.schwarz_coarse()[1]
             z = c.schwarz_apply(r)
-            c.set_option("gdsw_tol", 1e-6)
+            c.set_option("gdsw_tol", 1e-4)      # the default
             c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=ck)
             x, its, rel = c.gmres(None, rtol=1e-8, max_it=400, restart=100, use_prec=True)
             out[block] = (Kinv, z, its, x)
