@@ -1254,7 +1254,6 @@ static int gdsw_setup(fedd_ctx* c) {
             }
     if (stacked) {
         // MULTI_NR (colour, component) columns per sweep: one SpMM, and Phi read once per sweep by the restriction
-        const int64_t ns = n_rows * MULTI_NR;
         double* Vs = c->d_gd_stack.p;
         double* Ws = Vs + (((std::max<int64_t>(n_rows, c->n_cols) * MULTI_NR) + 15) & ~(int64_t)15);
         // chunks per cell: about 2048 rows each, so that few large cells still spread over the device
