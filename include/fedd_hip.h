@@ -280,7 +280,8 @@ int fedd_spmv_info(fedd_ctx* ctx, int64_t* nnz_pattern, int64_t* nnz_streamed);
  * names; Dohrmann & Widlund 2017, option 1): coarse functions only for the coarse nodes of the same decomposition (its
  * vertices; for slab / pencil decompositions the interface components without lower-dimensional neighbours), an interface
  * node of component e carrying 1 / |C(e)| for each adjacent coarse node; harmonic extensions and K0 as for GDSW.
- * (g - 1)^dim * dofs coarse dofs: the default lattice may be as fine as the Q1 one (one cell per 1000 nodes, <= 12^3). */
+ * (g - 1)^dim * dofs coarse dofs: the default lattice is one cell per 400 nodes, at most what the dense coarse solver takes
+ * (14^3 cells for 3-dof problems in 3D). */
 #define FEDD_COARSE_RGDSW 3
 int fedd_schwarz_setup(fedd_ctx* ctx, int overlap, int combine, int two_level, int coarse_kind);
 /* target_nodes = 0 (the default): 27 nodes for scalar problems, 27 / dofs-per-node for vector ones */
