@@ -1636,8 +1636,10 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
             if (count <= 0) return;
             if (shared) {
                 // ranges of whole 64-place chunks (measured on the 214^3 grid, 389017 subdomains: 64: 195 us, 128: 187, 256: 191, 512: 233)
-                // (19683 subdomains, the share of one GPU of eight: 64: 40.8 us, 48: 37.0, 32: 34.9, 16: 36.2)
-                int span = c->apply_span > 0 ? c->apply_span : (count >= 256 * 1024 ? 128 : (count >= 48 * 1024 ? 64 : 32));
+                // (19683 subdomains, the share of one GPU of eight: 64: 40.8 us, 48: 37.0, 32: 34.9, 16: 36.2;
+                //  166375 subdomains of 64 nodes, the headline: 32: 157 us, 48: 144, 64: 142.5, 96: 138, 128: 146)
+                int span = c->apply_span > 0 ? c->apply_span
+                                             : (count >= 256 * 1024 ? 128 : (count >= 128 * 1024 ? 96 : (count >= 48 * 1024 ? 64 : 32)));
                 span = std::max(16, (span + 15) / 16 * 16);     // whole 16-place batches
                 const int nwg = (int)((count + span - 1) / span);
 #define APPLY_MFMA(RT, KW)                                                                                                   \

@@ -327,7 +327,7 @@ int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_bloc
  * apply by the setup's outcome (batched matrix-core kernel when at most a quarter of at least 4096 subdomains have distinct
  * local matrices, else the flat streaming kernel), 1 = strided, 2 = flat without the compact LDS layout, 4 = matrix-core
  * kernel whenever the inverses are shared (any number of subdomains); "apply_span" places per workgroup of that kernel
- * (multiples of 16; 0 = 32 / 64 / 128 by the number of subdomains); "md2_gy" column groups in flight per row block of the
+ * (multiples of 16; 0 = 32 / 64 / 96 / 128 by the number of subdomains); "md2_gy" column groups in flight per row block of the
  * Gram-Schmidt dot sweep (0 = by vector length), "md2_nch" its 512-row chunks per workgroup (2 or 4; default 4);
  * "gmres_hostwrite" 1 (default) = the solver's small kernel writes the three numbers of the host's lagged convergence test
  * into mapped pinned memory itself, 0 = an asynchronous copy per iteration;
