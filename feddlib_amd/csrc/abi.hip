@@ -27,8 +27,8 @@ int timing_flush(fedd_ctx* c) {
             FEDD_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
             s.total_ms += ms;
             if (!pr.cont) s.launches += 1;
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
+            c->ev_pool.push_back(pr.first);
+            c->ev_pool.push_back(pr.second);
         }
         s.pending.clear();
     }
@@ -112,6 +112,8 @@ extern "C" void fedd_ctx_destroy(fedd_ctx* c) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         (void)timing_flush(c);
+        for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+        c->ev_pool.clear();
         if (c->comm) ncclCommDestroy((ncclComm_t)c->comm);
         fedd::DevBuf<int32_t>* ib[] = {&c->d_conn, &c->d_flag, &c->d_n2e_ptr, &c->d_n2e, &c->d_rowptr,
                                        &c->d_colind, &c->d_isdir, &c->d_node_bin, &c->d_bin_ptr,
@@ -762,6 +764,16 @@ extern "C" int fedd_timing_enable(fedd_ctx* c, int on) {
     FEDD_CHECK(on >= 0 && on <= 1024, "fedd_timing_enable: %d", on);
     c->timing = on != 0;
     c->timing_stride = on > 1 ? on : 1;
+    // the events of the timed launches, created here rather than inside the region the caller is about to time
+    // (ScopedTimer::take falls back to creating one when the pool runs dry)
+    if (on) {
+        (void)hipSetDevice(c->device);
+        while (c->ev_pool.size() < 4096) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            c->ev_pool.push_back(e);
+        }
+    }
     return 0;
 }
 

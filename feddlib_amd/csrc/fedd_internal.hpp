@@ -318,6 +318,7 @@ struct fedd_ctx {
     bool timing = false;
     int timing_stride = 1;
     fedd::TimerSlot timers[FEDD_T_COUNT];
+    std::vector<hipEvent_t> ev_pool;            // timer events waiting for reuse (ScopedTimer::take, timing_flush)
 };
 
 namespace fedd {
@@ -341,9 +342,18 @@ struct ScopedTimer {
             const int64_t k = c->timers[id].seen++;
             if (per_iteration && !block_sweeps && c->timing_stride > 1 && k % c->timing_stride != 0) return;
             sampled = true;
-            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
-                (void)hipEventRecord(a, c->stream);
+            if (take(&a) && take(&b)) (void)hipEventRecord(a, c->stream);
         }
+    }
+    // events come from the context's pool (timing_flush returns them): creating a pair per timed launch cost about 2 ms of
+    // host time per 100 ms step -- inside the timed region of the bench
+    bool take(hipEvent_t* e) {
+        if (!c->ev_pool.empty()) {
+            *e = c->ev_pool.back();
+            c->ev_pool.pop_back();
+            return true;
+        }
+        return hipEventCreate(e) == hipSuccess;
     }
     // algorithmic bytes of this launch (counted when the launch is timed)
     void bytes(double nbytes) {
@@ -360,8 +370,7 @@ struct ScopedTimer {
     void resume() {
         if (c->timing && sampled && !a) {
             cont = true;
-            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
-                (void)hipEventRecord(a, c->stream);
+            if (take(&a) && take(&b)) (void)hipEventRecord(a, c->stream);
         }
     }
     ~ScopedTimer() { stop(); }
