@@ -1142,12 +1142,12 @@ __global__ __launch_bounds__(256) void k_ss_pass1(double* __restrict__ Sx, Off3 
 template <int S>
 __global__ __launch_bounds__(256) void k_ss_pass2(double* __restrict__ Sx, Off o, Off3 o3, int k, int sa_req, int m, double tol,
                                                   int32_t* __restrict__ d_sa, double* __restrict__ host_out) {
-    extern __shared__ double dyn[];   // hc[m+2] | lcs[m] | lsn[m]
+    extern __shared__ double dyn[];   // hc[S][m+2] | lcs[m] | lsn[m]
     __shared__ double G[S][S], A[S][S], W[S][S], R2[S][S], R2i[S][S], R1[S][S], R1i[S][S], Rc[S][S], Rci[S][S];
     __shared__ double gd[S], th[S], dd[S];
     __shared__ int s_sa;
     double* hc = dyn;
-    double* lcs = hc + (m + 2);
+    double* lcs = hc + (size_t)S * (m + 2);
     double* lsn = lcs + m;
     const int tid = threadIdx.x, ldh = m + 1;
     const double* P = Sx + o3.P;
@@ -1239,36 +1239,57 @@ __global__ __launch_bounds__(256) void k_ss_pass2(double* __restrict__ Sx, Off o
         }
     }
     __syncthreads();
-    // Givens: columns k-1 .. k-1+ncolH-1, one after the other (the chain of rotations is sequential)
+    // Givens.  The rotations of the earlier columns (q < k - 1) are applied to all new columns at once, a lane per column (each
+    // chain is sequential in q, the columns are independent); then lane 0 runs the triangular rest -- the rotations the block
+    // itself creates -- column by column.  Per column the same operations in the same order as one chain after the other
+    // (which took 16 x k dependent LDS steps on one lane: 67 of the kernel's 95 us at k ~ 60).
     const int ncolH = brk ? 1 : sa;
     for (int i = 0; i < ncolH; ++i) {
         const int jj = k - 1 + i;
-        for (int q = tid; q <= jj + 1; q += 256) hc[q] = Hraw[(int64_t)jj * ldh + q];
-        __syncthreads();
-        if (tid == 0) {
-            for (int q = 0; q < jj; ++q) {
-                const double a = lcs[q] * hc[q] + lsn[q] * hc[q + 1];
-                hc[q + 1] = -lsn[q] * hc[q] + lcs[q] * hc[q + 1];
-                hc[q] = a;
+        double* hci = hc + (size_t)i * (m + 2);
+        for (int q = tid; q <= jj + 1; q += 256) hci[q] = Hraw[(int64_t)jj * ldh + q];
+    }
+    __syncthreads();
+    if (tid < ncolH) {
+        double* hci = hc + (size_t)tid * (m + 2);
+        for (int q = 0; q < k - 1; ++q) {
+            const double a = lcs[q] * hci[q] + lsn[q] * hci[q + 1];
+            hci[q + 1] = -lsn[q] * hci[q] + lcs[q] * hci[q + 1];
+            hci[q] = a;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 0; i < ncolH; ++i) {
+            const int jj = k - 1 + i;
+            double* hci = hc + (size_t)i * (m + 2);
+            for (int q = k - 1; q < jj; ++q) {
+                const double a = lcs[q] * hci[q] + lsn[q] * hci[q + 1];
+                hci[q + 1] = -lsn[q] * hci[q] + lcs[q] * hci[q + 1];
+                hci[q] = a;
             }
-            const double d = hypot(hc[jj], hc[jj + 1]);
-            const double cj = d > 0 ? hc[jj] / d : 1.0, sj = d > 0 ? hc[jj + 1] / d : 0.0;
+            const double d = hypot(hci[jj], hci[jj + 1]);
+            const double cj = d > 0 ? hci[jj] / d : 1.0, sj = d > 0 ? hci[jj + 1] / d : 0.0;
             lcs[jj] = cj;
             lsn[jj] = sj;
             Sx[o.cs + jj] = cj;
             Sx[o.sn + jj] = sj;
-            hc[jj] = d;
-            hc[jj + 1] = 0.0;
+            hci[jj] = d;
+            hci[jj + 1] = 0.0;
             const double gj = Sx[o.g + jj];
             Sx[o.g + jj + 1] = -sj * gj;
             Sx[o.g + jj] = cj * gj;
             Sx[o3.res + i] = fabs(sj * gj);
         }
-        __syncthreads();
-        double* H = Sx + o.H + (int64_t)jj * ldh;
-        for (int q = tid; q <= jj + 1; q += 256) H[q] = hc[q];
-        __syncthreads();
     }
+    __syncthreads();
+    for (int i = 0; i < ncolH; ++i) {
+        const int jj = k - 1 + i;
+        const double* hci = hc + (size_t)i * (m + 2);
+        double* H = Sx + o.H + (int64_t)jj * ldh;
+        for (int q = tid; q <= jj + 1; q += 256) H[q] = hci[q];
+    }
+    __syncthreads();
     if (tid == 0) {
         d_sa[0] = sa;
         Sx[o.misc + 4] = (double)sa;
@@ -1428,6 +1449,12 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     const dim3 gn((unsigned)((n + 255) / 256)), blk(256);
     hipStream_t st = c->stream;
     const double chol_tol = c->gmres_chol_tol;
+    // k_ss_pass2 keeps the S new Hessenberg columns in dynamic LDS (beside 18 KB of static block matrices): long restart cycles
+    // go beyond the 64 KB a kernel gets without asking
+    const size_t pass2_lds = (size_t)(S * (m + 2) + 2 * m) * sizeof(double);
+    FEDD_CHECK(pass2_lds <= 128 * 1024, "gmres (s-step): restart length %d with blocks of %d vectors exceeds the LDS of the block kernel", m, S);
+    if (pass2_lds > 40 * 1024)
+        FEDD_HIP(hipFuncSetAttribute((const void*)k_ss_pass2<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass2_lds));
 
     auto norm2_into = [&](const double* v, double* out) -> int {
         hipLaunchKernelGGL(k_multidot, dim3(nblk, 1), blk, 0, st, v, ldv, n, 0, v, c->d_part.p, nblk, (const int32_t*)nullptr);
@@ -1602,7 +1629,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
                 hipLaunchKernelGGL(k_reduce_cols, dim3((k + sa) * S), blk, 0, st, (const double*)c->d_part.p, Sx + o3.P, nblkd,
                                    (const int32_t*)nullptr);
                 FEDD_TRY(allreduce_sum(c, Sx + o3.P, (k + sa) * S));
-                hipLaunchKernelGGL(k_ss_pass2<S>, dim3(1), blk, (size_t)(3 * m + 2) * sizeof(double), st, Sx, o, o3, k, sa, m,
+                hipLaunchKernelGGL(k_ss_pass2<S>, dim3(1), blk, pass2_lds, st, Sx, o, o3, k, sa, m,
                                    chol_tol, d_sa, hout_dev);
                 if (!hout_dev)
                     FEDD_HIP(hipMemcpyAsync(hout, Sx + o.misc + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1777,6 +1804,9 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
         c->gmres_s_used = c->gmres_s;
         // (the constrained solves run monomial blocks of at most eight vectors: the 8-column kernels)
         if (c->gm_mask && c->gmres_s > 8) return gmres_solve_sstep<8>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
+        // (cycles of more than 800 vectors: the 16-column block kernel's LDS image of its new Hessenberg columns does not fit)
+        if (c->gmres_s > 8 && std::min(restart, max_it) > 800)
+            return gmres_solve_sstep<8>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
         if (c->gmres_s <= 4) return gmres_solve_sstep<4>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
         if (c->gmres_s <= 8) return gmres_solve_sstep<8>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
         return gmres_solve_sstep<16>(c, d_b, d_x, rtol, max_it, restart, use_prec, its_out, relres_out);
