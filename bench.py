@@ -284,7 +284,7 @@ def extra_cfg5_share(capi, dev, a):
             nr, _, nnz = c.csr_sizes()
             si = c.spmv_info()
             ms, nl = tm["spmv"]
-            byt = 12.0 * si["nnz_streamed"] + 20.0 * nr if not si.get("column_patterns") else \
+            byt = (8.0 + si.get("column_index_bytes", 4)) * si["nnz_streamed"] + 20.0 * nr if not si.get("column_patterns") else \
                 8.0 * si["nnz_streamed"] + 22.0 * nr + 4.0 * si["nnz_streamed"] * si["rows_with_explicit_columns"] / max(nr, 1)
             e["spmv"] = {"ms_per_launch": ms / max(nl, 1), "bytes_streamed": byt, "GBs": byt / (ms / max(nl, 1)) / 1e6,
                          "frac_hbm_peak": byt / (ms / max(nl, 1)) / 1e6 / HBM_PEAK_GBS, "nnz": si,
@@ -452,7 +452,7 @@ def main():
         column patterns (fedd_spmv_patterns) a 2-byte pattern id per row replaces the column ids of the rows that have one"""
         if si.get("column_patterns"):
             return 8.0 * si["nnz_streamed"] + 22.0 * nr + 4.0 * si["nnz_streamed"] * si["rows_with_explicit_columns"] / max(nr, 1)
-        return 12.0 * si["nnz_streamed"] + 20.0 * nr
+        return (8.0 + si.get("column_index_bytes", 4)) * si["nnz_streamed"] + 20.0 * nr      # (16-bit column offsets: 10 B per entry)
 
     def kernel_table(tm, m, nr, nnz, info):
         # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md section 6), this rank's share

@@ -578,6 +578,14 @@ extern "C" int fedd_spmv_patterns(fedd_ctx* c, int64_t* n_patterns, int64_t* n_r
     return 0;
 }
 
+extern "C" int fedd_spmv_col_bytes(fedd_ctx* c, int* bytes_per_column_index) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern && bytes_per_column_index, "fedd_spmv_col_bytes: no matrix / null output");
+    const bool pat = c->cs_valid && c->cs_npat > 0 && c->spmv_pattern;
+    *bytes_per_column_index = pat ? 0 : (c->cs_valid && c->cs_col16 ? 2 : 4);
+    return 0;
+}
+
 extern "C" int fedd_read_bandwidth(fedd_ctx* c, int64_t bytes, int reps, double* gb_per_s) {
     NEED_DEVICE(c);
     FEDD_CHECK(bytes >= (1 << 20) && reps > 0 && gb_per_s, "fedd_read_bandwidth: bytes %lld reps %d", (long long)bytes, reps);
@@ -719,6 +727,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "apply_span") c->apply_span = (int)value;
     else if (k == "gdsw_block") c->gdsw_block = value != 0.0;
     else if (k == "multi_ch") c->multi_ch = (int)value;
+    else if (k == "spmv_col16") { c->spmv_col16 = value != 0.0; c->cs_valid = false; }
     else if (k == "pat_hash") c->pat_hash = value != 0.0;
     else if (k == "md2_gy") c->md2_gy = (int)value;
     else if (k == "gmres_hostwrite") c->h_pinned_dev = value != 0 ? c->h_pinned_map : nullptr;

@@ -198,6 +198,10 @@ struct fedd_ctx {
     int64_t cs_nnz = 0;
     int32_t cs_tot32 = 0;
     fedd::DevBuf<int32_t> d_cs_rowptr, d_cs_col, d_cs_rows, d_cs_wincnt;
+    fedd::DevBuf<uint16_t> d_cs_col16;          // 16-bit column offsets of the compacted stream (k_cs_col16), d_cs_wbase their bases per window
+    fedd::DevBuf<int32_t> d_cs_wbase;
+    bool cs_col16 = false;
+    int spmv_col16 = 1;                         // option "spmv_col16": 16-bit columns in the per-entry window SpMV where the windows allow it
     fedd::DevBuf<double> d_cs_val;
     int spmv_pattern = 1;                       // option "spmv_pattern": rows that repeat their column offsets share a pattern (spmv.hip)
     int spmv_win_nu = 0;                        // option "spmv_win_nu": entries per lane of k_spmv_win on the compacted stream (4 ... 8; 0 = by row length)

@@ -122,11 +122,15 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__
 // with 1 / 2 lanes per row (376 -> 386 / 391 us at 214^3): the gathers are not what limits it; in real traffic
 // (2.14 GB per launch, x fetched three times) the kernel runs at 0.91 of the read ceiling.
 // NU = entries per lane: the window is 256 NU entries (8 = SP_CHUNK by default; option "spmv_win_nu" for the compacted stream).
-template <bool NT, int NU = SP_CHUNK / 256>
+// C16: the columns as 16-bit offsets from the smallest column of the entry's own window (col16, wbase; k_cs_col16): 10 instead
+// of 12 bytes per entry wherever a window's columns span less than 65536 (every mesh numbered with some locality)
+template <bool NT, int NU = SP_CHUNK / 256, bool C16 = false>
 __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                   const double* __restrict__ val, const double* __restrict__ x,
                                                   double* __restrict__ y, const int32_t* __restrict__ block_row,
-                                                  int32_t nb, int32_t nnz, int32_t ovh, SpmvEpi epi) {
+                                                  int32_t nb, int32_t nnz, int32_t ovh, SpmvEpi epi,
+                                                  const uint16_t* __restrict__ col16 = nullptr,
+                                                  const int32_t* __restrict__ wbase = nullptr) {
     extern __shared__ double prod[];
     constexpr int CH = 256 * NU;
     const int tid = threadIdx.x;
@@ -134,20 +138,27 @@ __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ ro
     const int32_t lb = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
     const int32_t R0 = block_row[lb], R1 = block_row[lb + 1];
     const int32_t base = lb * CH, last = nnz - 1;
+    int32_t cb0 = 0, cb1 = 0;       // column bases of this window and of the next one (the overhang's entries belong to it)
+    if (C16) {
+        cb0 = wbase[lb];
+        cb1 = wbase[min(lb + 1, nb - 1)];
+    }
     double v[NU + 1];
     int32_t cc[NU + 1];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int32_t idx = min(base + tid + u * 256, last);
         v[u] = NT ? __builtin_nontemporal_load(val + idx) : val[idx];
-        cc[u] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
+        if (C16) cc[u] = (idx >= base + CH ? cb1 : cb0) + (int32_t)(NT ? __builtin_nontemporal_load(col16 + idx) : col16[idx]);
+        else cc[u] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
     }
     v[NU] = 0.0;
     cc[NU] = 0;
     if (tid < ovh) {   // the overhang: tail of the last row that starts inside the window
         const int32_t idx = min(base + CH + tid, last);
         v[NU] = NT ? __builtin_nontemporal_load(val + idx) : val[idx];
-        cc[NU] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
+        if (C16) cc[NU] = (idx >= base + CH ? cb1 : cb0) + (int32_t)(NT ? __builtin_nontemporal_load(col16 + idx) : col16[idx]);
+        else cc[NU] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
     }
     // row bounds of the lane's first TWO rows, requested ahead of the gathers: with the compacted stream (7 entries
     // per interior row) a window holds ~290 rows, so the second trip of the row phase is the normal case and
@@ -268,6 +279,38 @@ __global__ __launch_bounds__(256) void k_cs_fill(const int32_t* __restrict__ row
         }
     }
     for (int32_t r = R0 + tid; r < R1; r += 256) cs_rowptr[r] = wbase + pre[rowptr[r] - lo];
+}
+
+// 16-bit columns of the compacted stream for k_spmv_win<.., C16>: window lb (CH entries of the stream) takes the smallest column
+// among its entries as base; flag <- 1 if some window spans 65536 columns or more (the stream then keeps its 32-bit columns)
+__global__ __launch_bounds__(256) void k_cs_col16(const int32_t* __restrict__ col, int32_t total, int32_t CH,
+                                                  int32_t* __restrict__ wbase, uint16_t* __restrict__ col16, int32_t* __restrict__ flag) {
+    __shared__ int32_t smin[4], smax[4];
+    const int tid = threadIdx.x;
+    const int32_t lo = blockIdx.x * CH, hi = min(total, lo + CH);
+    int32_t mn = 0x7fffffff, mx = 0;
+    for (int32_t i = lo + tid; i < hi; i += 256) {
+        const int32_t cidx = col[i];
+        mn = min(mn, cidx);
+        mx = max(mx, cidx);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = min(mn, __shfl_xor(mn, off, 64));
+        mx = max(mx, __shfl_xor(mx, off, 64));
+    }
+    if ((tid & 63) == 0) {
+        smin[tid >> 6] = mn;
+        smax[tid >> 6] = mx;
+    }
+    __syncthreads();
+    mn = min(min(smin[0], smin[1]), min(smin[2], smin[3]));
+    mx = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+    if (lo >= hi) mn = 0;
+    if (tid == 0) {
+        wbase[blockIdx.x] = mn;
+        if (lo < hi && mx - mn > 65535) *flag = 1;
+    }
+    for (int32_t i = lo + tid; i < hi; i += 256) col16[i] = (uint16_t)(col[i] - mn);
 }
 
 // Read-only streaming calibration (fedd_read_bandwidth): sums `n2` double2 with 16-byte loads, four independent
@@ -582,6 +625,21 @@ static int spmv_compact_build(fedd_ctx* c) {
     FEDD_TRY(c->d_cs_rows.ensure((size_t)nbc + 1));
     hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nbc + 1 + 255) / 256)), dim3(256), 0, c->stream,
                        (const int32_t*)c->d_cs_rowptr.p, n, nbc, c->d_cs_rows.p, 256 * c->cs_win_nu);
+    // 16-bit columns for the per-entry window kernel (option "spmv_col16"; decided by the data: every window's column span)
+    c->cs_col16 = false;
+    if (c->spmv_col16 && total > 0) {
+        FEDD_TRY(c->d_cs_col16.ensure((size_t)total + 4096 + 8));
+        FEDD_TRY(c->d_cs_wbase.ensure((size_t)nbc + 1));
+        FEDD_TRY(c->d_flags.ensure(16));
+        int32_t* flag = c->d_flags.p + 7;
+        FEDD_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), c->stream));
+        hipLaunchKernelGGL(k_cs_col16, dim3((unsigned)nbc), dim3(256), 0, c->stream, (const int32_t*)c->d_cs_col.p, (int32_t)total,
+                           256 * c->cs_win_nu, c->d_cs_wbase.p, c->d_cs_col16.p, flag);
+        int32_t hflag = 1;
+        FEDD_HIP(hipMemcpyAsync(&hflag, flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        c->cs_col16 = hflag == 0;
+    }
     // column patterns (see k_spmv_pat)
     c->cs_npat = 0;
     // (matrices that fit the Infinity Cache keep the per-entry kernel -- measured: 100^3 cells 20.5 us against 25 us --,
@@ -695,9 +753,16 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
 #undef SPMV_PAT1
         } else {
 #define SPMV_WIN(NT_, NU_)                                                                                                       \
-    hipLaunchKernelGGL((k_spmv_win<NT_, NU_>), dim3((unsigned)nbc), dim3(256), lds, c->stream, (const int32_t*)c->d_cs_rowptr.p, \
-                       (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, x, d_y_owned,                               \
-                       (const int32_t*)c->d_cs_rows.p, nbc, (int32_t)c->cs_nnz, ovh, epi)
+    if (c->cs_col16)                                                                                                             \
+        hipLaunchKernelGGL((k_spmv_win<NT_, NU_, true>), dim3((unsigned)nbc), dim3(256), lds, c->stream,                         \
+                           (const int32_t*)c->d_cs_rowptr.p, (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, x,     \
+                           d_y_owned, (const int32_t*)c->d_cs_rows.p, nbc, (int32_t)c->cs_nnz, ovh, epi,                         \
+                           (const uint16_t*)c->d_cs_col16.p, (const int32_t*)c->d_cs_wbase.p);                                   \
+    else                                                                                                                         \
+        hipLaunchKernelGGL((k_spmv_win<NT_, NU_>), dim3((unsigned)nbc), dim3(256), lds, c->stream, (const int32_t*)c->d_cs_rowptr.p, \
+                           (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, x, d_y_owned,                            \
+                           (const int32_t*)c->d_cs_rows.p, nbc, (int32_t)c->cs_nnz, ovh, epi, (const uint16_t*)nullptr,           \
+                           (const int32_t*)nullptr)
 #define SPMV_WIN_NU(NT_)                 \
     switch (wnu) {                       \
         case 4: SPMV_WIN(NT_, 4); break; \

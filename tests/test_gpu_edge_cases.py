@@ -305,3 +305,69 @@ def test_spmv_column_patterns_fall_back_on_an_unstructured_mesh(fedd_lib, ctx):
     finally:
         ctx.set_option("spmv_pattern", 1)
 
+
+
+@pytest.mark.parametrize("dim,M,dofs", [(3, 20, 1), (2, 70, 1), (3, 10, 3)])
+def test_spmv_sixteen_bit_columns_give_the_same_bits(fedd_lib, ctx, dim, M, dofs):
+    """option "spmv_col16" (default on): the per-entry window kernel reads its column indices as 16-bit offsets from a base per
+    window of the stream -- the same entries in the same order, so y is bit for bit the y of the 32-bit stream"""
+    m = fedd_lib.structured_mesh(dim, 1, M)
+    ctx.mesh_set_dict(m)
+    if dofs == 1:
+        ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+        ctx.assemble(fedd_lib.FORM_LAPLACE)
+        ctx.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+    else:
+        ctx.pattern_build(dofs, fedd_lib.BLOCK_FULL)
+        ctx.assemble(fedd_lib.FORM_LINELAS, [1.5, 1.0])
+        ctx.dirichlet([2], np.zeros(dofs))
+    x = np.random.default_rng(17).standard_normal(ctx.csr_sizes()[0])
+    ctx.set_option("spmv_exact_public", 0)     # fedd_spmv = the solver's stream in this test
+    try:
+        ys = {}
+        for on in (0, 1):
+            ctx.set_option("spmv_col16", on)
+            for nu in (0, 4, 6, 8):
+                ctx.set_option("spmv_win_nu", nu)
+                ys[(on, nu)] = ctx.spmv(x)
+                assert ctx.spmv_info()["column_index_bytes"] == (2 if on else 4)
+        for key, y in ys.items():
+            assert np.array_equal(y, ys[(0, 0)]), key
+    finally:
+        ctx.set_option("spmv_col16", 1)
+        ctx.set_option("spmv_win_nu", 0)
+        ctx.set_option("spmv_exact_public", 1)
+
+
+def test_spmv_sixteen_bit_columns_are_not_taken_when_a_window_spans_too_many_columns(fedd_lib, ctx):
+    """a row that couples dof 0 with the last dof of a 70 000-row system: its window spans more than 65 535 columns, the stream
+    keeps 32-bit indices (decided from the data, per matrix) and the product is unchanged"""
+    M = 42      # 43^3 = 79 507 nodes
+    m = fedd_lib.structured_mesh(3, 1, M)
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+    ctx.assemble(fedd_lib.FORM_LAPLACE)
+    x = np.random.default_rng(18).standard_normal(ctx.csr_sizes()[0])
+    ctx.set_option("spmv_exact_public", 0)
+    try:
+        y = ctx.spmv(x)
+        # the natural numbering of the cube couples nodes 43^2 apart: windows of 2048 entries span ~2 * 1849 + a few hundred columns
+        assert ctx.spmv_info()["column_index_bytes"] == 2
+        # renumbered so that neighbours lie far apart: every second node sent to the far end
+        n = m["xyz"].shape[0]
+        perm = np.concatenate([np.arange(0, n, 2), np.arange(1, n, 2)])       # new id -> old id
+        inv = np.empty(n, dtype=np.int64)
+        inv[perm] = np.arange(n)
+        m2 = dict(m)
+        m2["xyz"] = m["xyz"][perm]
+        for key in ("gid_rep", "flag_rep", "gid_uni", "flag_uni"):
+            m2[key] = m[key][perm]
+        m2["conn"] = inv[m["conn"]].astype(m["conn"].dtype)
+        ctx.mesh_set_dict(m2)
+        ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+        ctx.assemble(fedd_lib.FORM_LAPLACE)
+        y2 = ctx.spmv(x[perm])
+        assert ctx.spmv_info()["column_index_bytes"] == 4
+        np.testing.assert_allclose(y2, y[perm], rtol=0, atol=1e-12 * np.abs(y).max())
+    finally:
+        ctx.set_option("spmv_exact_public", 1)
