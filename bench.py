@@ -452,7 +452,9 @@ def main():
         column patterns (fedd_spmv_patterns) a 2-byte pattern id per row replaces the column ids of the rows that have one"""
         if si.get("column_patterns"):
             return 8.0 * si["nnz_streamed"] + 22.0 * nr + 4.0 * si["nnz_streamed"] * si["rows_with_explicit_columns"] / max(nr, 1)
-        return (8.0 + si.get("column_index_bytes", 4)) * si["nnz_streamed"] + 20.0 * nr      # (16-bit column offsets: 10 B per entry)
+        # (16-bit column offsets: 10 B per entry, 12 for the entries of the windows that keep 32-bit indices)
+        wide = si.get("entries_with_32bit_columns", 0) if si.get("column_index_bytes", 4) == 2 else 0
+        return (8.0 + si.get("column_index_bytes", 4)) * si["nnz_streamed"] + 2.0 * wide + 20.0 * nr
 
     def kernel_table(tm, m, nr, nnz, info):
         # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md section 6), this rank's share

@@ -86,7 +86,7 @@ SIGNATURES = {
     "fedd_schwarz_sizes": [C.c_void_p, _i64p, _i64p],
     "fedd_schwarz_conforming": [C.c_void_p, _i64p],
     "fedd_spmv_patterns": [C.c_void_p, _i64p, _i64p],
-    "fedd_spmv_col_bytes": [C.c_void_p, C.POINTER(C.c_int)],
+    "fedd_spmv_col_bytes": [C.c_void_p, C.POINTER(C.c_int), _i64p],
     "fedd_gmres": [C.c_void_p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int, _ip, _f64p],
     "fedd_set_option": [C.c_void_p, C.c_char_p, C.c_double],
     "fedd_timing_enable": [C.c_void_p, C.c_int],
@@ -470,10 +470,10 @@ class Context:
         _chk(self._L.fedd_spmv_info(self._h, C.byref(a), C.byref(b)))
         p, e = C.c_int64(), C.c_int64()
         _chk(self._L.fedd_spmv_patterns(self._h, C.byref(p), C.byref(e)))
-        cb = C.c_int()
-        _chk(self._L.fedd_spmv_col_bytes(self._h, C.byref(cb)))
+        cb, wide = C.c_int(), C.c_int64()
+        _chk(self._L.fedd_spmv_col_bytes(self._h, C.byref(cb), C.byref(wide)))
         return dict(nnz_pattern=a.value, nnz_streamed=b.value, column_patterns=p.value, rows_with_explicit_columns=e.value,
-                    column_index_bytes=cb.value)
+                    column_index_bytes=cb.value, entries_with_32bit_columns=wide.value)
 
     def spmv_device(self, reps):
         _chk(self._L.fedd_spmv_device(self._h, reps))

@@ -578,11 +578,20 @@ extern "C" int fedd_spmv_patterns(fedd_ctx* c, int64_t* n_patterns, int64_t* n_r
     return 0;
 }
 
-extern "C" int fedd_spmv_col_bytes(fedd_ctx* c, int* bytes_per_column_index) {
+extern "C" int fedd_spmv_col_bytes(fedd_ctx* c, int* bytes_per_column_index, int64_t* entries_with_32bit_columns) {
     NEED_DEVICE(c);
     FEDD_CHECK(c->have_pattern && bytes_per_column_index, "fedd_spmv_col_bytes: no matrix / null output");
     const bool pat = c->cs_valid && c->cs_npat > 0 && c->spmv_pattern;
-    *bytes_per_column_index = pat ? 0 : (c->cs_valid && c->cs_col16 ? 2 : 4);
+    const bool c16 = c->cs_valid && c->cs_col16 && !pat;
+    *bytes_per_column_index = pat ? 0 : (c16 ? 2 : 4);
+    if (entries_with_32bit_columns) {
+        int32_t wide = 0;
+        if (c16) {
+            FEDD_HIP(hipMemcpyAsync(&wide, c->d_flags.p + 7, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            FEDD_HIP(hipStreamSynchronize(c->stream));
+        }
+        *entries_with_32bit_columns = pat ? 0 : (c16 ? (int64_t)wide : (c->cs_valid ? c->cs_nnz : c->nnz));
+    }
     return 0;
 }
 

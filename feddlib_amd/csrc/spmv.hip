@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int32_t* __restrict__
 // (2.14 GB per launch, x fetched three times) the kernel runs at 0.91 of the read ceiling.
 // NU = entries per lane: the window is 256 NU entries (8 = SP_CHUNK by default; option "spmv_win_nu" for the compacted stream).
 // C16: the columns as 16-bit offsets from the smallest column of the entry's own window (col16, wbase; k_cs_col16): 10 instead
-// of 12 bytes per entry wherever a window's columns span less than 65536 (every mesh numbered with some locality)
+// of 12 bytes per entry in every window whose columns span less than 65536 (every mesh numbered with some locality; the windows
+// that reach ghost columns on several ranks, or far neighbours, keep 32-bit indices: wbase < 0)
 template <bool NT, int NU = SP_CHUNK / 256, bool C16 = false>
 __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                   const double* __restrict__ val, const double* __restrict__ x,
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ ro
     for (int u = 0; u < NU; ++u) {
         const int32_t idx = min(base + tid + u * 256, last);
         v[u] = NT ? __builtin_nontemporal_load(val + idx) : val[idx];
-        if (C16) cc[u] = (idx >= base + CH ? cb1 : cb0) + (int32_t)(NT ? __builtin_nontemporal_load(col16 + idx) : col16[idx]);
+        // (cb0 < 0: this window's columns span too much for 16 bits, its entries keep their 32-bit indices; uniform over the workgroup)
+        if (C16 && cb0 >= 0) cc[u] = cb0 + (int32_t)(NT ? __builtin_nontemporal_load(col16 + idx) : col16[idx]);
         else cc[u] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
     }
     v[NU] = 0.0;
@@ -157,7 +159,8 @@ __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ ro
     if (tid < ovh) {   // the overhang: tail of the last row that starts inside the window
         const int32_t idx = min(base + CH + tid, last);
         v[NU] = NT ? __builtin_nontemporal_load(val + idx) : val[idx];
-        if (C16) cc[NU] = (idx >= base + CH ? cb1 : cb0) + (int32_t)(NT ? __builtin_nontemporal_load(col16 + idx) : col16[idx]);
+        const int32_t cbo = idx >= base + CH ? cb1 : cb0;       // (the clamp at the end of the stream stays inside this window)
+        if (C16 && cbo >= 0) cc[NU] = cbo + (int32_t)(NT ? __builtin_nontemporal_load(col16 + idx) : col16[idx]);
         else cc[NU] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
     }
     // row bounds of the lane's first TWO rows, requested ahead of the gathers: with the compacted stream (7 entries
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void k_cs_fill(const int32_t* __restrict__ row
 }
 
 // 16-bit columns of the compacted stream for k_spmv_win<.., C16>: window lb (CH entries of the stream) takes the smallest column
-// among its entries as base; flag <- 1 if some window spans 65536 columns or more (the stream then keeps its 32-bit columns)
+// among its entries as base, or -1 if it spans 65536 columns or more (its entries are then read from the 32-bit array; flag counts them)
 __global__ __launch_bounds__(256) void k_cs_col16(const int32_t* __restrict__ col, int32_t total, int32_t CH,
                                                   int32_t* __restrict__ wbase, uint16_t* __restrict__ col16, int32_t* __restrict__ flag) {
     __shared__ int32_t smin[4], smax[4];
@@ -305,12 +308,14 @@ __global__ __launch_bounds__(256) void k_cs_col16(const int32_t* __restrict__ co
     __syncthreads();
     mn = min(min(smin[0], smin[1]), min(smin[2], smin[3]));
     mx = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+    const bool wide = lo < hi && mx - mn > 65535;
     if (lo >= hi) mn = 0;
     if (tid == 0) {
-        wbase[blockIdx.x] = mn;
-        if (lo < hi && mx - mn > 65535) *flag = 1;
+        wbase[blockIdx.x] = wide ? -1 : mn;
+        if (wide) atomicAdd(flag, hi - lo);     // entries that keep 32-bit columns
     }
-    for (int32_t i = lo + tid; i < hi; i += 256) col16[i] = (uint16_t)(col[i] - mn);
+    if (!wide)
+        for (int32_t i = lo + tid; i < hi; i += 256) col16[i] = (uint16_t)(col[i] - mn);
 }
 
 // Read-only streaming calibration (fedd_read_bandwidth): sums `n2` double2 with 16-byte loads, four independent
@@ -635,10 +640,7 @@ static int spmv_compact_build(fedd_ctx* c) {
         FEDD_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), c->stream));
         hipLaunchKernelGGL(k_cs_col16, dim3((unsigned)nbc), dim3(256), 0, c->stream, (const int32_t*)c->d_cs_col.p, (int32_t)total,
                            256 * c->cs_win_nu, c->d_cs_wbase.p, c->d_cs_col16.p, flag);
-        int32_t hflag = 1;
-        FEDD_HIP(hipMemcpyAsync(&hflag, flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        FEDD_HIP(hipStreamSynchronize(c->stream));
-        c->cs_col16 = hflag == 0;
+        c->cs_col16 = true;     // (per window: nothing for the host to wait for; fedd_spmv_col_bytes reads the count when asked)
     }
     // column patterns (see k_spmv_pat)
     c->cs_npat = 0;

@@ -394,10 +394,12 @@ int fedd_timing_get_sampled(fedd_ctx* ctx, int timer, double* sampled_ms, int64_
  * n_rows_explicit = rows that keep explicit column indices. */
 int fedd_spmv_patterns(fedd_ctx* ctx, int64_t* n_patterns, int64_t* n_rows_explicit);
 /* bytes per column index of the solver's SpMV stream: 0 = column patterns in use (above), 2 = 16-bit offsets from a base per
- * window of the stream (option "spmv_col16", default 1: taken whenever every window's columns span less than 65536 -- any mesh
- * numbered with some locality; 10 instead of 12 bytes per entry), 4 = plain indices.  Replaces nothing in the reference (Tpetra's
- * local column indices are 32-bit, feddlib/core/LinearAlgebra/Matrix_def.hpp:88-92); a property of this library's stream. */
-int fedd_spmv_col_bytes(fedd_ctx* ctx, int* bytes_per_column_index);
+ * window of the stream (option "spmv_col16", default 1; 10 instead of 12 bytes per entry) in every window whose columns span less
+ * than 65536 -- any mesh numbered with some locality; entries_with_32bit_columns (nullable) = the entries of the windows that
+ * span more (ghost columns on several ranks, far neighbours) and keep plain indices --, 4 = plain indices throughout.  Replaces
+ * nothing in the reference (Tpetra's local column indices are 32-bit, feddlib/core/LinearAlgebra/Matrix_def.hpp:88-92); a
+ * property of this library's stream. */
+int fedd_spmv_col_bytes(fedd_ctx* ctx, int* bytes_per_column_index, int64_t* entries_with_32bit_columns);
 
 int fedd_read_bandwidth(fedd_ctx* ctx, int64_t bytes, int reps, double* gb_per_s);
 

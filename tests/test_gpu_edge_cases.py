@@ -339,9 +339,9 @@ def test_spmv_sixteen_bit_columns_give_the_same_bits(fedd_lib, ctx, dim, M, dofs
         ctx.set_option("spmv_exact_public", 1)
 
 
-def test_spmv_sixteen_bit_columns_are_not_taken_when_a_window_spans_too_many_columns(fedd_lib, ctx):
-    """a row that couples dof 0 with the last dof of a 70 000-row system: its window spans more than 65 535 columns, the stream
-    keeps 32-bit indices (decided from the data, per matrix) and the product is unchanged"""
+def test_spmv_sixteen_bit_columns_are_not_taken_where_a_window_spans_too_many_columns(fedd_lib, ctx):
+    """a numbering that puts neighbours 40 000 rows apart: windows of the stream that span more than 65 535 columns keep their
+    32-bit indices (decided from the data, window by window), the others take the 16-bit offsets, and the product is unchanged"""
     M = 42      # 43^3 = 79 507 nodes
     m = fedd_lib.structured_mesh(3, 1, M)
     ctx.mesh_set_dict(m)
@@ -352,7 +352,8 @@ def test_spmv_sixteen_bit_columns_are_not_taken_when_a_window_spans_too_many_col
     try:
         y = ctx.spmv(x)
         # the natural numbering of the cube couples nodes 43^2 apart: windows of 2048 entries span ~2 * 1849 + a few hundred columns
-        assert ctx.spmv_info()["column_index_bytes"] == 2
+        info = ctx.spmv_info()
+        assert info["column_index_bytes"] == 2 and info["entries_with_32bit_columns"] == 0
         # renumbered so that neighbours lie far apart: every second node sent to the far end
         n = m["xyz"].shape[0]
         perm = np.concatenate([np.arange(0, n, 2), np.arange(1, n, 2)])       # new id -> old id
@@ -367,7 +368,11 @@ def test_spmv_sixteen_bit_columns_are_not_taken_when_a_window_spans_too_many_col
         ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
         ctx.assemble(fedd_lib.FORM_LAPLACE)
         y2 = ctx.spmv(x[perm])
-        assert ctx.spmv_info()["column_index_bytes"] == 4
+        info = ctx.spmv_info()
+        assert info["column_index_bytes"] == 2 and 0 < info["entries_with_32bit_columns"] <= info["nnz_streamed"]
         np.testing.assert_allclose(y2, y[perm], rtol=0, atol=1e-12 * np.abs(y).max())
+        ctx.set_option("spmv_col16", 0)
+        assert np.array_equal(ctx.spmv(x[perm]), y2) and ctx.spmv_info()["column_index_bytes"] == 4
+        ctx.set_option("spmv_col16", 1)
     finally:
         ctx.set_option("spmv_exact_public", 1)
