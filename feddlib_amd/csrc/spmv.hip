@@ -647,7 +647,10 @@ static int spmv_compact_build(fedd_ctx* c) {
     // (matrices that fit the Infinity Cache keep the per-entry kernel -- measured: 100^3 cells 20.5 us against 25 us --,
     // so the dictionary is not built for them; option value 2 forces it)
     const bool big = 12.0 * (double)total > 256.0 * 1024.0 * 1024.0 || c->spmv_pattern == 2;
-    if (c->spmv_pattern && total > 0 && big) {
+    // (rows longer than a pattern holds -- 16 entries; vector problems with full node blocks have 36 and more -- find none: the
+    // three passes over the stream that would establish that cost 3.7 ms at cfg 5's share, so they are skipped by the average)
+    const bool short_rows = total <= (int64_t)SPAT_L * std::max<int32_t>(n, 1);
+    if (c->spmv_pattern && total > 0 && big && short_rows) {
         FEDD_TRY(c->d_cs_hash.ensure((size_t)n + SPAT_TS));
         FEDD_TRY(c->d_cs_pati.ensure((size_t)n + 2 * SPAT_TS + SPAT_P * (SPAT_L + 1) + 16));
         FEDD_TRY(c->d_cs_pat.ensure((size_t)n + 1));
