@@ -150,18 +150,37 @@ __global__ __launch_bounds__(256) void k_spmv_win(const int32_t* __restrict__ ro
     for (int u = 0; u < NU; ++u) {
         const int32_t idx = min(base + tid + u * 256, last);
         v[u] = NT ? __builtin_nontemporal_load(val + idx) : val[idx];
-        // (cb0 < 0: this window's columns span too much for 16 bits, its entries keep their 32-bit indices; uniform over the workgroup)
-        if (C16 && cb0 >= 0) cc[u] = cb0 + (int32_t)(NT ? __builtin_nontemporal_load(col16 + idx) : col16[idx]);
-        else cc[u] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
+        // the 16-bit offset is requested unconditionally, with the value: its address depends on nothing.  (cb0 < 0: this window's
+        // columns span too much for 16 bits and its entries take their 32-bit indices -- a second, dependent load, on the rare
+        // path only; loading the offsets behind the test of cb0 put the base's latency in front of every gather: 26.8 -> 34 us
+        // at the share of cfg 3)
+        if (C16) {
+            const int32_t c16v = (int32_t)(NT ? __builtin_nontemporal_load(col16 + idx) : col16[idx]);
+            cc[u] = cb0 + c16v;
+        } else {
+            cc[u] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
+        }
+    }
+    if (C16 && cb0 < 0) {   // (uniform over the workgroup)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int32_t idx = min(base + tid + u * 256, last);
+            cc[u] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
+        }
     }
     v[NU] = 0.0;
     cc[NU] = 0;
     if (tid < ovh) {   // the overhang: tail of the last row that starts inside the window
         const int32_t idx = min(base + CH + tid, last);
         v[NU] = NT ? __builtin_nontemporal_load(val + idx) : val[idx];
-        const int32_t cbo = idx >= base + CH ? cb1 : cb0;       // (the clamp at the end of the stream stays inside this window)
-        if (C16 && cbo >= 0) cc[NU] = cbo + (int32_t)(NT ? __builtin_nontemporal_load(col16 + idx) : col16[idx]);
-        else cc[NU] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
+        if (C16) {
+            const int32_t cbo = idx >= base + CH ? cb1 : cb0;   // (the clamp at the end of the stream stays inside this window)
+            const int32_t c16v = (int32_t)(NT ? __builtin_nontemporal_load(col16 + idx) : col16[idx]);
+            cc[NU] = cbo + c16v;
+            if (cbo < 0) cc[NU] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
+        } else {
+            cc[NU] = NT ? __builtin_nontemporal_load(colind + idx) : colind[idx];
+        }
     }
     // row bounds of the lane's first TWO rows, requested ahead of the gathers: with the compacted stream (7 entries
     // per interior row) a window holds ~290 rows, so the second trip of the row phase is the normal case and
