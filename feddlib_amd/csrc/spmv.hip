@@ -649,18 +649,6 @@ static int spmv_compact_build(fedd_ctx* c) {
     FEDD_TRY(c->d_cs_rows.ensure((size_t)nbc + 1));
     hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nbc + 1 + 255) / 256)), dim3(256), 0, c->stream,
                        (const int32_t*)c->d_cs_rowptr.p, n, nbc, c->d_cs_rows.p, 256 * c->cs_win_nu);
-    // 16-bit columns for the per-entry window kernel (option "spmv_col16"; decided by the data: every window's column span)
-    c->cs_col16 = false;
-    if (c->spmv_col16 && total > 0) {
-        FEDD_TRY(c->d_cs_col16.ensure((size_t)total + 4096 + 8));
-        FEDD_TRY(c->d_cs_wbase.ensure((size_t)nbc + 1));
-        FEDD_TRY(c->d_flags.ensure(16));
-        int32_t* flag = c->d_flags.p + 7;
-        FEDD_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), c->stream));
-        hipLaunchKernelGGL(k_cs_col16, dim3((unsigned)nbc), dim3(256), 0, c->stream, (const int32_t*)c->d_cs_col.p, (int32_t)total,
-                           256 * c->cs_win_nu, c->d_cs_wbase.p, c->d_cs_col16.p, flag);
-        c->cs_col16 = true;     // (per window: nothing for the host to wait for; fedd_spmv_col_bytes reads the count when asked)
-    }
     // column patterns (see k_spmv_pat)
     c->cs_npat = 0;
     // (matrices that fit the Infinity Cache keep the per-entry kernel -- measured: 100^3 cells 20.5 us against 25 us --,
@@ -712,6 +700,19 @@ static int spmv_compact_build(fedd_ctx* c) {
             hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nbp + 1 + 255) / 256)), dim3(256), 0, c->stream,
                                (const int32_t*)c->d_cs_rowptr.p, n, nbp, c->d_cs_prows.p, 512 * c->cs_pat_nu);
         }
+    }
+    // 16-bit columns for the per-entry window kernel (option "spmv_col16"; decided by the data: every window's column span)
+    // (not for a stream that goes through the column patterns: k_spmv_pat reads no column of a row that has one)
+    c->cs_col16 = false;
+    if (c->spmv_col16 && total > 0 && c->cs_npat == 0) {
+        FEDD_TRY(c->d_cs_col16.ensure((size_t)total + 4096 + 8));
+        FEDD_TRY(c->d_cs_wbase.ensure((size_t)nbc + 1));
+        FEDD_TRY(c->d_flags.ensure(16));
+        int32_t* flag = c->d_flags.p + 7;
+        FEDD_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), c->stream));
+        hipLaunchKernelGGL(k_cs_col16, dim3((unsigned)nbc), dim3(256), 0, c->stream, (const int32_t*)c->d_cs_col.p, (int32_t)total,
+                           256 * c->cs_win_nu, c->d_cs_wbase.p, c->d_cs_col16.p, flag);
+        c->cs_col16 = true;     // (per window: nothing for the host to wait for; fedd_spmv_col_bytes reads the count when asked)
     }
     ts.stop();
     FEDD_HIP(hipGetLastError());
