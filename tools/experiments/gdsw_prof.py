@@ -7,7 +7,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from feddlib_amd import capi  # noqa: E402
 
-kind = capi.COARSE_GDSW if (len(sys.argv) > 1 and sys.argv[1] == "gdsw") else capi.COARSE_RGDSW
+kind = {"gdsw": capi.COARSE_GDSW, "q1": capi.COARSE_Q1}.get(sys.argv[1] if len(sys.argv) > 1 else "", capi.COARSE_RGDSW)
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 94
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 m = capi.structured_mesh(3, (1, 1, 1), [M] * 3, 0)
