@@ -94,10 +94,23 @@ constexpr int LDA_S = 68, LDB_S = 80;  // LDS leading dimensions: the fragment r
 __device__ __forceinline__ void mm64(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
                                      int64_t ldb, double* As, double* Bs, double4_t acc[2][2]) {
     const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e >> 6, cidx = e & 63;
-        As[r * LDA_S + cidx] = A[(int64_t)r * lda + cidx];
-        Bs[r * LDB_S + cidx] = B[(int64_t)r * ldb + cidx];
+    {
+        // all 32 loads of a lane in flight before the first store to LDS (a load -> store loop waited for memory sixteen times
+        // per tile: k_update 0.41 ms per step on the 6 591^2 coarse matrix of GDSW)
+        constexpr int U = NB * NB / 256;
+        double ra[U], rb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = tid + 256 * u, r = e >> 6, cidx = e & 63;
+            ra[u] = A[(int64_t)r * lda + cidx];
+            rb[u] = B[(int64_t)r * ldb + cidx];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = tid + 256 * u, r = e >> 6, cidx = e & 63;
+            As[r * LDA_S + cidx] = ra[u];
+            Bs[r * LDB_S + cidx] = rb[u];
+        }
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
@@ -146,9 +159,19 @@ __global__ __launch_bounds__(256) void k_panels(const double* __restrict__ Kall,
     const double* __restrict__ Dinv = Dall + (int64_t)bz * NB * NB;
     double* __restrict__ R = Rall + (int64_t)bz * NB * ld;
     double* __restrict__ Cp = Call + (int64_t)bz * NB * ld;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {
-        const int r = e >> 6, cidx = e & 63;
-        Cp[((int64_t)bj * NB + r) * NB + cidx] = K[((int64_t)bj * NB + r) * ld + (int64_t)kb * NB + cidx];
+    {
+        constexpr int U = NB * NB / 256;
+        double rc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = threadIdx.x + 256 * u, r = e >> 6, cidx = e & 63;
+            rc[u] = K[((int64_t)bj * NB + r) * ld + (int64_t)kb * NB + cidx];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = threadIdx.x + 256 * u, r = e >> 6, cidx = e & 63;
+            Cp[((int64_t)bj * NB + r) * NB + cidx] = rc[u];
+        }
     }
     if (bj == kb) return;
     double4_t acc[2][2];
@@ -171,9 +194,17 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ Kall, int64
     if (bi == kb) {
         const double* __restrict__ src = bj == kb ? Dinv : R + (int64_t)bj * NB;
         const int64_t lds = bj == kb ? NB : ld;
-        for (int e = threadIdx.x; e < NB * NB; e += 256) {
-            const int r = e >> 6, cidx = e & 63;
-            tile[(int64_t)r * ld + cidx] = src[(int64_t)r * lds + cidx];
+        constexpr int U = NB * NB / 256;
+        double rc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = threadIdx.x + 256 * u, r = e >> 6, cidx = e & 63;
+            rc[u] = src[(int64_t)r * lds + cidx];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = threadIdx.x + 256 * u, r = e >> 6, cidx = e & 63;
+            tile[(int64_t)r * ld + cidx] = rc[u];
         }
         return;
     }
