@@ -25,7 +25,7 @@ typedef double mr_d2 __attribute__((ext_vector_type(2)));
 // pair per row, so the sums do not depend on where the chunks fall.  Measured at cfg 5's share (2.57 M rows, 113.8 M entries): 0.72 ms
 // per sweep of sixteen columns (entries read per lane straight from memory: 1.16 ms; the three rows of a node block sharing their
 // gathers of X, entries again per lane: 1.18 ms; the same with the blocks' entries staged through LDS: 1.07 ms -- the gathered
-// bytes are not what costs)
+// bytes are not what costs; four or two lanes per row with 32 / 64 bytes gathered per lane and entry: 0.74 / 0.84 ms)
 constexpr int SPMM_CHUNK = 2048;
 __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                               const double* __restrict__ val, int64_t n_rows, const double* __restrict__ X,
