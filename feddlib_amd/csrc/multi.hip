@@ -45,9 +45,26 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
     for (int32_t cs = wb; cs < we; cs += SPMM_CHUNK) {
         const int32_t ce = min(cs + SPMM_CHUNK, we);
         if (cs != wb) __syncthreads();
-        for (int32_t q = cs + tid; q < ce; q += 256) {
-            sc[q - cs] = colind[q];
-            sv[q - cs] = val[q];
+        {
+            // every load of the chunk in flight before the first store to LDS (a load -> store loop waits for memory once per
+            // trip: 0.72 ms per sweep instead of the figure below)
+            constexpr int U = SPMM_CHUNK / 256;
+            int32_t rc[U];
+            double rv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int32_t q = cs + tid + 256 * u;
+                rc[u] = q < ce ? colind[q] : 0;
+                rv[u] = q < ce ? val[q] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int32_t q = cs + tid + 256 * u;
+                if (q < ce) {
+                    sc[q - cs] = rc[u];
+                    sv[q - cs] = rv[u];
+                }
+            }
         }
         __syncthreads();
         int32_t p = max(b, cs) - cs;
