@@ -222,7 +222,21 @@ constexpr int CS_OVH = 256;   // windowed SpMV is only used for rows of at most 
 __device__ __forceinline__ void cs_window_flags(const int32_t* __restrict__ rowptr, const double* __restrict__ val,
                                                 int32_t R0, int32_t R1, int32_t lo, int32_t len, double tol,
                                                 double* sval, uint8_t* sflag, int tid) {
-    for (int32_t j = tid; j < len; j += 256) sval[j] = __builtin_nontemporal_load(val + lo + j);
+    {
+        // (all loads of the window in flight before the first store to LDS: a load -> store loop waits for memory once per trip)
+        constexpr int U = (SP_CHUNK + CS_OVH + 255) / 256;
+        double rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int32_t j = tid + 256 * u;
+            rv[u] = j < len ? __builtin_nontemporal_load(val + lo + j) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int32_t j = tid + 256 * u;
+            if (j < len) sval[j] = rv[u];
+        }
+    }
     __syncthreads();
     for (int32_t r = R0 + tid; r < R1; r += 256) {
         const int32_t b = rowptr[r] - lo, e = rowptr[r + 1] - lo;
@@ -294,10 +308,21 @@ __global__ __launch_bounds__(256) void k_cs_fill(const int32_t* __restrict__ row
     }
     if (tid == 255) pre[len] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     __syncthreads();
-    for (int32_t j = tid; j < len; j += 256) {
-        if (sflag[j]) {
-            cs_val[wbase + pre[j]] = sval[j];
-            cs_col[wbase + pre[j]] = __builtin_nontemporal_load(colind + lo + j);
+    {
+        constexpr int U = (SP_CHUNK + CS_OVH + 255) / 256;
+        int32_t rc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int32_t j = tid + 256 * u;
+            rc[u] = (j < len && sflag[j]) ? __builtin_nontemporal_load(colind + lo + j) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int32_t j = tid + 256 * u;
+            if (j < len && sflag[j]) {
+                cs_val[wbase + pre[j]] = sval[j];
+                cs_col[wbase + pre[j]] = rc[u];
+            }
         }
     }
     for (int32_t r = R0 + tid; r < R1; r += 256) cs_rowptr[r] = wbase + pre[rowptr[r] - lo];
