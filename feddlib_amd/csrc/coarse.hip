@@ -573,13 +573,33 @@ __global__ __launch_bounds__(256) void k_gd_restrict_cells(const int32_t* __rest
 #pragma unroll
     for (int q = 0; q < CH; ++q) acc[q] = 0.0;
     const int32_t b = cell_ptr[cell], e = cell_ptr[cell + 1];
-    for (int64_t item = (int64_t)b * dofs + tid; item < (int64_t)e * dofs; item += 256) {
-        const int32_t node = cell_nodes[item / dofs];
-        const int64_t r = (int64_t)node * dofs + item % dofs;
-        const double x = rv[r];
+    // four rows per lane and trip: their node ids, then their entries of rv and of the CH columns of Phi, requested together and
+    // added in row order (one row per trip put two dependent memory latencies in every trip: 155 us per launch with RGDSW's 24 columns
+    // at cfg 5's share, where the 0.49 GB of Phi take 0.1 ms)
+    constexpr int U = 4;
+    const int64_t ib = (int64_t)b * dofs, ie = (int64_t)e * dofs;
+    for (int64_t item0 = ib + tid; item0 < ie; item0 += 256 * U) {
+        int64_t r[U];
+        bool on[U];
 #pragma unroll
-        for (int q = 0; q < CH; ++q)
-            if (s0 + q < nsd) acc[q] = fma(phiT[(int64_t)(s0 + q) * ldp + r], x, acc[q]);
+        for (int u = 0; u < U; ++u) {
+            const int64_t item = item0 + 256 * u;
+            on[u] = item < ie;
+            const int64_t it = on[u] ? item : ib;
+            r[u] = (int64_t)cell_nodes[it / dofs] * dofs + it % dofs;
+        }
+        double x[U], ph[U][CH];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            x[u] = rv[r[u]];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) ph[u][q] = phiT[(int64_t)min(s0 + q, nsd - 1) * ldp + r[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+                if (on[u] && s0 + q < nsd) acc[q] = fma(ph[u][q], x[u], acc[q]);
     }
 #pragma unroll
     for (int q = 0; q < CH; ++q) {

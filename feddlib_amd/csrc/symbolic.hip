@@ -215,7 +215,15 @@ __global__ __launch_bounds__(128) void k_pattern_compact(const int32_t* __restri
     const int32_t r = R0 + tid;
     if (r < R1) {
         const int32_t b = rowptr[r] - b0, len = rowptr[r + 1] - rowptr[r];
-        for (int k = 0; k < len; ++k) sh[b + k] = stash[(int64_t)k * n_own + r];
+        // (eight planes of the stash at a time: the loads in flight together, then the stores to LDS)
+        for (int k0 = 0; k0 < len; k0 += 8) {
+            int32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = k0 + u < len ? stash[(int64_t)(k0 + u) * n_own + r] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u < len) sh[b + k0 + u] = v[u];
+        }
     }
     __syncthreads();
     for (int32_t i = tid; i < total; i += 128) colind[b0 + i] = sh[i];
