@@ -167,30 +167,66 @@ __global__ __launch_bounds__(64) void k_cell_galerkin(CoarseGeom cg, const int32
 #pragma unroll
                     for (int a = 0; a < NC; ++a) W[a][lane] = corner_weight<DIM>(oi, a) * mrow;
                     if (mrow != 0.0) {
-                        for (int32_t p = rowptr[row]; p < rowptr[row + 1]; ++p) {
-                            const int32_t col = colind[p];
-                            const int32_t jn = col / dofs;
-                            if (col - jn * dofs != l) continue;
-                            const double v = val[p] * mask[col];
-                            if (v == 0.0) continue;
-                            const Loc oj = locate<DIM>(cg, xyz, jn);
-                            int rel[3] = {0, 0, 0};
-                            bool ok = true;
+                        // the entries of column component l, four at a time: their columns and values, then the masks and
+                        // coordinates of the column nodes, requested together; the contributions are added in entry order (one
+                        // entry per trip waited for two dependent loads each time: 4.9 ms for the 857 375 node rows of cfg 5's share)
+                        constexpr int U = 4;
+                        const int32_t pe = rowptr[row + 1];
+                        for (int32_t p0 = rowptr[row]; p0 < pe; p0 += U) {
+                            int32_t col[U];
+                            double av[U];
 #pragma unroll
-                            for (int d = 0; d < DIM; ++d) {
-                                rel[d] = oj.i0[d] - cc[d] + 1;
-                                ok = ok && rel[d] >= 0 && rel[d] <= 2;
+                            for (int u = 0; u < U; ++u) {
+                                const int32_t p = min(p0 + u, pe - 1);
+                                col[u] = colind[p];
+                                av[u] = val[p];
                             }
-                            if (!ok) {
-                                bad[0] = 1;  // a matrix entry couples cells that are not neighbours
-                                continue;
+                            bool on[U];
+                            double mc[U], X[U][3];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const int32_t jn = col[u] / dofs;
+                                on[u] = p0 + u < pe && col[u] - jn * dofs == l;
+                                mc[u] = mask[col[u]];
+#pragma unroll
+                                for (int d = 0; d < DIM; ++d) X[u][d] = xyz[(int64_t)jn * DIM + d];
                             }
 #pragma unroll
-                            for (int b = 0; b < NC; ++b) {
-                                int slot = 0;
+                            for (int u = 0; u < U; ++u) {
+                                const double v = av[u] * mc[u];
+                                if (!on[u] || v == 0.0) continue;
+                                Loc oj;
 #pragma unroll
-                                for (int d = DIM - 1; d >= 0; --d) slot = slot * 4 + rel[d] + ((b >> d) & 1);
-                                P[slot][lane] += v * corner_weight<DIM>(oj, b);
+                                for (int d = 0; d < 3; ++d) {
+                                    oj.i0[d] = 0;
+                                    oj.f[d] = 0.0;
+                                }
+#pragma unroll
+                                for (int d = 0; d < DIM; ++d) {     // (locate() on the coordinates already here)
+                                    const double t = (X[u][d] - cg.lo[d]) / cg.L[d] * (double)cg.g[d];
+                                    int i = (int)floor(t);
+                                    i = min(cg.g[d] - 1, max(0, i));
+                                    oj.i0[d] = i;
+                                    oj.f[d] = t - (double)i;
+                                }
+                                int rel[3] = {0, 0, 0};
+                                bool ok = true;
+#pragma unroll
+                                for (int d = 0; d < DIM; ++d) {
+                                    rel[d] = oj.i0[d] - cc[d] + 1;
+                                    ok = ok && rel[d] >= 0 && rel[d] <= 2;
+                                }
+                                if (!ok) {
+                                    bad[0] = 1;  // a matrix entry couples cells that are not neighbours
+                                    continue;
+                                }
+#pragma unroll
+                                for (int b = 0; b < NC; ++b) {
+                                    int slot = 0;
+#pragma unroll
+                                    for (int d = DIM - 1; d >= 0; --d) slot = slot * 4 + rel[d] + ((b >> d) & 1);
+                                    P[slot][lane] += v * corner_weight<DIM>(oj, b);
+                                }
                             }
                         }
                     }
