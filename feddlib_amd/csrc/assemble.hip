@@ -696,13 +696,24 @@ __global__ __launch_bounds__(256) void k_rhs(RhsArgs a, const double* __restrict
     // the run is processed in windows of `cap` pairs (one window unless a node has very many elements)
     for (int32_t w0 = p0; w0 < a.n2e_ptr[node1]; w0 += cap) {
         const int32_t w1 = min(a.n2e_ptr[node1], w0 + cap);
-        for (int32_t p = w0 + tid; p < w1; p += 256) {
-            const int32_t idx = a.n2e[p];
-            const int32_t e = idx / a.nen;
-            const int li = idx - e * a.nen;
-            double b = 0.0;
-            for (int i = 0; i < 10; ++i) b = i == li ? a.base[i] : b;
-            park[p - w0] = b * absdet[e];
+        // (four pairs per lane and trip: their adjacency entries, then their |det B|, requested together)
+        for (int32_t q0 = w0 + tid; q0 < w1; q0 += 256 * 4) {
+            int32_t idx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) idx[u] = a.n2e[min(q0 + 256 * u, w1 - 1)];
+            double ad[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ad[u] = absdet[idx[u] / a.nen];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int32_t p = q0 + 256 * u;
+                if (p < w1) {
+                    const int li = idx[u] - (idx[u] / a.nen) * a.nen;
+                    double b = 0.0;
+                    for (int i = 0; i < 10; ++i) b = i == li ? a.base[i] : b;
+                    park[p - w0] = b * ad[u];
+                }
+            }
         }
         __syncthreads();
         for (int32_t p = max(nb, w0); p < min(ne, w1); ++p) sum += park[p - w0];
