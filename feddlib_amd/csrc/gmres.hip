@@ -1563,6 +1563,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     std::vector<double> theta((size_t)S, 0.0);
     int s_cur = std::min(s_goal, 8);
     const bool dbg = getenv("FEDD_GMRES_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[gmres s-step] basis at %p (%zu MB), ldv %lld\n", (void*)V, c->d_V.cap * sizeof(double) >> 20, (long long)ldv);
     double tol_abs = rtol * beta0;      // target of the recurrence residual; tightened when the true residual lags behind it
     double last_true = beta0;
     int nfail = 0;                      // claims of the recurrence that the true residual did not confirm
