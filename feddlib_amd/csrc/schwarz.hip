@@ -304,35 +304,54 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 // (column - row, value quantised to 2^-44 of the row's largest magnitude) of every entry that does not quantise to zero.
 // A subdomain's fingerprint is then built from the hashes of its rows (k_sub_fingerprint_rows below): 31 M row hashes to
 // gather at the 214^3 grid instead of 460 M matrix entries to look up (3.4 ms -> well under 1 ms).
+// (four rows per 16-lane group: their bounds, then the first sixteen entries of each -- values and columns -- requested together and
+// kept in registers for both passes; longer rows loop over the rest)
+constexpr int RH_R = 4;
 __global__ void k_row_hash(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, const double* __restrict__ val,
                            int32_t n_rows, double* __restrict__ rmax, uint64_t* __restrict__ rh) {
-    const int32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int e = threadIdx.x & 15;
-    double m = 0.0;
-    int32_t p0 = 0, p_end = 0;
-    if (r < n_rows) {
-        p0 = rowptr[r];
-        p_end = rowptr[r + 1];
-        for (int32_t p = p0 + e; p < p_end; p += 16) m = fmax(m, fabs(val[p]));
+    const int32_t r0 = g * RH_R;
+    int32_t pb[RH_R + 1];
+#pragma unroll
+    for (int q = 0; q <= RH_R; ++q) pb[q] = rowptr[min(r0 + q, n_rows)];
+    double v0[RH_R];
+    int32_t c0[RH_R];
+#pragma unroll
+    for (int q = 0; q < RH_R; ++q) {
+        const int32_t idx = pb[q] + e;
+        const bool has = r0 + q < n_rows && idx < pb[q + 1];
+        v0[q] = has ? val[idx] : 0.0;
+        c0[q] = has ? colind[idx] : 0;
     }
-    for (int off = 8; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 16));
-    const double scale = m > 0.0 ? 17592186044416.0 / m : 0.0;   // 2^44 / row max
-    uint64_t h1 = 0, h2 = 0;
-    for (int32_t p = p0 + e; p < p_end; p += 16) {
-        const int64_t q = (int64_t)llrint(val[p] * scale);
-        if (q == 0) continue;
-        const uint64_t key = (uint64_t)(uint32_t)(colind[p] - r);
-        h1 += mix64((key + 0x2545f4914f6cdd1dull) * 0x9e3779b97f4a7c15ull + (uint64_t)q);
-        h2 += mix64((key + 0x632be59bd9b4e019ull) * 0xd6e8feb86659fd93ull ^ ((uint64_t)q * 0xa0761d6478bd642full));
-    }
-    for (int off = 8; off > 0; off >>= 1) {
-        h1 += __shfl_xor(h1, off, 16);
-        h2 += __shfl_xor(h2, off, 16);
-    }
-    if (r < n_rows && e == 0) {
-        rmax[r] = m;
-        rh[2 * (int64_t)r] = h1;
-        rh[2 * (int64_t)r + 1] = h2;
+#pragma unroll
+    for (int q = 0; q < RH_R; ++q) {
+        const int32_t r = r0 + q;
+        const bool live = r < n_rows;
+        const int32_t p0 = pb[q], p_end = live ? pb[q + 1] : pb[q];
+        double m = fabs(v0[q]);
+        for (int32_t p = p0 + 16 + e; p < p_end; p += 16) m = fmax(m, fabs(val[p]));
+        for (int off = 8; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 16));
+        const double scale = m > 0.0 ? 17592186044416.0 / m : 0.0;   // 2^44 / row max
+        uint64_t h1 = 0, h2 = 0;
+        auto add = [&](double a, int32_t cidx) {
+            const int64_t qv = (int64_t)llrint(a * scale);
+            if (qv == 0) return;
+            const uint64_t key = (uint64_t)(uint32_t)(cidx - r);
+            h1 += mix64((key + 0x2545f4914f6cdd1dull) * 0x9e3779b97f4a7c15ull + (uint64_t)qv);
+            h2 += mix64((key + 0x632be59bd9b4e019ull) * 0xd6e8feb86659fd93ull ^ ((uint64_t)qv * 0xa0761d6478bd642full));
+        };
+        if (p0 + e < p_end) add(v0[q], c0[q]);
+        for (int32_t p = p0 + 16 + e; p < p_end; p += 16) add(val[p], colind[p]);
+        for (int off = 8; off > 0; off >>= 1) {
+            h1 += __shfl_xor(h1, off, 16);
+            h2 += __shfl_xor(h2, off, 16);
+        }
+        if (live && e == 0) {
+            rmax[r] = m;
+            rh[2 * (int64_t)r] = h1;
+            rh[2 * (int64_t)r + 1] = h2;
+        }
     }
 }
 
@@ -1437,7 +1456,7 @@ int schwarz_setup(fedd_ctx* c) {
         FEDD_TRY(c->d_sw_fp.ensure((size_t)(2 * nsub + 2 * tsize) + (by_rows ? 2 * (size_t)n_stored : 0)));
         uint64_t* row_hash = c->d_sw_fp.p + 2 * nsub + 2 * tsize;
         if (by_rows)
-            hipLaunchKernelGGL(k_row_hash, dim3((unsigned)((n_stored + 15) / 16)), blk, 0, c->stream, (const int32_t*)c->d_rowptr.p,
+            hipLaunchKernelGGL(k_row_hash, dim3((unsigned)((n_stored + 16 * RH_R - 1) / (16 * RH_R))), blk, 0, c->stream, (const int32_t*)c->d_rowptr.p,
                                (const int32_t*)c->d_colind.p, (const double*)c->d_val.p, n_stored, c->d_sw_rmax.p, row_hash);
         else
             hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)((n_stored + 15) / 16)), blk, 0, c->stream, (const int32_t*)c->d_rowptr.p,
