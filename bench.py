@@ -696,8 +696,11 @@ def main():
                 # the same launch priced on the compacted (value, column) stream it replaces when column patterns are in use
                 "effective_frac_hbm_peak_on_compacted_csr_bytes": (12.0 * info["spmv"]["nnz_streamed"] + 20.0 * nr)
                                                                    / kern["spmv"]["ms_per_launch"] / 1e6 / HBM_PEAK_GBS,
-                "note": "the solver streams a compacted copy of the owned rows (exact zeros dropped: 8 of the 15 pattern "
-                        "entries of an interior Kuhn-cube row, all but the 1 of a Dirichlet row); fractions are quoted on "
+                "note": "the solver streams a compacted copy of the owned rows: entries with |a_ij| <= 2^-52 x the row's "
+                        "largest magnitude are left out (option spmv_drop_tol; that is the exact zeros -- 8 of the 15 pattern "
+                        "entries of an interior Kuhn-cube row, all but the 1 of a Dirichlet row -- and cancellation noise "
+                        "below one ulp of the row's largest entry); fedd_spmv, true_relres and the solver's own acceptance "
+                        "check multiply with the parity CSR (every stored entry); fractions are quoted on "
                         "the bytes actually streamed, the parity-CSR figure (SURVEY 8d model) is the effective rate; "
                         "with column_patterns > 0 the rows repeat their column offsets and the stream carries a 2-byte "
                         "pattern id per row instead of 4 bytes per entry (values per row, y bit for bit the same)"},

@@ -94,6 +94,9 @@ SIGNATURES = {
     "fedd_timing_get": [C.c_void_p, C.c_int, _f64p, _i64p],
     "fedd_timing_get_sampled": [C.c_void_p, C.c_int, _f64p, _i64p, _f64p],
     "fedd_gmres_info": [C.c_void_p, _ip, _ip, _ip, _ip],
+    "fedd_gmres_x0": [C.c_void_p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int, _ip, _f64p],
+    "fedd_gmres_status": [C.c_void_p, _ip, _f64p],
+    "fedd_schwarz_coarse_apply": [C.c_void_p, _f64p, _f64p],
     "fedd_read_bandwidth": [C.c_void_p, C.c_int64, C.c_int, _f64p],
     "fedd_rccl_selftest": [C.c_void_p, C.c_int, _f64p],
     "fedd_halo_plan_sizes": [C.c_void_p, _ip, _i64p, _i64p],
@@ -534,6 +537,31 @@ class Context:
         _chk(self._L.fedd_gmres(self._h, _p(bb, _f64p), _p(x, _f64p), rtol, max_it, restart, int(use_prec),
                                 C.byref(its), C.byref(rel)))
         return x, its.value, rel.value
+
+    def gmres_x0(self, x0=None, b=None, rtol=1e-8, max_it=100, restart=100, use_prec=True):
+        """the solve from an initial guess ("Zero Initial Guess" = false); x0 None: from the vector the device holds"""
+        bb = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        x = None if x0 is None else np.array(x0, dtype=np.float64, copy=True)
+        its, rel = C.c_int(), C.c_double()
+        _chk(self._L.fedd_gmres_x0(self._h, _p(bb, _f64p), _p(x, _f64p), rtol, max_it, restart, int(use_prec),
+                                   C.byref(its), C.byref(rel)))
+        return (x if x is not None else self.solution_get()), its.value, rel.value
+
+    def gmres_status(self):
+        fl, rr = C.c_int(), C.c_double()
+        _chk(self._L.fedd_gmres_status(self._h, C.byref(fl), C.byref(rr)))
+        return {"floor_reached": fl.value, "recurrence_relres": rr.value}
+
+    def schwarz_coarse_apply(self, r=None):
+        """z = Phi K0^-1 Phi^T r (FROSch's "Only apply coarse"); r None: the assembled rhs, z stays on the device as the
+        solution vector (Level Combination = Multiplicative: then gmres_x0(None))"""
+        if r is None:
+            _chk(self._L.fedd_schwarz_coarse_apply(self._h, None, None))
+            return None
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        _chk(self._L.fedd_schwarz_coarse_apply(self._h, _p(r, _f64p), _p(z, _f64p)))
+        return z
 
     def set_option(self, key, value):
         _chk(self._L.fedd_set_option(self._h, key.encode(), float(value)))

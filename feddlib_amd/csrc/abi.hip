@@ -489,11 +489,7 @@ extern "C" int fedd_spmv(fedd_ctx* c, const double* x_owned, double* y_owned) {
     // the caller's product (Matrix::apply, residual checks) is formed with the parity CSR itself, every stored entry:
     // the compacted stream that leaves out sub-ulp cancellation noise is the solver's private copy (fedd_spmv_device times it)
     // (option "spmv_exact_public" 0: this call runs the solver's stream instead -- how the tests reach those kernels)
-    const int compact = c->spmv_compact;
-    if (c->spmv_exact_public) c->spmv_compact = 0;
-    const int rc = spmv_owned(c, dx, dy);
-    c->spmv_compact = compact;
-    if (rc) return rc;
+    FEDD_TRY(spmv_owned(c, dx, dy, false, nullptr, 0.0, c->spmv_exact_public ? 0 : -1));
     FEDD_HIP(hipMemcpyAsync(y_owned, dy, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FEDD_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -698,6 +694,56 @@ extern "C" int fedd_gmres(fedd_ctx* c, const double* b_owned, double* x_owned, d
     FEDD_TRY(gmres_solve(c, c->d_rhs.p, c->d_x.p, rtol, max_it, restart, use_prec, its_out, relres_out));
     if (x_owned) {
         FEDD_HIP(hipMemcpyAsync(x_owned, c->d_x.p, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// "Zero Initial Guess" = false (LinearSolver_def.hpp:76-78): the solve starts from x_owned (NULL: from the vector the
+// device holds -- the last solution, or what fedd_schwarz_coarse_apply(ctx, NULL, NULL) left there)
+extern "C" int fedd_gmres_x0(fedd_ctx* c, const double* b_owned, double* x_owned, double rtol, int max_it,
+                             int restart, int use_prec, int* its_out, double* relres_out) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_gmres_x0: no matrix");
+    FEDD_CHECK(!use_prec || c->have_schwarz, "fedd_gmres_x0: preconditioner requested but fedd_schwarz_setup was not called");
+    FEDD_CHECK(rtol > 0 && max_it >= 1 && restart >= 1 && restart <= 1000, "fedd_gmres_x0: bad rtol/max_it/restart");
+    FEDD_HIP(hipSetDevice(c->device));
+    if (b_owned) FEDD_HIP(hipMemcpyAsync(c->d_rhs.p, b_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (x_owned) FEDD_HIP(hipMemcpyAsync(c->d_x.p, x_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->gm_x0 = 1;
+    const int rc = gmres_solve(c, c->d_rhs.p, c->d_x.p, rtol, max_it, restart, use_prec, its_out, relres_out);
+    c->gm_x0 = 0;
+    if (rc) return rc;
+    if (x_owned) {
+        FEDD_HIP(hipMemcpyAsync(x_owned, c->d_x.p, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+extern "C" int fedd_gmres_status(fedd_ctx* c, int* floor_reached, double* recurrence_relres) {
+    FEDD_CHECK(c, "fedd_gmres_status: null context");
+    if (floor_reached) *floor_reached = c->gmres_floor;
+    if (recurrence_relres) *recurrence_relres = c->gmres_rec_relres;
+    return 0;
+}
+
+// FROSch's "Only apply coarse" (LinearSolver_def.hpp:98-104): z = Phi K0^-1 Phi^T r, the second level alone
+extern "C" int fedd_schwarz_coarse_apply(fedd_ctx* c, const double* r_owned, double* z_owned) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_schwarz && c->sw_two_level && c->have_coarse, "fedd_schwarz_coarse_apply: no coarse level (fedd_schwarz_setup with two_level = 1)");
+    FEDD_CHECK((r_owned == nullptr) == (z_owned == nullptr), "fedd_schwarz_coarse_apply: r and z both host pointers or both NULL");
+    FEDD_HIP(hipSetDevice(c->device));
+    const int64_t nc = std::max(c->n_rows, c->n_cols);
+    FEDD_TRY(c->d_dtmp0.ensure((size_t)nc * 2));
+    double* dr = c->d_dtmp0.p;
+    double* dz = r_owned ? dr + nc : c->d_x.p;
+    if (r_owned) FEDD_HIP(hipMemcpyAsync(dr, r_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    else FEDD_HIP(hipMemcpyAsync(dr, c->d_rhs.p, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    FEDD_HIP(hipMemsetAsync(dz, 0, (size_t)c->n_rows * sizeof(double), c->stream));
+    FEDD_TRY(coarse_apply_add(c, dr, dz));
+    if (z_owned) {
+        FEDD_HIP(hipMemcpyAsync(z_owned, dz, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         FEDD_HIP(hipStreamSynchronize(c->stream));
     }
     return 0;

@@ -238,6 +238,9 @@ struct fedd_ctx {
     int gmres_newton = 1;                       // ... Newton block basis (Leja-ordered Ritz shifts) once the first s Arnoldi steps exist; 0 = monomial, blocks <= 8
     double gmres_chol_tol = 1e-13;              // ... a block is cut where the squared sine of a new vector against its predecessors falls to this
     int gmres_blocks = 0, gmres_cut_blocks = 0; // ... blocks / blocks that were cut in the last solve
+    int gmres_floor = 0;                        // ... the last solve stopped at the rounding floor of b - A x (relres returned = true residual, may exceed rtol)
+    double gmres_rec_relres = -1.0;             // ... and the recurrence residual it had reached then (-1: not that case)
+    int gm_x0 = 0;                              // the next solve starts from the vector in d_x ("Zero Initial Guess" = false), set per call by fedd_gmres_x0
     fedd::DevBuf<int32_t> d_node_bin;           // [n_own] compact bin id of each owned node
     fedd::DevBuf<int32_t> d_bin_ptr, d_bin_nodes;   // [nsub+1], [n_own]
     fedd::DevBuf<int32_t> d_sub_n, d_sub_nown;  // [nsub] total / owned dofs of each subdomain
@@ -410,8 +413,9 @@ int block_merge(fedd_ctx* c, int slot_a, int slot_bt, int slot_b, int slot_c);
 // x_has_tail: the buffer behind d_x_owned has room for all n_cols entries; the ghost values are then imported in
 // place (behind the owned entries) instead of into a copy of x
 // d_sub != nullptr: y = A x - theta * d_sub (owned rows), fused into the kernel's store
+// use_compact: -1 = as option "spmv_compact" says, 0 = the parity CSR (every stored entry), 1 = the solver's compacted stream
 int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_has_tail = false, const double* d_sub = nullptr,
-               double theta = 0.0);   // incl. ghost import
+               double theta = 0.0, int use_compact = -1);   // incl. ghost import
 int halo_import(fedd_ctx* c, double* d_xcol, int dofs);                    // fill ghost tail
 int read_bandwidth(fedd_ctx* c, int64_t bytes, int reps, double* gbs);     // read-only streaming calibration
 

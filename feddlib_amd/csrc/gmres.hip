@@ -640,8 +640,13 @@ static int gmres_solve_dcgs2(fedd_ctx* c, const double* d_b, double* d_x, double
         return spmv_owned(c, use_prec ? z : in, out, use_prec ? true : tail);
     };
 
-    FEDD_HIP(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), st));  // "Zero Initial Guess" (LinearSolver_def.hpp:76-78)
-    FEDD_HIP(hipMemcpyAsync(r, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (c->gm_x0 && !mk) {   // "Zero Initial Guess" = false (LinearSolver_def.hpp:76-78): d_x holds x_0, r_0 = b - A x_0
+        FEDD_TRY(spmv_owned(c, d_x, wt));
+        hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, d_b, -1.0, (const double*)wt, r, n);
+    } else {
+        FEDD_HIP(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), st));  // "Zero Initial Guess" (LinearSolver_def.hpp:76-78)
+        FEDD_HIP(hipMemcpyAsync(r, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
     FEDD_TRY(norm2_into(r, S + o.nrm + 3));
     FEDD_HIP(hipMemcpyAsync(c->h_pinned, S + o.nrm + 3, sizeof(double), hipMemcpyDeviceToHost, st));
     FEDD_HIP(hipStreamSynchronize(st));
@@ -1486,9 +1491,14 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
         return spmv_owned(c, use_prec ? z : in, out, use_prec, theta != 0.0 ? in : nullptr, theta);
     };
 
-    FEDD_HIP(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), st));  // "Zero Initial Guess" (LinearSolver_def.hpp:76-78)
     FEDD_HIP(hipMemsetAsync(Sx + o3.th, 0, (size_t)S * sizeof(double), st));   // monomial block basis (shifts 0)
-    FEDD_HIP(hipMemcpyAsync(r, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (c->gm_x0 && !mk && nr == 1) {   // "Zero Initial Guess" = false (LinearSolver_def.hpp:76-78): d_x holds x_0, r_0 = b - A x_0
+        FEDD_TRY(spmv_owned(c, d_x, axt));
+        hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, d_b, -1.0, (const double*)axt, r, n);
+    } else {
+        FEDD_HIP(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), st));  // "Zero Initial Guess" (LinearSolver_def.hpp:76-78)
+        FEDD_HIP(hipMemcpyAsync(r, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
     FEDD_TRY(norm2_into(r, Sx + o.nrm + 3));
     FEDD_HIP(hipMemcpyAsync(c->h_pinned, Sx + o.nrm + 3, sizeof(double), hipMemcpyDeviceToHost, st));
     FEDD_HIP(hipStreamSynchronize(st));
@@ -1533,7 +1543,9 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
         if (nr > 1) {
             FEDD_TRY(spmm_owned(c, xt, axt, mk, xt));
         } else {
-            FEDD_TRY(spmv_owned(c, xt, axt, true));
+            // the residual that decides is formed with the parity CSR (every stored entry), like fedd_spmv, not with the
+            // compacted stream the Krylov process runs on (which leaves out sub-ulp cancellation noise)
+            FEDD_TRY(spmv_owned(c, xt, axt, true, nullptr, 0.0, 0));
             if (mk) hipLaunchKernelGGL(k_mask_mix, gn, blk, 0, st, mk, (const double*)axt, (const double*)xt, axt, n);
         }
         hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, d_b, -1.0, (const double*)axt, r, n);
@@ -1682,11 +1694,14 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
                     } else if (nfail >= 1 && ta >= 0.5 * best_fail && ta <= 100.0 * rtol * beta0) {
                         // the recurrence keeps falling, the true residual of the computed x does not follow any more: b - A x
                         // has reached its rounding floor (badly scaled systems, tolerances near 1e-13).  The one-vector
-                        // solvers stop on the recurrence alone; here the claim is taken once the floor is evident, and the
-                        // recurrence residual is what is reported, as they do.
+                        // solvers stop on the recurrence alone; here the iteration ends once the floor is evident.  What is
+                        // reported is the TRUE residual (it may exceed rtol by up to 100x: the caller sees that);
+                        // fedd_gmres_status tells that the floor was reached and gives the recurrence residual beside it.
                         FEDD_TRY(commit());
                         its += cols;
-                        relres = hout[2 + i] / beta0;
+                        relres = ta / beta0;
+                        c->gmres_floor = 1;
+                        c->gmres_rec_relres = hout[2 + i] / beta0;
                         done = true;
                     } else if (ta > 4.0 * std::max(hout[2 + i], 1e-300) || !(ta < last_true)) {
                         // the recurrence has lost touch with the true residual: keep what was gained, restart
@@ -1780,6 +1795,8 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
 
 int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int max_it, int restart, int use_prec,
                 int* its_out, double* relres_out) {
+    c->gmres_floor = 0;
+    c->gmres_rec_relres = -1.0;
     if (c->gmres_kind == 2) {
         // block length: "gmres_s" 0 = by the vector length per rank -- 16-vector (Newton-basis) blocks where the sweeps over the
         // basis dominate, 8-vector blocks on short vectors, where the longer blocks' fixed costs (two monomial blocks first,
@@ -1856,8 +1873,12 @@ int gmres_solve(fedd_ctx* c, const double* d_b, double* d_x, double rtol, int ma
         return 0;
     };
 
-    FEDD_HIP(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), st));  // "Zero Initial Guess" (LinearSolver_def.hpp:76-78)
-    FEDD_HIP(hipMemcpyAsync(r, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (c->gm_x0) {   // "Zero Initial Guess" = false (LinearSolver_def.hpp:76-78): d_x holds x_0, r_0 = b - A x_0
+        FEDD_TRY(residual());
+    } else {
+        FEDD_HIP(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), st));  // "Zero Initial Guess" (LinearSolver_def.hpp:76-78)
+        FEDD_HIP(hipMemcpyAsync(r, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
     FEDD_TRY(norm2_into(r, S + o.nrm + 3));
     FEDD_HIP(hipMemcpyAsync(c->h_pinned, S + o.nrm + 3, sizeof(double), hipMemcpyDeviceToHost, st));
     FEDD_HIP(hipStreamSynchronize(st));

@@ -745,9 +745,16 @@ static int spmv_compact_build(fedd_ctx* c) {
     return 0;
 }
 
-int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_has_tail, const double* d_sub, double theta) {
+__global__ void k_epi_only(double* __restrict__ y, SpmvEpi epi, int32_t n) {   // y = 0 * x - theta * sub (matrix without entries)
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = epi_apply(epi, 0.0, i);
+}
+
+int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_has_tail, const double* d_sub, double theta,
+               int use_compact) {
     const double* x = d_x_owned;
     const SpmvEpi epi{d_sub, theta};
+    const bool compact = use_compact < 0 ? c->spmv_compact != 0 : use_compact != 0;
     if (c->n_cols != c->n_rows || !c->halo.peers.empty()) {   // also a rank that only sends takes part
         if (x_has_tail) {   // the caller's buffer takes the ghost values behind its owned entries
             FEDD_TRY(halo_import(c, const_cast<double*>(d_x_owned), c->dofs));
@@ -763,7 +770,7 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
     // very long rows), 1 = row-per-lane-group, 2 = CSR-stream
     const bool windowed = c->spmv_kind == 0 && c->max_row_nnz <= 256 && c->nnz > 0;
     const bool streamed = !windowed && (c->spmv_kind == 0 || c->spmv_kind == 2) && avg <= 64.0 && c->max_row_nnz <= 2048;
-    if (windowed && c->spmv_compact) {
+    if (windowed && compact) {
         // the compacted stream (numerically zero entries left out): same kernel, fewer bytes
         if (!c->cs_valid) FEDD_TRY(spmv_compact_build(c));
         const int wnu = c->cs_win_nu;
@@ -772,9 +779,10 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
         const size_t lds = (size_t)(256 * wnu + ovh) * sizeof(double);
         const bool nt = c->spmv_nt < 0 ? 12.0 * (double)c->cs_nnz > 256.0 * 1024.0 * 1024.0 : c->spmv_nt != 0;
         ScopedTimer ts(c, FEDD_T_SPMV);
-        if (c->cs_nnz == 0)
-            FEDD_HIP(hipMemsetAsync(d_y_owned, 0, (size_t)n * sizeof(double), c->stream));
-        else if (c->cs_npat > 0 && c->spmv_pattern) {
+        if (c->cs_nnz == 0) {
+            if (epi.sub) hipLaunchKernelGGL(k_epi_only, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_y_owned, epi, n);
+            else FEDD_HIP(hipMemsetAsync(d_y_owned, 0, (size_t)n * sizeof(double), c->stream));
+        } else if (c->cs_npat > 0 && c->spmv_pattern) {
             const int32_t* plen = c->d_cs_pati.p + n + 2 * SPAT_TS;
             const int32_t* pdelta = plen + SPAT_P;
             const int nu = c->cs_pat_nu;                        // 16-byte loads per lane: window = 512 nu values

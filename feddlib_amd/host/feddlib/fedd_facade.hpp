@@ -1124,11 +1124,12 @@ int LinearSolver<SC, LO, GO, NO>::solve(Problem_Type* problem, BlockMultiVectorP
         // this library's lattice space, not FROSch's GDSW: say so.
         const bool twoLevel = frosch.get("TwoLevel", false);
         // "CoarseOperator Type" (parametersPrec.xml:23): GDSWCoarseOperator / RGDSWCoarseOperator -> the library's GDSW /
-        // RGDSW level on the coarse lattice; IPOUHarmonic is not built and runs GDSW (said so); "Q1" = lattice hat functions
+        // RGDSW level on the coarse lattice; "Q1" = lattice hat functions; anything else (IPOUHarmonicCoarseOperator, the
+        // third value the reference's XML files list) is not built: an error, not a silent substitute
         const std::string coarseType = frosch.get("CoarseOperator Type", "GDSWCoarseOperator");
         const int coarseKind = coarseType == "Q1" ? FEDD_COARSE_Q1 : (coarseType == "RGDSWCoarseOperator" ? FEDD_COARSE_RGDSW : FEDD_COARSE_GDSW);
-        if (twoLevel && problem->getVerbose() && coarseType != "GDSWCoarseOperator" && coarseType != "RGDSWCoarseOperator" && coarseType != "Q1")
-            std::cout << "-- note: CoarseOperator Type " << coarseType << " is not built; running GDSWCoarseOperator --" << std::endl;
+        TEUCHOS_TEST_FOR_EXCEPTION(twoLevel && coarseType != "GDSWCoarseOperator" && coarseType != "RGDSWCoarseOperator" && coarseType != "Q1",
+                                   std::logic_error, "CoarseOperator Type \"" + coarseType + "\" is not built (GDSWCoarseOperator, RGDSWCoarseOperator, Q1 are)");
         const int target = frosch.get("Subdomain Nodes", 0);   // 0 = the library's default (27 / dofs per node)
         feddCheck(fedd_schwarz_set_target(ctx, target, 1.0), "fedd_schwarz_set_target");
         feddCheck(fedd_schwarz_set_coarse(ctx, frosch.get("Coarse Cells", 0.0)), "fedd_schwarz_set_coarse");
@@ -1143,6 +1144,14 @@ int LinearSolver<SC, LO, GO, NO>::solve(Problem_Type* problem, BlockMultiVectorP
     auto x = problem->getSolution();
     int its = 0;
     double rel = 0.;
+    // "Zero Initial Guess" (LinearSolver_def.hpp:76-78): true clears the solution vector, false keeps it as x_0.
+    // "Level Combination" = "Multiplicative" (:98-104): one coarse-only application of the preconditioner to the right-hand
+    // side goes into the solution vector before the solve, which then starts from it
+    const bool zeroGuess = pl->get("Zero Initial Guess", true);
+    if (zeroGuess) x->putScalar(0.);
+    const bool multiplicative = usePrec && std::string(frosch.get("Level Combination", "Additive")) == "Multiplicative";
+    TEUCHOS_TEST_FOR_EXCEPTION(multiplicative && (blocks || !frosch.get("TwoLevel", false)), std::logic_error,
+                               "Level Combination = Multiplicative needs the coarse level (TwoLevel = true, single-block system)");
     if (!problem->getUserPreconditioner().is_null()) {
         // INTEGRATION.md 3(b), "keep the iterative solver, plug in operator and preconditioner": right-preconditioned
         // GMRES(m) on the host -- what Belos' Block GMRES does with Thyra operators (LinearSolver_def.hpp:72-135), two-pass
@@ -1154,8 +1163,14 @@ int LinearSolver<SC, LO, GO, NO>::solve(Problem_Type* problem, BlockMultiVectorP
         return its;
     }
     if (!blocks) {
-        feddCheck(fedd_gmres(ctx, b->getBlock(0)->raw().data(), x->getBlockNonConst(0)->raw().data(), tol, maxIt, numBlocks,
-                             usePrec ? 1 : 0, &its, &rel), "fedd_gmres");
+        if (multiplicative && problem->getUserPreconditioner().is_null())
+            feddCheck(fedd_schwarz_coarse_apply(ctx, b->getBlock(0)->raw().data(), x->getBlockNonConst(0)->raw().data()), "fedd_schwarz_coarse_apply");
+        if (multiplicative || !zeroGuess)
+            feddCheck(fedd_gmres_x0(ctx, b->getBlock(0)->raw().data(), x->getBlockNonConst(0)->raw().data(), tol, maxIt, numBlocks,
+                                    usePrec ? 1 : 0, &its, &rel), "fedd_gmres_x0");
+        else
+            feddCheck(fedd_gmres(ctx, b->getBlock(0)->raw().data(), x->getBlockNonConst(0)->raw().data(), tol, maxIt, numBlocks,
+                                 usePrec ? 1 : 0, &its, &rel), "fedd_gmres");
     } else {       // merged vectors = the blocks one after the other (BlockMap::merge, BlockMap_def.hpp:55-80)
         std::vector<double> bb, xx;
         for (UN k = 0; k < b->size(); ++k) bb.insert(bb.end(), b->getBlock(k)->raw().begin(), b->getBlock(k)->raw().end());

@@ -313,6 +313,21 @@ int fedd_schwarz_conforming(fedd_ctx* ctx, int64_t* n_conforming);
  * count the way Problem::solve does (its_out). */
 int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rtol, int max_it,
                int restart, int use_prec, int* its_out, double* relres_out);
+/* The same solve from a given initial guess: the reference's "Zero Initial Guess" = false (LinearSolver_def.hpp:76-78, where
+ * the solution vector is only cleared when the key is true).  x_owned in: x_0, out: the solution; NULL: x_0 is the vector the
+ * device holds (the last solution, or what fedd_schwarz_coarse_apply(ctx, NULL, NULL) left there) and the solution stays on
+ * the device.  The relative residual refers to ||r_0|| = ||b - A x_0||, as Belos' default scaling does. */
+int fedd_gmres_x0(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rtol, int max_it,
+                  int restart, int use_prec, int* its_out, double* relres_out);
+/* how the last solve ended: floor_reached = 1 when the s-step solver stopped because b - A x had reached its rounding floor
+ * (the recurrence residual kept falling, the true residual did not follow; relres_out of that solve is the TRUE residual and may
+ * exceed rtol by up to 100x), recurrence_relres = the recurrence residual at that point (-1 otherwise); outputs may be NULL */
+int fedd_gmres_status(fedd_ctx* ctx, int* floor_reached, double* recurrence_relres);
+/* The second level alone, z = Phi K0^-1 Phi^T r: FROSch's "Only apply coarse", which the reference uses for
+ * "Level Combination" = "Multiplicative" (LinearSolver_def.hpp:98-104: one coarse pre-apply of the right-hand side into the
+ * solution vector, then the solve).  r_owned / z_owned both NULL: r = the assembled right-hand side, z -> the device's solution
+ * vector (then fedd_gmres_x0(ctx, NULL, NULL, ...) continues from it).  Needs fedd_schwarz_setup(two_level = 1). */
+int fedd_schwarz_coarse_apply(fedd_ctx* ctx, const double* r_owned, double* z_owned);
 /* the orthogonalisation in use ("gmres_kind") and, for the s-step form, its block length and the blocks of the last solve
  * (all, and those that were cut short because the block basis became numerically dependent); outputs may be NULL */
 int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_blocks);

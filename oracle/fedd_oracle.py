@@ -1207,6 +1207,19 @@ def gmres_right(A, b, M=None, rtol=1e-8, max_it=100, restart=100, x0=None):
     return x, its, hist
 
 
+def solve_monolithic(A, b, prec=None, coarse_only=None, x_init=None, zero_initial_guess=True,
+                     level_combination="Additive", rtol=1e-8, max_it=100, restart=100):
+    """LinearSolver::solveMonolithic (feddlib/problems/Solver/LinearSolver_def.hpp:72-135), the part around Thyra::solve:
+    "Zero Initial Guess" = true clears the solution vector (:76-78), otherwise the vector the problem holds is x_0;
+    "Level Combination" = "Multiplicative" applies the preconditioner with "Only apply coarse" to the right-hand side, INTO
+    the solution vector, before the solve (:98-104) -- the solve then starts from that vector with the preconditioner as it
+    was built.  prec / coarse_only are callables r -> z.  Returns (x, iterations, relres history vs ||b - A x_0||)."""
+    x = np.zeros(b.shape[0]) if (zero_initial_guess or x_init is None) else np.array(x_init, dtype=float, copy=True)
+    if level_combination == "Multiplicative":
+        x = coarse_only(b)
+    return gmres_right(A, b, prec, rtol=rtol, max_it=max_it, restart=restart, x0=x)
+
+
 def direct_solve(A: sp.csr_matrix, b: np.ndarray, refine: int = 2) -> np.ndarray:
     """Sparse LU + a few steps of iterative refinement (badly scaled systems, e.g. elasticity with
     unit Dirichlet rows next to 1e6-sized entries, otherwise keep O(1e-16) absolute noise at the

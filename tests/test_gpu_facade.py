@@ -150,7 +150,7 @@ def test_driver_on_several_ranks(driver, tmp_path, dim, ranks, hh):
         seen[gid] += 1
     assert (seen == 1).all()                                # the unique maps partition the global nodes
     assert rel <= 1e-12
-    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
     # 3D: the four ghost layers hold every 27-node box that a rank boundary crosses, so the preconditioner does not depend
     # on the split and the one-rank driver on the same grid takes the same number of iterations; the wider 2D boxes are
     # cut at the rank boundaries (each rank inverts its part), which costs a few iterations
@@ -168,7 +168,7 @@ def test_driver_on_several_ranks(driver, tmp_path, dim, ranks, hh):
     np.testing.assert_allclose(pts_n[:, :dim], m.xyz_uni if m.xyz_uni is not None else m.xyz, atol=1e-14)
     x1, its1, rel1, _ = run_driver(driver, tmp_path, prob1, prec, sol)
     assert (abs(its - its1) <= 2) if dim == 3 else (its1 - 2 <= its <= its1 + 12), (its, its1)
-    np.testing.assert_allclose(x, x1, rtol=0, atol=1e-9 * np.abs(xd).max())
+    np.testing.assert_allclose(x, x1, rtol=0, atol=1e-10 * np.abs(xd).max())
     # ... and the one-rank export of the same grid: the same points, the same set of elements (every element exactly once)
     pts_1 = np.fromfile(str(tmp_path / "solutionLaplace.xyz.bin"), dtype="<f8").reshape(-1, 3)
     conn_1 = np.fromfile(str(tmp_path / "solutionLaplace.conn.bin"), dtype="<i4").reshape(-1, nv)
@@ -219,7 +219,7 @@ def test_driver_reads_and_partitions_an_unstructured_mesh(driver, tmp_path, rank
         x[gid] = part[:, 1]
         seen[gid] += 1
     assert (seen == 1).all()
-    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
 
 
 LINELAS_XML = os.path.join(ROOT, "tests", "golden", "linelas_xml")

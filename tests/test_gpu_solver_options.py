@@ -1,0 +1,203 @@
+"""The solver-side keys of LinearSolver::solveMonolithic (feddlib/problems/Solver/LinearSolver_def.hpp:72-135) beyond the
+defaults: "Zero Initial Guess" = false (fedd_gmres_x0), "Level Combination" = "Multiplicative" (one coarse-only application
+into the solution vector before the solve: fedd_schwarz_coarse_apply + fedd_gmres_x0), and what fedd_gmres reports as the
+relative residual (the true one for the s-step solver, fedd_gmres_status when b - A x reached its rounding floor).  Oracle:
+fo.solve_monolithic / fo.gmres_right(x0=...)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import fedd_oracle as fo
+from test_gpu_two_level import laplace_setup
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+XML = os.path.join(ROOT, "tests", "golden", "laplace_xml")
+
+
+@pytest.fixture(scope="module")
+def ctx(fedd_lib):
+    c = fedd_lib.Context(device=0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("kind,s", [(0, 0), (1, 0), (2, 8), (2, 16)])
+def test_initial_guess_is_used(fedd_lib, ctx, kind, s):
+    m, om, A_bc, rhs_bc, is_dir = laplace_setup(fedd_lib, ctx, 3, 14)
+    ctx.schwarz_set_target(27, 1.0)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+    ctx.set_option("gmres_kind", kind)
+    ctx.set_option("gmres_s", s)
+    try:
+        xd = fo.direct_solve(A_bc, rhs_bc)
+        rng = np.random.default_rng(11)
+        # (a) a good guess: the exact solution plus a small perturbation -- far fewer iterations than from zero, and the
+        #     relative residual refers to ||b - A x_0|| (Belos' default scaling)
+        x0 = xd + 1e-6 * np.abs(xd).max() * rng.standard_normal(xd.shape[0])
+        x0[is_dir] = xd[is_dir]
+        _, its_zero, _ = ctx.gmres(None, rtol=1e-8, max_it=300, restart=100, use_prec=True)
+        x, its, rel = ctx.gmres_x0(x0, rtol=1e-8, max_it=300, restart=100, use_prec=True)
+        node_bin, nb, _ = fo.schwarz_bins(m["xyz"], 27)
+        ras = fo.RAS(A_bc, node_bin, nb)
+        xo, its_o, hist = fo.gmres_right(A_bc, rhs_bc, ras.apply, rtol=1e-8, max_it=300, restart=100, x0=x0)
+        assert abs(its - its_o) <= 2, (its, its_o)
+        r0 = np.linalg.norm(rhs_bc - A_bc @ x0)
+        assert np.linalg.norm(rhs_bc - A_bc @ x) <= 1.01e-8 * r0
+        assert rel <= 1e-8
+        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
+        # (b) the exact solution as the guess: nothing to do
+        x, its, rel = ctx.gmres_x0(xd, rtol=1e-8, max_it=300, restart=100, use_prec=True)
+        assert its <= 1 and np.abs(x - xd).max() <= 1e-12 * np.abs(xd).max()
+        # (c) x_0 = None: the vector on the device (the last solution)
+        ctx.gmres(None, rtol=1e-4, max_it=300, restart=100, use_prec=True, want_x=False)
+        x1 = ctx.solution_get()
+        x, its, rel = ctx.gmres_x0(None, rtol=1e-13 / max(np.linalg.norm(rhs_bc - A_bc @ x1) / np.linalg.norm(rhs_bc), 1e-9),
+                                   max_it=300, restart=100, use_prec=True)
+        assert 0 < its < its_zero * 2
+        np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+    finally:
+        ctx.set_option("gmres_kind", 2)
+        ctx.set_option("gmres_s", 0)
+
+
+@pytest.mark.parametrize("coarse", ["Q1", "GDSW"])
+def test_level_combination_multiplicative(fedd_lib, ctx, coarse):
+    """LinearSolver_def.hpp:98-104 on the device against its restatement fo.solve_monolithic"""
+    m, om, A_bc, rhs_bc, is_dir = laplace_setup(fedd_lib, ctx, 3, 16)
+    ctx.schwarz_set_target(27, 1.0)
+    ctx.schwarz_set_coarse(27)
+    kind = fedd_lib.COARSE_Q1 if coarse == "Q1" else fedd_lib.COARSE_GDSW
+    ctx.set_option("gdsw_tol", 1e-13)
+    try:
+        ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=kind)
+    finally:
+        ctx.set_option("gdsw_tol", 1e-4)
+    node_bin, nb, _ = fo.schwarz_bins(m["xyz"], 27)
+    ras = fo.RAS(A_bc, node_bin, nb)
+    if coarse == "Q1":
+        co = fo.CoarseQ1(A_bc, m["xyz"], is_dir, 1, cells_target=27)
+    else:
+        co = fo.CoarseGDSW(A_bc, m["conn"], m["xyz"], is_dir, 1, cells_target=27)
+    rng = np.random.default_rng(3)
+    r = rng.standard_normal(A_bc.shape[0])
+    zc = ctx.schwarz_coarse_apply(r)                      # "Only apply coarse"
+    zo = co.apply(r)
+    np.testing.assert_allclose(zc, zo, rtol=0, atol=1e-10 * np.abs(zo).max())
+    prec = lambda v: ras.apply(v) + co.apply(v)
+    xo, its_o, hist = fo.solve_monolithic(A_bc, rhs_bc, prec, co.apply, level_combination="Multiplicative", rtol=1e-8,
+                                          max_it=200, restart=100)
+    xa, its_a, _ = fo.solve_monolithic(A_bc, rhs_bc, prec, co.apply, level_combination="Additive", rtol=1e-8, max_it=200,
+                                       restart=100)
+    ctx.schwarz_coarse_apply(None)                        # rhs -> solution vector, on the device
+    x0 = ctx.solution_get()
+    np.testing.assert_allclose(x0, co.apply(rhs_bc), rtol=0, atol=1e-10 * np.abs(x0).max())
+    x, its, rel = ctx.gmres_x0(None, rtol=1e-8, max_it=200, restart=100, use_prec=True)
+    assert abs(its - its_o) <= 2, (its, its_o, its_a)
+    r0 = np.linalg.norm(rhs_bc - A_bc @ x0)
+    assert np.linalg.norm(rhs_bc - A_bc @ x) <= 1.01e-8 * r0
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-6 * np.abs(xd).max())
+    # to the parity bar with both sides driven down
+    ctx.schwarz_coarse_apply(None)
+    x, its, rel = ctx.gmres_x0(None, rtol=1e-12, max_it=400, restart=100, use_prec=True)
+    np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
+
+
+def test_coarse_only_apply_needs_a_coarse_level(fedd_lib, ctx):
+    laplace_setup(fedd_lib, ctx, 3, 8)
+    ctx.schwarz_set_target(27, 1.0)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+    with pytest.raises(RuntimeError, match="no coarse level"):
+        ctx.schwarz_coarse_apply(np.ones(9 ** 3))
+
+
+def test_reported_residual_is_the_true_one(fedd_lib, ctx):
+    """the s-step solver's relres_out against ||b - A x|| / ||b|| formed on the host with the stored matrix, on a badly
+    scaled system (elasticity, unit Dirichlet rows beside 1e6-sized entries) at tolerances down to the rounding floor of
+    b - A x.  Where the solver stops at that floor it says so (fedd_gmres_status) and still reports the true residual."""
+    M = 10
+    m = fedd_lib.structured_mesh(3, 1, M)
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(3, fedd_lib.BLOCK_FULL)
+    mu, nu = 2.0e6, 0.4
+    lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
+    ctx.assemble(fedd_lib.FORM_LINELAS, [lam, mu])
+    ctx.assemble_rhs([0.0, 1.0, 0.0])
+    ctx.dirichlet([2], [0.0, 0.0, 0.0])
+    ctx.schwarz_set_target(9, 1.0)
+    ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+    rowptr, col, val, gid = ctx.csr_get()
+    A = sp.csr_matrix((val, col, rowptr), shape=(rowptr.shape[0] - 1, gid.shape[0]))
+    b = ctx.rhs_get()
+    floors = 0
+    for rtol in (1e-6, 1e-10, 1e-13, 1e-15):
+        x, its, rel = ctx.gmres(None, rtol=rtol, max_it=1500, restart=100, use_prec=True)
+        tr = float(np.linalg.norm(b - A @ x) / np.linalg.norm(b))
+        st = ctx.gmres_status()
+        assert abs(rel - tr) <= 0.05 * tr + 2e-16, (rtol, rel, tr, st)
+        if st["floor_reached"]:
+            floors += 1
+            assert st["recurrence_relres"] <= rtol and rel <= 100.0 * rtol
+        elif its < 1500:
+            assert rel <= rtol and st["recurrence_relres"] == -1.0
+    # (nothing to assert on `floors`: whether 1e-15 ends at the floor or at the iteration limit depends on the system)
+
+
+def test_facade_reads_the_keys(fedd_lib, tmp_path):
+    """the reference-style Laplace driver with "Level Combination" = "Multiplicative" (laplace/parametersPrec.xml:19 lists
+    the key) and an unknown "CoarseOperator Type" (IPOUHarmonicCoarseOperator, :23): the first runs and agrees with the
+    oracle, the second is an error, not a silent substitute"""
+    from feddlib_amd import build
+    driver = build.build_driver(verbose=False)
+    prob = tmp_path / "p.xml"
+    prob.write_text(open(os.path.join(XML, "parametersProblem.xml")).read()
+                    .replace('name="Dimension" type="int" value="2"', 'name="Dimension" type="int" value="3"')
+                    .replace('name="H/h" type="int" value="10"', 'name="H/h" type="int" value="12"'))
+    sol = tmp_path / "s.xml"
+    sol.write_text(open(os.path.join(XML, "parametersSolver.xml")).read()
+                   .replace('value="1e-8"', 'value="1e-12"').replace('"Maximum Iterations" type="int" value="100"',
+                                                                     '"Maximum Iterations" type="int" value="400"'))
+    base = open(os.path.join(XML, "parametersPrec.xml")).read() \
+        .replace('name="Combine Values in Overlap" type="string" value="Averaging"',
+                 'name="Combine Values in Overlap" type="string" value="Restricted"')
+    assert 'name="Level Combination"' in base and 'name="TwoLevel"' in base
+    two = re.sub(r'(name="TwoLevel" type="bool" value=")[a-z]+"', r'\1true"', base)
+    two = re.sub(r'(name="CoarseOperator Type" type="string" value=")[A-Za-z0-9]+"', r'\1Q1"', two)
+
+    def run(prec_txt, name):
+        prec = tmp_path / (name + ".xml")
+        prec.write_text(prec_txt)
+        out = tmp_path / (name + ".txt")
+        r = subprocess.run([driver, "--problemfile=%s" % prob, "--precfile=%s" % prec, "--solverfile=%s" % sol,
+                            "--out=%s" % out], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+        return r, out
+
+    res = {}
+    for comb in ("Additive", "Multiplicative"):
+        txt = re.sub(r'(name="Level Combination" type="string" value=")[A-Za-z]+"', r'\1%s"' % comb, two)
+        r, out = run(txt, comb)
+        assert r.returncode == 0, r.stdout + r.stderr
+        mt = re.search(r"iterations (\d+) relres (\S+)", r.stdout)
+        assert mt, r.stdout
+        part = np.loadtxt(out)
+        x = np.zeros(int(part[:, 0].max()) + 1)
+        x[part[:, 0].astype(int)] = part[:, 1]
+        res[comb] = (x, int(mt.group(1)), float(mt.group(2)))
+    om = fo.build_mesh_structured(3, 1, 12)
+    A_bc, rhs_bc, _, _, _ = fo.laplace_problem(om)
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    for comb in res:
+        assert res[comb][2] <= 1e-12
+        np.testing.assert_allclose(res[comb][0], xd, rtol=0, atol=1e-10 * np.abs(xd).max())
+    # the coarse pre-apply leaves a smaller ||r_0||: the multiplicative run never needs more iterations to the same
+    # RELATIVE reduction ... of a smaller initial residual; what is checked is that the key changed the run
+    assert res["Multiplicative"][1] != res["Additive"][1] or \
+        not np.array_equal(res["Multiplicative"][0], res["Additive"][0])
+    bad = re.sub(r'(name="CoarseOperator Type" type="string" value=")[A-Za-z0-9]+"', r'\1IPOUHarmonicCoarseOperator"', two)
+    r, _ = run(bad, "ipou")
+    assert r.returncode != 0 and "IPOUHarmonicCoarseOperator" in (r.stdout + r.stderr)
