@@ -185,12 +185,21 @@ def env_options(c):
         c.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 
 
-def timed_passes(c, step, steps, warmup, stride=1):
+def timed_passes(c, step, steps, warmup, stride=1, wall_without_timers=False):
     """`warmup` untimed and `steps` timed passes of step() on one context; wall ms per pass, the last pass' return value and the
-    device-time table"""
+    device-time table.  wall_without_timers: the wall time comes from `steps` passes with the device timers OFF (an event pair
+    around every launch of a launch-bound step costs 10 % and more of it), the table from `steps` further passes with them on"""
     for _ in range(warmup):
         step()
     c.sync()
+    wall = None
+    if wall_without_timers:
+        c.timing_enable(0)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        c.sync()
+        wall = (time.perf_counter() - t0) / steps * 1e3
     c.timing_enable(stride)
     c.timing_reset()
     t0 = time.perf_counter()
@@ -198,9 +207,13 @@ def timed_passes(c, step, steps, warmup, stride=1):
     for _ in range(steps):
         ret = step()
     c.sync()
-    wall = (time.perf_counter() - t0) / steps * 1e3
+    wall_t = (time.perf_counter() - t0) / steps * 1e3
     tm = c.timing_get()
     c.timing_enable(0)
+    if wall is None:
+        wall = wall_t
+    else:
+        tm["_wall_with_timers_ms"] = wall_t
     return wall, ret, tm
 
 
@@ -230,14 +243,18 @@ def extra_per_gpu_share(capi, dev, a, its_headline):
         c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
         return c.gmres(None, rtol=1e-300, max_it=its_headline, restart=a.restart, use_prec=True, want_x=False)[1:]
 
-    wall, (its, rel), tm = timed_passes(c, step, 3, 2)
+    wall, (its, rel), tm = timed_passes(c, step, 5, 2, wall_without_timers=True)
+    wall_timed = tm.pop("_wall_with_timers_ms")
     per_it = ("spmv", "schwarz_apply", "ortho", "gs_dot", "gs_update")
-    dev_total = sum(v[0] for k, v in tm.items() if k not in ("gs_dot", "gs_update", "allreduce")) / 3
+    dev_total = sum(v[0] for k, v in tm.items() if k not in ("gs_dot", "gs_update", "allreduce")) / 5
     out = {"workload": "107^3-cell cube, %d dofs, held to the %d iterations of the 214^3 grid" % (m["n_global"], its),
-           "ms_per_step": wall, "gmres_iterations": its, "phases_device_ms_per_step": phases(tm, 3),
-           "device_us_per_iteration": {k: round(tm[k][0] / 3 / max(its, 1) * 1e3, 2) for k in per_it},
+           "ms_per_step": wall, "ms_per_step_with_event_timers": wall_timed,
+           "note": "ms_per_step: 5 steps with the device timers off (round 3 quoted the step WITH an event pair around every "
+                   "launch: 21.1 ms); the device table below is from 5 further steps with the timers on",
+           "gmres_iterations": its, "phases_device_ms_per_step": phases(tm, 5),
+           "device_us_per_iteration": {k: round(tm[k][0] / 5 / max(its, 1) * 1e3, 2) for k in per_it},
            "device_ms_per_step": dev_total, "wall_minus_device_ms": wall - dev_total,
-           "solve_device_ms_per_iteration": round(sum(tm[k][0] for k in ("spmv", "schwarz_apply", "ortho")) / 3 / max(its, 1), 4),
+           "solve_device_ms_per_iteration": round(sum(tm[k][0] for k in ("spmv", "schwarz_apply", "ortho")) / 5 / max(its, 1), 4),
            "gmres": c.gmres_info(), "schwarz": c.schwarz_info()}
     c.close()
     return out
@@ -398,6 +415,8 @@ def main():
     if not a.cpu_cells:
         a.cpu_cells = min(128, max(cells))
 
+    cold = {}
+
     def measure(c, n_global, two_level, extra=True):
         """W warm-up steps, then exactly K timed steps between barriers; max over ranks."""
         # the headline takes exactly the W warm-up steps of the contract; the extra measurements (two-level variant,
@@ -407,6 +426,12 @@ def main():
         n_w = 0
         while n_w < a.warmup or (extra and time.perf_counter() - t_w < 0.25 and n_w < 50):
             one_step(c, capi, a, two_level)
+            if n_w == 0 and not extra and "first_step_ms" not in cold:
+                # the very first step on this mesh: the per-mesh structures (node -> element adjacency, tile structures of
+                # the assembly kernel), first-touch allocations and everything a steady-state step does
+                c.sync()
+                cold["first_step_ms"] = (time.perf_counter() - t_w) * 1e3
+                cold["per_mesh_setup"] = c.mesh_setup_info()
             n_w += 1
         c.sync()
         # HIP events on the library's stream, live in the timed region; the per-iteration kernels are
@@ -511,6 +536,28 @@ def main():
     c = capi.Context(device=dev, rank=rank, nranks=N, nccl_id=nccl_id)
     for kv in filter(None, os.environ.get("FEDD_OPTIONS", "").split(",")):   # development: key=value,...
         c.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+    preflight = None
+    if N > 1 and not rehearse:
+        # pre-flight: the solver's collectives on the library's own communicator (all-reduce, grouped send / receive with every
+        # rank, ring shift) before any work depends on them, under a watchdog -- a misuse of RCCL ends the run within a minute
+        # and with a message instead of hanging the scaling run
+        import threading
+
+        def _hung():
+            sys.stderr.write("bench.py: rank %d: the RCCL pre-flight (fedd_comm_selftest) did not return within 90 s\n" % rank)
+            sys.stderr.flush()
+            os._exit(3)
+
+        wd = threading.Timer(90.0, _hung)
+        wd.daemon = True
+        wd.start()
+        t_pf = time.perf_counter()
+        pf_err = c.comm_selftest(65536)
+        wd.cancel()
+        pf_err = max_over_ranks(pf_err)
+        preflight = {"max_abs_err": pf_err, "seconds": time.perf_counter() - t_pf, "doubles_per_message": 65536}
+        if not pf_err <= 1e-9:
+            raise SystemExit("bench.py: RCCL pre-flight failed: max deviation %r" % pf_err)
     t0 = time.perf_counter()
     c.mesh_set_dict(m)
     if N > 1:
@@ -705,8 +752,15 @@ def main():
                         "with column_patterns > 0 the rows repeat their column offsets and the stream carries a 2-byte "
                         "pattern id per row instead of 4 bytes per entry (values per row, y bit for bit the same)"},
             "mesh_generation_s": t_mesh, "mesh_upload_s": t_upload,
+            # what a driver that assembles and solves ONCE pays (the reference's drivers do): the cold first step, and inside it
+            # the structures built once per mesh by device kernels (wall ms each, device synchronised around them)
+            "first_step_ms": cold.get("first_step_ms"),
+            "per_mesh_setup_ms": None if "per_mesh_setup" not in cold else
+                round(cold["per_mesh_setup"]["adjacency_ms"] + cold["per_mesh_setup"]["tiles_ms"], 3),
+            "per_mesh_setup": cold.get("per_mesh_setup"),
         }
         if N > 1:
+            out["rccl_preflight"] = preflight
             out["self_check"] = self_check
             out["communication_note"] = ("phases 'halo' (pack kernel, grouped RCCL send/receive, unpack kernel; one before every SpMV "
                                          "and every Schwarz apply) and 'allreduce' are HIP-event times on the library's stream, rank 0, "

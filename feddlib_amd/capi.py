@@ -96,9 +96,11 @@ SIGNATURES = {
     "fedd_gmres_info": [C.c_void_p, _ip, _ip, _ip, _ip],
     "fedd_gmres_x0": [C.c_void_p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int, _ip, _f64p],
     "fedd_gmres_status": [C.c_void_p, _ip, _f64p],
+    "fedd_mesh_setup_info": [C.c_void_p, _f64p, _f64p, _ip, _i64p],
     "fedd_schwarz_coarse_apply": [C.c_void_p, _f64p, _f64p],
     "fedd_read_bandwidth": [C.c_void_p, C.c_int64, C.c_int, _f64p],
     "fedd_rccl_selftest": [C.c_void_p, C.c_int, _f64p],
+    "fedd_comm_selftest": [C.c_void_p, C.c_int, _f64p],
     "fedd_halo_plan_sizes": [C.c_void_p, _ip, _i64p, _i64p],
     "fedd_halo_plan_get": [C.c_void_p, _i32p, _i64p, _i32p, _i64p, _i32p],
     "fedd_halo_set_owners": [C.c_void_p, C.c_int64, _i64p, _i32p],
@@ -547,6 +549,11 @@ class Context:
                                    C.byref(its), C.byref(rel)))
         return (x if x is not None else self.solution_get()), its.value, rel.value
 
+    def mesh_setup_info(self):
+        a, t, st, nt = C.c_double(), C.c_double(), C.c_int(), C.c_int64()
+        _chk(self._L.fedd_mesh_setup_info(self._h, C.byref(a), C.byref(t), C.byref(st), C.byref(nt)))
+        return {"adjacency_ms": a.value, "tiles_ms": t.value, "tiles_state": st.value, "n_tiles": nt.value}
+
     def gmres_status(self):
         fl, rr = C.c_int(), C.c_double()
         _chk(self._L.fedd_gmres_status(self._h, C.byref(fl), C.byref(rr)))
@@ -730,6 +737,12 @@ class Context:
     def rccl_selftest(self, n=4096):
         e = C.c_double()
         _chk(self._L.fedd_rccl_selftest(self._h, n, C.byref(e)))
+        return e.value
+
+    def comm_selftest(self, n=4096):
+        """the solver's collectives on this context's own communicator (every rank calls it); largest deviation"""
+        e = C.c_double()
+        _chk(self._L.fedd_comm_selftest(self._h, n, C.byref(e)))
         return e.value
 
     def halo_exchange_setup(self):

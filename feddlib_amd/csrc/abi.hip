@@ -721,6 +721,15 @@ extern "C" int fedd_gmres_x0(fedd_ctx* c, const double* b_owned, double* x_owned
     return 0;
 }
 
+extern "C" int fedd_mesh_setup_info(fedd_ctx* c, double* adjacency_ms, double* tiles_ms, int* tiles_state, int64_t* n_tiles) {
+    FEDD_CHECK(c, "fedd_mesh_setup_info: null context");
+    if (adjacency_ms) *adjacency_ms = c->have_adj ? c->adj_build_ms : 0.0;
+    if (tiles_ms) *tiles_ms = c->tl_state != 0 ? c->tl_build_ms : 0.0;
+    if (tiles_state) *tiles_state = c->tl_state;
+    if (n_tiles) *n_tiles = c->tl_state == 1 ? c->tl_ntile : 0;
+    return 0;
+}
+
 extern "C" int fedd_gmres_status(fedd_ctx* c, int* floor_reached, double* recurrence_relres) {
     FEDD_CHECK(c, "fedd_gmres_status: null context");
     if (floor_reached) *floor_reached = c->gmres_floor;
@@ -773,6 +782,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
         c->cs_valid = false;
     }
     else if (k == "spmv_exact_public") c->spmv_exact_public = (int)value;
+    else if (k == "asm_tiles_host") { c->asm_tiles_host = (int)value; c->tl_state = 0; }
     else if (k == "whole_boxes") c->whole_boxes = (int)value;
     else if (k == "gdsw_tol") {
         FEDD_CHECK(value > 0.0 && value < 1.0, "fedd_set_option: gdsw_tol %g", value);

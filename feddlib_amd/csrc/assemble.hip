@@ -18,6 +18,8 @@
 #include "fedd_internal.hpp"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <climits>
 #include <cmath>
 #include <thread>
 
@@ -1283,9 +1285,482 @@ static int build_tiles(fedd_ctx* c) {
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same tile structures built ON THE DEVICE (default since round 4; option "asm_tiles_host" 1 = the host builder above):
+// no copy of the mesh back to the host, no host pass.  Cell binning by counting sort (k_tb_cell / k_tb_fill / k_tb_sort_cells),
+// then one workgroup per tile (k_tb_build): the distinct elements and vertices of the tile by two bitonic sorts in LDS, the
+// per-slot gather lists by a wave per node (a lane per CSR slot walks the node's adjacency once to count and once to fill: the
+// entries of a slot stay in adjacency order, the summation order of the pair kernels), the blob put together in LDS and written
+// as one contiguous stream.  A sizes pass (FILL = false) runs first; tiles that do not fit the limits are split in halves
+// (k_tb_split_*) and sized again, as the host builder's recursion does.  The slot of a neighbour is its position in the
+// node's row of the CURRENT pattern (columns sorted): the node-level pattern is a function of the mesh alone.
+// ---------------------------------------------------------------------------------------------
+constexpr int TB_BS = 256;        // threads of the build kernel
+constexpr int TB_SORT = 2048;     // capacity of the LDS sorts: adjacency entries / element vertices of a tile
+constexpr int TB_NSMAX = 64;      // most CSR slots of a node (a wave takes a node, a lane a slot)
+
+struct TbGeom {
+    double lo[3], L[3];
+    int g[3];
+};
+
+template <int DIM>
+__global__ void k_tb_cell(const double* __restrict__ xyz, int32_t nn, TbGeom gm, int32_t* __restrict__ cell, int32_t* __restrict__ cnt) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    int64_t id = 0, mul = 1;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        int k = gm.L[d] > 0 ? (int)floor((xyz[(size_t)i * DIM + d] - gm.lo[d]) / gm.L[d] * gm.g[d]) : 0;
+        k = min(gm.g[d] - 1, max(0, k));
+        id += mul * k;
+        mul *= gm.g[d];
+    }
+    cell[i] = (int32_t)id;
+    atomicAdd(&cnt[id], 1);
+}
+
+__global__ void k_tb_fill(const int32_t* __restrict__ cell, int32_t nn, int32_t* __restrict__ cursor, int32_t* __restrict__ order) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nn) order[atomicAdd(&cursor[cell[i]], 1)] = i;
+}
+
+// a wave per cell: its nodes ascending (rank sort through LDS; longer cells in global memory, lane 0)
+__global__ __launch_bounds__(64) void k_tb_sort_cells(const int32_t* __restrict__ ptr, int32_t ncell, int32_t* order) {
+    __shared__ int32_t sh[1024];
+    const int32_t b = ptr[blockIdx.x], e = ptr[blockIdx.x + 1];
+    const int n = e - b, lane = threadIdx.x;
+    if (n <= 1) return;
+    if (n > 1024) {
+        if (lane == 0)
+            for (int32_t i = b + 1; i < e; ++i) {
+                const int32_t v = order[i];
+                int32_t j = i - 1;
+                while (j >= b && order[j] > v) {
+                    order[j + 1] = order[j];
+                    --j;
+                }
+                order[j + 1] = v;
+            }
+        return;
+    }
+    for (int i = lane; i < n; i += 64) sh[i] = order[b + i];
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+        const int32_t v = sh[i];
+        int rank = 0;
+        for (int k = 0; k < n; ++k) rank += sh[k] < v ? 1 : 0;
+        order[b + rank] = v;
+    }
+}
+
+__global__ void k_tb_flag_cells(const int32_t* __restrict__ ptr, int32_t ncell, int32_t* __restrict__ flag) {
+    const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < ncell) flag[k] = ptr[k + 1] > ptr[k] ? 1 : 0;
+}
+
+__global__ void k_tb_pieces0(const int32_t* __restrict__ ptr, int32_t ncell, const int32_t* __restrict__ pos, int2* __restrict__ pieces) {
+    const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < ncell && ptr[k + 1] > ptr[k]) pieces[pos[k]] = make_int2(ptr[k], ptr[k + 1]);
+}
+
+__global__ void k_tb_split_count(const int32_t* __restrict__ split, int32_t n, int32_t* __restrict__ cnt) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cnt[i] = split[i] ? 2 : 1;
+}
+
+__global__ void k_tb_split_scatter(const int2* __restrict__ in, const int32_t* __restrict__ split, const int32_t* __restrict__ pos,
+                                   int32_t n, int2* __restrict__ out) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int2 pc = in[i];
+    if (split[i]) {
+        const int32_t mid = pc.x + (pc.y - pc.x) / 2;
+        out[pos[i]] = make_int2(pc.x, mid);
+        out[pos[i] + 1] = make_int2(mid, pc.y);
+    } else {
+        out[pos[i]] = pc;
+    }
+}
+
+__global__ void k_tb_set_off(TileHdr* __restrict__ hdr, const int64_t* __restrict__ off, int32_t n) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hdr[i].off = (uint32_t)off[i];
+}
+
+// ascending bitonic sort of s[0, N), N a power of two, by the whole workgroup
+__device__ __forceinline__ void tb_bitonic(int32_t* s, int N, int tid) {
+    for (int k = 2; k <= N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < (N >> 1); i += TB_BS) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo + j;
+                const bool up = (lo & k) == 0;
+                const int32_t a = s[lo], b = s[hi];
+                if ((a > b) == up) {
+                    s[lo] = b;
+                    s[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// exclusive prefix of one value per thread over the workgroup (sh: TB_BS + 1 ints); *total = the sum
+__device__ __forceinline__ int tb_scan(int v, int32_t* sh, int tid, int* total) {
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < TB_BS; off <<= 1) {
+        const int t = tid >= off ? sh[tid - off] : 0;
+        __syncthreads();
+        sh[tid] += t;
+        __syncthreads();
+    }
+    const int incl = sh[tid];
+    *total = sh[TB_BS - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+__device__ __forceinline__ int tb_find(const int32_t* s, int n, int32_t v) {   // position of v in the ascending s[0, n), -1 if absent
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < n && s[lo] == v ? lo : -1;
+}
+
+__device__ __forceinline__ int tb_upper(const int32_t* pre, int n, int t) {    // the p in [0, n) with pre[p] <= t < pre[p + 1]
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pre[mid] <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// counters: 0 = pieces to split, 1 = a single node that does not fit (the mesh stays on the pair kernels), 2 / 3 / 4 = largest
+// element count / extended node count / blob words
+template <int DIM, bool FILL>
+__global__ __launch_bounds__(TB_BS) void k_tb_build(const int2* __restrict__ pieces, const int32_t* __restrict__ order,
+                                                    const int32_t* __restrict__ conn, const double* __restrict__ xyz,
+                                                    const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e,
+                                                    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, int dofs,
+                                                    int full, TileHdr* __restrict__ hdr, int64_t* __restrict__ words,
+                                                    int32_t* __restrict__ split, int32_t* __restrict__ counters,
+                                                    uint32_t* __restrict__ blob) {
+    constexpr int NEN = DIM + 1;
+    __shared__ int32_t s_sort[TB_SORT];
+    __shared__ int32_t s_els[TL_ELMAX];
+    __shared__ int32_t s_ext[256];
+    __shared__ int32_t s_nodes[TL_RMAX];
+    __shared__ int32_t s_degp[TL_RMAX + 1];     // prefix of the nodes' adjacency lengths
+    __shared__ int32_t s_nsl[TL_RMAX + 1];      // prefix of (slots + 1): the blob's sp
+    __shared__ int32_t s_nbp[TL_RMAX + 1];      // prefix of the slots
+    __shared__ int32_t s_scan[TB_BS + 1];
+    __shared__ int32_t s_flag[2];
+    __shared__ uint32_t s_elrec[FILL ? TL_ELMAX : 1];
+    __shared__ uint16_t s_adj[FILL ? TB_SORT : 2];
+    __shared__ uint8_t s_nbrl[FILL ? TL_RMAX * TB_NSMAX : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_blob[FILL ? TL_BLOBMAX : 2];
+    const int tid = threadIdx.x, tI = blockIdx.x;
+    const int2 pc = pieces[tI];
+    const int R = pc.y - pc.x;
+    bool fail = R > TL_RMAX || R < 1;
+    int total = 0, NS = 0, MAXS = 0, EL = 0, NE = 0;
+    if (!fail) {
+        if (tid < R) {
+            const int32_t nd = order[pc.x + tid];
+            s_nodes[tid] = nd;
+            s_degp[tid + 1] = n2e_ptr[nd + 1] - n2e_ptr[nd];
+            const int32_t row = nd * dofs, len = rowptr[row + 1] - rowptr[row];
+            s_nbp[tid + 1] = full ? len / dofs : len;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_degp[0] = s_nbp[0] = s_nsl[0] = 0;
+            int mx = 0;
+            for (int p = 0; p < R; ++p) {
+                mx = max(mx, s_nbp[p + 1]);
+                s_nsl[p + 1] = s_nsl[p] + s_nbp[p + 1] + 1;
+                s_degp[p + 1] += s_degp[p];
+                s_nbp[p + 1] += s_nbp[p];
+            }
+            s_flag[0] = mx;
+        }
+        __syncthreads();
+        total = s_degp[R];
+        NS = s_nsl[R];
+        MAXS = s_flag[0];
+        fail = total > TB_SORT || MAXS > TB_NSMAX;
+    }
+    if (!fail) {    // (uniform) the distinct elements of the tile, ascending
+        int N = 2;
+        while (N < total) N <<= 1;
+        for (int i = tid; i < N; i += TB_BS) s_sort[i] = INT32_MAX;
+        __syncthreads();
+        for (int t = tid; t < total; t += TB_BS) {
+            const int p = tb_upper(s_degp, R, t);
+            s_sort[t] = n2e[n2e_ptr[s_nodes[p]] + (t - s_degp[p])] / NEN;
+        }
+        __syncthreads();
+        tb_bitonic(s_sort, N, tid);
+        const int C = (N + TB_BS - 1) / TB_BS, i0 = tid * C, i1 = min(N, i0 + C);
+        int cnt = 0;
+        for (int i = i0; i < i1; ++i) cnt += s_sort[i] != INT32_MAX && (i == 0 || s_sort[i] != s_sort[i - 1]) ? 1 : 0;
+        int pos = tb_scan(cnt, s_scan, tid, &EL);
+        for (int i = i0; i < i1; ++i)
+            if (s_sort[i] != INT32_MAX && (i == 0 || s_sort[i] != s_sort[i - 1])) {
+                if (pos < TL_ELMAX) s_els[pos] = s_sort[i];
+                ++pos;
+            }
+        __syncthreads();
+        fail = EL > TL_ELMAX;
+    }
+    if (!fail) {    // the distinct vertices of those elements that are not nodes of the tile, ascending, behind the tile's nodes
+        int N = 2;
+        while (N < EL * NEN) N <<= 1;
+        for (int i = tid; i < N; i += TB_BS) s_sort[i] = INT32_MAX;
+        __syncthreads();
+        for (int t = tid; t < EL * NEN; t += TB_BS) s_sort[t] = conn[(size_t)s_els[t / NEN] * NEN + (t % NEN)];
+        __syncthreads();
+        tb_bitonic(s_sort, N, tid);
+        const int C = (N + TB_BS - 1) / TB_BS, i0 = tid * C, i1 = min(N, i0 + C);
+        int cnt = 0;
+        for (int i = i0; i < i1; ++i)
+            cnt += s_sort[i] != INT32_MAX && (i == 0 || s_sort[i] != s_sort[i - 1]) && tb_find(s_nodes, R, s_sort[i]) < 0 ? 1 : 0;
+        int others = 0;
+        int pos = tb_scan(cnt, s_scan, tid, &others);
+        NE = R + others;
+        for (int i = i0; i < i1; ++i)
+            if (s_sort[i] != INT32_MAX && (i == 0 || s_sort[i] != s_sort[i - 1]) && tb_find(s_nodes, R, s_sort[i]) < 0) {
+                if (R + pos < 256) s_ext[R + pos] = s_sort[i];
+                ++pos;
+            }
+        if (tid < R) s_ext[tid] = s_nodes[tid];
+        __syncthreads();
+        fail = NE > TL_EXTMAX;
+    }
+    const int GN = total * NEN;
+    const int nw_raw = 2 * DIM * NE + NE + R + EL + 2 * (R + 1) + ((NS + 1) >> 1) + ((GN + 1) >> 1);
+    if (!fail) fail = nw_raw > TL_BLOBMAX || NS > 65535 || GN > 65535;
+    if constexpr (!FILL) {
+        if (tid == 0) {
+            hdr[tI] = TileHdr{0u, (uint16_t)R, (uint16_t)NE, (uint16_t)EL, (uint16_t)NS, (uint16_t)GN, (uint16_t)MAXS};
+            words[tI] = fail ? 0 : (int64_t)((nw_raw + 1) & ~1);
+            split[tI] = fail ? 1 : 0;
+            if (fail) {
+                atomicAdd(&counters[0], 1);
+                if (R <= 1) atomicMax(&counters[1], 1);
+            } else {
+                atomicMax(&counters[2], EL);
+                atomicMax(&counters[3], NE);
+                atomicMax(&counters[4], (nw_raw + 1) & ~1);
+            }
+        }
+        return;
+    } else {
+        if (fail) {     // (cannot happen: the sizes pass accepted this tile)
+            if (tid == 0) atomicMax(&counters[1], 1);
+            return;
+        }
+        auto ext_local = [&](int32_t v) -> uint32_t {
+            const int a = tb_find(s_nodes, R, v);
+            return a >= 0 ? (uint32_t)a : (uint32_t)(R + tb_find(s_ext + R, NE - R, v));
+        };
+        const int o_ext = 2 * DIM * NE, o_nb = o_ext + NE, o_el = o_nb + R, o_gp = o_el + EL, o_sp = o_gp + R + 1, o_gs = o_sp + R + 1,
+                  o_gl = o_gs + ((NS + 1) >> 1), nw = (nw_raw + 1) & ~1;
+        for (int i = tid; i < nw; i += TB_BS) s_blob[i] = 0u;
+        for (int q = tid; q < EL; q += TB_BS) {
+            uint32_t rec = 0;
+#pragma unroll
+            for (int j = 0; j < NEN; ++j) rec |= ext_local(conn[(size_t)s_els[q] * NEN + j]) << (8 * j);
+            s_elrec[q] = rec;
+        }
+        for (int t = tid; t < total; t += TB_BS) {
+            const int p = tb_upper(s_degp, R, t);
+            const int32_t idx = n2e[n2e_ptr[s_nodes[p]] + (t - s_degp[p])], el = idx / NEN, li = idx - el * NEN;
+            s_adj[t] = (uint16_t)((tb_find(s_els, EL, el) << 2) | li);
+        }
+        const int nnb = s_nbp[R];
+        for (int t = tid; t < nnb; t += TB_BS) {
+            const int p = tb_upper(s_nbp, R, t), sl = t - s_nbp[p];
+            const int32_t rs = rowptr[s_nodes[p] * dofs];
+            s_nbrl[t] = (uint8_t)ext_local(colind[rs + (full ? sl * dofs : sl)] / dofs);
+        }
+        __syncthreads();
+        double* cw = reinterpret_cast<double*>(s_blob);
+        for (int t = tid; t < NE * DIM; t += TB_BS) cw[t] = xyz[(size_t)s_ext[t / DIM] * DIM + (t % DIM)];
+        for (int t = tid; t < NE; t += TB_BS) s_blob[o_ext + t] = (uint32_t)s_ext[t];
+        if (tid < R) {
+            const int32_t rs = rowptr[s_nodes[tid] * dofs];
+            s_blob[o_nb + tid] = (uint32_t)(dofs == 1 ? rs : (full ? rs / (dofs * dofs) : rs / dofs));
+        }
+        for (int t = tid; t < EL; t += TB_BS) s_blob[o_el + t] = s_elrec[t];
+        if (tid <= R) {
+            s_blob[o_gp + tid] = (uint32_t)(s_degp[tid] * NEN);
+            s_blob[o_sp + tid] = (uint32_t)s_nsl[tid];
+        }
+        __syncthreads();
+        // gather lists: a wave per node, a lane per slot; the lane walks the node's adjacency twice (count, fill)
+        uint16_t* gs = reinterpret_cast<uint16_t*>(s_blob + o_gs);
+        uint16_t* gl = reinterpret_cast<uint16_t*>(s_blob + o_gl);
+        const int w = tid >> 6, lane = tid & 63;
+        for (int p = w; p < R; p += TB_BS / 64) {
+            const int nslot = s_nbp[p + 1] - s_nbp[p], qb = s_degp[p], qe = s_degp[p + 1];
+            const uint32_t target = lane < nslot ? s_nbrl[s_nbp[p] + lane] : 0xffffu;
+            int cnt = 0;
+            for (int q = qb; q < qe; ++q) {
+                const uint32_t rec = s_elrec[s_adj[q] >> 2];
+                bool hit = false;
+#pragma unroll
+                for (int j = 0; j < NEN; ++j) hit = hit || ((rec >> (8 * j)) & 255u) == target;
+                cnt += hit ? 1 : 0;
+            }
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            int k = incl - cnt;
+            if (lane < nslot) gs[s_nsl[p] + lane] = (uint16_t)k;
+            if (lane == nslot - 1) gs[s_nsl[p] + nslot] = (uint16_t)incl;
+            if (lane < nslot) {
+                uint16_t* dst = gl + qb * NEN;
+                for (int q = qb; q < qe; ++q) {
+                    const uint32_t a = s_adj[q], rec = s_elrec[a >> 2];
+#pragma unroll
+                    for (int j = 0; j < NEN; ++j)
+                        if (((rec >> (8 * j)) & 255u) == target) dst[k++] = (uint16_t)(((a >> 2) << 4) | ((a & 3u) << 2) | (uint32_t)j);
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t* out = blob + hdr[tI].off;
+        for (int i = tid; i < nw; i += TB_BS) out[i] = s_blob[i];
+    }
+}
+
+static int build_tiles_device(fedd_ctx* c) {
+    const int dim = c->dim, nen = c->nen;
+    const int64_t nn = c->n_own + c->n_rowg;          // nodes with rows
+    c->tl_state = -1;
+    if (nen != dim + 1 || nn <= 0 || c->n_elem <= 0 || !c->have_pattern || !c->have_adj || nn > ((int64_t)1 << 30)) return 0;
+    hipStream_t st = c->stream;
+    // ---- nodes -> cells of a coordinate lattice with ~27 nodes each (the host builder's lattice) ----
+    double lo[3], hi[3];
+    {
+        DevBuf<double> mm;      // (the context's double scratch holds the quadrature tables of the assembly in progress)
+        FEDD_TRY(mm.ensure(768));
+        FEDD_TRY(bounding_box(c, nn, lo, hi, mm.p));
+    }
+    double V = 1.0;
+    for (int d = 0; d < dim; ++d) V *= std::max(hi[d] - lo[d], 1e-300);
+    const double target = dim == 3 ? 27.0 : 25.0;
+    const double w = std::pow(V * target / (double)nn, 1.0 / dim);
+    TbGeom gm;
+    int64_t ncell = 1;
+    for (int d = 0; d < 3; ++d) {
+        gm.lo[d] = d < dim ? lo[d] : 0.0;
+        gm.L[d] = d < dim ? hi[d] - lo[d] : 0.0;
+        gm.g[d] = d < dim ? std::max(1, (int)std::floor((hi[d] - lo[d]) / w + 0.5)) : 1;
+        ncell *= gm.g[d];
+    }
+    if (ncell > ((int64_t)1 << 30)) return 0;
+    DevBuf<int32_t> cell, cptr, cursor, order, flag, split, cnt, counters;
+    DevBuf<int64_t> words;
+    DevBuf<int2> pieces[2];
+    FEDD_TRY(cell.ensure((size_t)nn));
+    FEDD_TRY(cptr.ensure((size_t)ncell + 2));
+    FEDD_TRY(cursor.ensure((size_t)ncell + 2));
+    FEDD_TRY(order.ensure((size_t)nn));
+    FEDD_TRY(flag.ensure((size_t)ncell + 2));
+    FEDD_TRY(counters.ensure(8));
+    FEDD_HIP(hipMemsetAsync(cptr.p, 0, ((size_t)ncell + 2) * sizeof(int32_t), st));
+    const dim3 blk(256), gnn((unsigned)((nn + 255) / 256)), gc((unsigned)((ncell + 255) / 256));
+    if (dim == 3) hipLaunchKernelGGL(k_tb_cell<3>, gnn, blk, 0, st, (const double*)c->d_xyz.p, (int32_t)nn, gm, cell.p, cptr.p);
+    else hipLaunchKernelGGL(k_tb_cell<2>, gnn, blk, 0, st, (const double*)c->d_xyz.p, (int32_t)nn, gm, cell.p, cptr.p);
+    FEDD_TRY(exclusive_scan_i32(c, cptr.p, cptr.p, ncell, nullptr));
+    FEDD_HIP(hipMemcpyAsync(cursor.p, cptr.p, ((size_t)ncell + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_tb_fill, gnn, blk, 0, st, (const int32_t*)cell.p, (int32_t)nn, cursor.p, order.p);
+    hipLaunchKernelGGL(k_tb_sort_cells, dim3((unsigned)ncell), dim3(64), 0, st, (const int32_t*)cptr.p, (int32_t)ncell, order.p);
+    hipLaunchKernelGGL(k_tb_flag_cells, gc, blk, 0, st, (const int32_t*)cptr.p, (int32_t)ncell, flag.p);
+    int64_t npiece = 0;
+    FEDD_TRY(exclusive_scan_i32(c, flag.p, flag.p, ncell, &npiece));
+    if (npiece <= 0) return 0;
+    FEDD_TRY(pieces[0].ensure((size_t)npiece));
+    hipLaunchKernelGGL(k_tb_pieces0, gc, blk, 0, st, (const int32_t*)cptr.p, (int32_t)ncell, (const int32_t*)flag.p, pieces[0].p);
+    // ---- sizes; tiles that do not fit are split in halves and sized again ----
+    const int full = c->block_mode == FEDD_BLOCK_FULL ? 1 : 0;
+    int cur = 0;
+    int32_t h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int round = 0;; ++round) {
+        FEDD_CHECK(round < 40, "tile build: the splitting does not end");
+        FEDD_TRY(c->tl_hdr.ensure((size_t)npiece * sizeof(TileHdr) / sizeof(uint32_t)));
+        FEDD_TRY(words.ensure((size_t)npiece + 2));
+        FEDD_TRY(split.ensure((size_t)npiece + 2));
+        FEDD_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(int32_t), st));
+#define TB_BUILD(D, F)                                                                                                             \
+    hipLaunchKernelGGL((k_tb_build<D, F>), dim3((unsigned)npiece), dim3(TB_BS), 0, st, (const int2*)pieces[cur].p,               \
+                       (const int32_t*)order.p, (const int32_t*)c->d_conn.p, (const double*)c->d_xyz.p,                           \
+                       (const int32_t*)c->d_n2e_ptr.p, (const int32_t*)c->d_n2e.p, (const int32_t*)c->d_rowptr.p,                 \
+                       (const int32_t*)c->d_colind.p, c->dofs, full, reinterpret_cast<TileHdr*>(c->tl_hdr.p), words.p, split.p,   \
+                       counters.p, c->tl_blob.p)
+        if (dim == 3) TB_BUILD(3, false);
+        else TB_BUILD(2, false);
+        FEDD_HIP(hipMemcpyAsync(h_cnt, counters.p, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        FEDD_HIP(hipStreamSynchronize(st));
+        if (h_cnt[1]) return 0;          // a single node that does not fit: the mesh stays on the pair kernels
+        if (h_cnt[0] == 0) break;
+        FEDD_TRY(cnt.ensure((size_t)npiece + 2));
+        const dim3 gp((unsigned)((npiece + 255) / 256));
+        hipLaunchKernelGGL(k_tb_split_count, gp, blk, 0, st, (const int32_t*)split.p, (int32_t)npiece, cnt.p);
+        int64_t nnew = 0;
+        FEDD_TRY(exclusive_scan_i32(c, cnt.p, cnt.p, npiece, &nnew));
+        FEDD_TRY(pieces[cur ^ 1].ensure((size_t)nnew));
+        hipLaunchKernelGGL(k_tb_split_scatter, gp, blk, 0, st, (const int2*)pieces[cur].p, (const int32_t*)split.p,
+                           (const int32_t*)cnt.p, (int32_t)npiece, pieces[cur ^ 1].p);
+        cur ^= 1;
+        npiece = nnew;
+    }
+    // ---- blob offsets, then the blobs ----
+    int64_t total_words = 0;
+    FEDD_TRY(exclusive_scan_i64(c, words.p, words.p, npiece, &total_words));
+    if (total_words >= ((int64_t)1 << 32)) return 0;      // 32-bit word offsets
+    hipLaunchKernelGGL(k_tb_set_off, dim3((unsigned)((npiece + 255) / 256)), blk, 0, st, reinterpret_cast<TileHdr*>(c->tl_hdr.p),
+                       (const int64_t*)words.p, (int32_t)npiece);
+    FEDD_TRY(c->tl_blob.ensure((size_t)total_words + 2));
+    FEDD_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(int32_t), st));
+    if (dim == 3) TB_BUILD(3, true);
+    else TB_BUILD(2, true);
+#undef TB_BUILD
+    int32_t h_bad[2] = {0, 0};
+    FEDD_HIP(hipMemcpyAsync(h_bad, counters.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FEDD_HIP(hipStreamSynchronize(st));
+    FEDD_HIP(hipGetLastError());
+    if (h_bad[1]) return 0;
+    c->tl_ntile = npiece;
+    c->tl_max_el = h_cnt[2];
+    c->tl_max_ext = h_cnt[3];
+    c->tl_max_blob = h_cnt[4];
+    c->tl_state = 1;
+    return 0;
+}
+
 template <int DIM, int FORM>
 int launch_tiles(fedd_ctx* c, const AsmArgs& a, int ntab) {
-    if (c->tl_state == 0) FEDD_TRY(build_tiles(c));
+    if (c->tl_state == 0) {     // once per mesh; its wall time is kept for fedd_mesh_setup_info
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        if (c->asm_tiles_host) FEDD_TRY(build_tiles(c));
+        else FEDD_TRY(build_tiles_device(c));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        c->tl_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     if (c->tl_state != 1) return -1;
     constexpr int NEN = DIM + 1, PARK = FORM == F_LAPLACE ? NEN * NEN : NEN * DIM + 1;
     static_assert(sizeof(TileHdr) == 16, "tile header");

@@ -181,6 +181,8 @@ struct fedd_ctx {
     int asm_u = 1;                              // slot-addressed assembly: pairs per lane with their loads in flight together (P1)
     int asm_kind = 0;                           // 0 = slot-addressed pair-parallel assembly, 2 = pair-parallel with slot sweep, 1 = lane-per-row gather
     // element-major tile structures of the current mesh (assemble.hip build_tiles): 0 = not built, 1 = ready, -1 = mesh does not fit
+    int asm_tiles_host = 0;                     // option "asm_tiles_host": 1 = the tile structures are built on the host (the round-3 builder; A/B and tests), 0 = on the device
+    double tl_build_ms = 0.0, adj_build_ms = 0.0;   // wall ms of the per-mesh structures of the current mesh: tile build, node -> element adjacency
     int tl_state = 0, asm_tiles = 1;            // option "asm_tiles": the P1 Laplace / elasticity forms take the element-major tile kernel (0: pair kernels)
     int64_t tl_ntile = 0;
     int tl_max_el = 0, tl_max_ext = 0, tl_max_blob = 0;
@@ -422,7 +424,7 @@ int read_bandwidth(fedd_ctx* c, int64_t bytes, int reps, double* gbs);     // re
 // schwarz.hip
 int schwarz_setup(fedd_ctx* c);
 int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool r_has_tail = false);
-int bounding_box(fedd_ctx* c, int64_t n_nodes, double lo[3], double hi[3]);   // of d_xyz[0, n_nodes)
+int bounding_box(fedd_ctx* c, int64_t n_nodes, double lo[3], double hi[3], double* d_scratch = nullptr);   // of d_xyz[0, n_nodes)
 int global_box(fedd_ctx* c, int64_t n_own, double lo[3], double hi[3], double* n_global);   // over all ranks
 
 // schwarz_big.hip: subdomains of up to 1024 dofs (balanced coordinate-bisection boxes, batched dense inverses on the

@@ -1578,6 +1578,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     if (dbg) fprintf(stderr, "[gmres s-step] basis at %p (%zu MB), ldv %lld\n", (void*)V, c->d_V.cap * sizeof(double) >> 20, (long long)ldv);
     double tol_abs = rtol * beta0;      // target of the recurrence residual; tightened when the true residual lags behind it
     double last_true = beta0;
+    int floor_restarts = 0;             // restarts taken because the true residual stopped following the recurrence
     int nfail = 0;                      // claims of the recurrence that the true residual did not confirm
     double best_fail = 1e300;           // ... and the smallest true residual among them
     int stalls = 0;
@@ -1691,6 +1692,24 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
                         its += cols;
                         relres = ta / beta0;
                         done = true;
+                    } else if (nfail >= 1 && ta >= 0.5 * best_fail && ta <= 100.0 * rtol * beta0 && floor_restarts < 1) {
+                        // the true residual has stopped following the recurrence.  That is either the rounding floor of
+                        // b - A x or only the floor of THIS cycle's recurrence (a cycle is good to about eps * kappa(block
+                        // basis) relative to the residual it started from): one restart from the true residual tells them
+                        // apart -- a new cycle reaches the target if it is reachable (the effect of iterative refinement)
+                        ++floor_restarts;
+                        if (ta < last_true) {
+                            FEDD_TRY(commit());
+                            last_true = ta;
+                        } else {
+                            FEDD_TRY(trial(0, &ta));
+                        }
+                        its += cols;
+                        relres = last_true / beta0;
+                        nfail = 0;
+                        best_fail = 1e300;
+                        tol_abs = rtol * beta0;
+                        restart_now = true;
                     } else if (nfail >= 1 && ta >= 0.5 * best_fail && ta <= 100.0 * rtol * beta0) {
                         // the recurrence keeps falling, the true residual of the computed x does not follow any more: b - A x
                         // has reached its rounding floor (badly scaled systems, tolerances near 1e-13).  The one-vector
@@ -1784,7 +1803,10 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
             relres = last_true / beta0;
             if (last_true <= rtol * beta0) done = true;
         }
-        if (stalls >= 3) break;   // no progress in three cycles: give the caller the residual reached
+        if (stalls >= 3) {        // no progress in three cycles: give the caller the residual reached
+            c->gmres_floor = 2;
+            break;
+        }
     }
     FEDD_HIP(hipGetLastError());
     FEDD_HIP(hipStreamSynchronize(st));

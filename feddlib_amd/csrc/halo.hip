@@ -287,6 +287,67 @@ extern "C" int fedd_rccl_selftest(fedd_ctx* c, int n, double* max_abs_err) {
     return rc;
 }
 
+// The collectives of the N > 1 path on the context's OWN communicator, in the shapes the solver uses them: an in-place
+// all-reduce (allreduce_sum), a grouped send / receive with every other rank (halo_import with all peers: the 2 x 2 x 2
+// decomposition's centre block) and a ring shift.  bench.py runs it as a pre-flight right after the contexts exist, under a
+// watchdog: a misuse of RCCL shows here within seconds and with a message.
+extern "C" int fedd_comm_selftest(fedd_ctx* c, int n, double* max_abs_err) {
+    FEDD_CHECK(c && c->device >= 0, "fedd_comm_selftest needs a GPU context");
+    FEDD_CHECK(n > 0 && max_abs_err, "fedd_comm_selftest: n %d", n);
+    *max_abs_err = 0.0;
+    if (c->nranks == 1) return 0;
+    FEDD_CHECK(c->comm || c->cb_allreduce, "fedd_comm_selftest: no transport (context created without an RCCL id and without host callbacks)");
+    FEDD_HIP(hipSetDevice(c->device));
+    const int N = c->nranks, me = c->rank;
+    double err = 0.0;
+    // (1) all-reduce through the solver's own entry
+    DevBuf<double> a, sb, rb;
+    FEDD_TRY(a.ensure((size_t)n));
+    std::vector<double> h((size_t)n), out((size_t)n);
+    for (int i = 0; i < n; ++i) h[(size_t)i] = (me + 1) * (1.0 + 1e-3 * i);
+    FEDD_HIP(hipMemcpyAsync(a.p, h.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    FEDD_TRY(allreduce_sum(c, a.p, n));
+    FEDD_HIP(hipMemcpyAsync(out.data(), a.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) err = std::max(err, std::abs(out[(size_t)i] - 0.5 * N * (N + 1) * (1.0 + 1e-3 * i)));
+    if (c->comm) {
+        // (2) grouped send / receive with every other rank, n doubles each: rank p gets (me, p, i) encoded
+        ncclComm_t comm = (ncclComm_t)c->comm;
+        FEDD_TRY(sb.ensure((size_t)n * N));
+        FEDD_TRY(rb.ensure((size_t)n * N));
+        std::vector<double> hs((size_t)n * N), hr((size_t)n * N, -1.0);
+        for (int p = 0; p < N; ++p)
+            for (int i = 0; i < n; ++i) hs[(size_t)p * n + i] = 1000.0 * me + p + 1e-6 * i;
+        FEDD_HIP(hipMemcpyAsync(sb.p, hs.data(), hs.size() * 8, hipMemcpyHostToDevice, c->stream));
+        FEDD_HIP(hipMemsetAsync(rb.p, 0, (size_t)n * N * 8, c->stream));
+        ncclResult_t bad = ncclGroupStart();
+        for (int p = 0; p < N && bad == ncclSuccess; ++p) {
+            if (p == me) continue;
+            bad = ncclSend(sb.p + (size_t)p * n, (size_t)n, ncclDouble, p, comm, c->stream);
+            if (bad == ncclSuccess) bad = ncclRecv(rb.p + (size_t)p * n, (size_t)n, ncclDouble, p, comm, c->stream);
+        }
+        ncclResult_t r = ncclGroupEnd();
+        FEDD_CHECK(bad == ncclSuccess && r == ncclSuccess, "fedd_comm_selftest: grouped send/recv: %s", ncclGetErrorString(bad != ncclSuccess ? bad : r));
+        FEDD_HIP(hipMemcpyAsync(hr.data(), rb.p, hr.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        for (int p = 0; p < N; ++p)
+            if (p != me)
+                for (int i = 0; i < n; ++i) err = std::max(err, std::abs(hr[(size_t)p * n + i] - (1000.0 * p + me + 1e-6 * i)));
+        // (3) ring shift
+        const int to = (me + 1) % N, from = (me + N - 1) % N;
+        bad = ncclGroupStart();
+        if (bad == ncclSuccess) bad = ncclSend(sb.p, (size_t)n, ncclDouble, to, comm, c->stream);
+        if (bad == ncclSuccess) bad = ncclRecv(rb.p, (size_t)n, ncclDouble, from, comm, c->stream);
+        r = ncclGroupEnd();
+        FEDD_CHECK(bad == ncclSuccess && r == ncclSuccess, "fedd_comm_selftest: ring shift: %s", ncclGetErrorString(bad != ncclSuccess ? bad : r));
+        FEDD_HIP(hipMemcpyAsync(hr.data(), rb.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        FEDD_HIP(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < n; ++i) err = std::max(err, std::abs(hr[(size_t)i] - (1000.0 * from + 0 + 1e-6 * i)));
+    }
+    *max_abs_err = err;
+    return 0;
+}
+
 // owner rank of a structured-grid node under the lowest-rank rule (mesh_structured.cpp)
 extern "C" int fedd_mesh_structured_owner(int dim, const int* decomp, const int* cells, int64_t n, const int64_t* gid,
                                           int32_t* owner_rank) {

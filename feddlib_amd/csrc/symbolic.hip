@@ -8,6 +8,7 @@
 // No dynamic insert here: counting sort by node, per-row sorted-unique merge in LDS, closed-form
 // expansion to dofs.
 #include "fedd_internal.hpp"
+#include <chrono>
 
 namespace fedd {
 namespace {
@@ -257,7 +258,17 @@ __global__ void k_expand_pattern(const int32_t* __restrict__ nptr, const int32_t
 
 }  // namespace
 
-int build_adjacency(fedd_ctx* c) {
+static int build_adjacency_impl(fedd_ctx* c);
+int build_adjacency(fedd_ctx* c) {      // once per mesh; its wall time is kept for fedd_mesh_setup_info
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    FEDD_TRY(build_adjacency_impl(c));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    c->adj_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+static int build_adjacency_impl(fedd_ctx* c) {
     const int64_t n_ent = c->n_elem * c->nen;
     const int32_t n_own = (int32_t)(c->n_own + c->n_rowg);   // every node that gets rows
     FEDD_TRY(c->d_n2e_ptr.ensure((size_t)n_own + 1));

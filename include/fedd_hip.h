@@ -319,9 +319,17 @@ int fedd_gmres(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rto
  * the device.  The relative residual refers to ||r_0|| = ||b - A x_0||, as Belos' default scaling does. */
 int fedd_gmres_x0(fedd_ctx* ctx, const double* b_owned, double* x_owned, double rtol, int max_it,
                   int restart, int use_prec, int* its_out, double* relres_out);
+/* The structures that depend on the mesh alone are built once per mesh, at the first call that needs them, and reused by every
+ * later assembly: the node -> element adjacency (fedd_pattern_build) and the element-major tile structures of the assembly
+ * kernel (fedd_assemble, P1 forms).  Their wall time (ms, device synchronised before and after) is not part of a steady-state
+ * step; a driver that assembles once (the reference's do: laplace/main.cpp:199-208) pays it once.  tiles_state: 0 = not built
+ * (yet), 1 = built, -1 = the mesh does not fit the tile limits (pair kernels are used).  Outputs may be NULL.  Both are built
+ * by device kernels (option "asm_tiles_host" 1: the tile structures by the round-3 host builder, for A/B). */
+int fedd_mesh_setup_info(fedd_ctx* ctx, double* adjacency_ms, double* tiles_ms, int* tiles_state, int64_t* n_tiles);
 /* how the last solve ended: floor_reached = 1 when the s-step solver stopped because b - A x had reached its rounding floor
- * (the recurrence residual kept falling, the true residual did not follow; relres_out of that solve is the TRUE residual and may
- * exceed rtol by up to 100x), recurrence_relres = the recurrence residual at that point (-1 otherwise); outputs may be NULL */
+ * (the recurrence residual kept falling, the true residual did not follow, and a restart from the true residual did not help
+ * either; relres_out of that solve is the TRUE residual and may exceed rtol by up to 100x), 2 when three restart cycles in a
+ * row made no progress; recurrence_relres = the recurrence residual at that point (-1 otherwise); outputs may be NULL */
 int fedd_gmres_status(fedd_ctx* ctx, int* floor_reached, double* recurrence_relres);
 /* The second level alone, z = Phi K0^-1 Phi^T r: FROSch's "Only apply coarse", which the reference uses for
  * "Level Combination" = "Multiplicative" (LinearSolver_def.hpp:98-104: one coarse pre-apply of the right-hand side into the
@@ -440,6 +448,11 @@ int fedd_comm_set_host_callbacks(fedd_ctx* ctx, fedd_exchange_fn exchange, fedd_
  * all-reduce, all-gather -- the call shapes of the halo import and the Gram-Schmidt reductions (what can run of the
  * RCCL path on a one-GPU box).  max_abs_err = deviation from the expected values (0 when RCCL works). */
 int fedd_rccl_selftest(fedd_ctx* ctx, int n, double* max_abs_err);
+/* The collectives of the N > 1 path on the context's OWN communicator, in the shapes the solver uses them: the in-place
+ * all-reduce of the Gram-Schmidt reductions, a grouped send / receive with every other rank (the halo import of a block that
+ * touches all others) and a ring shift, n doubles each; max_abs_err = largest deviation from the expected values (0 on one
+ * rank).  A pre-flight for multi-GPU runs (bench.py calls it under a watchdog before the first step): every rank must call it. */
+int fedd_comm_selftest(fedd_ctx* ctx, int n, double* max_abs_err);
 
 int fedd_mesh_structured_owner(int dim, const int* decomp, const int* cells, int64_t n,
                                const int64_t* gid, int32_t* owner_rank);

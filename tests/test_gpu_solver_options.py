@@ -50,9 +50,10 @@ def test_initial_guess_is_used(fedd_lib, ctx, kind, s):
         assert np.linalg.norm(rhs_bc - A_bc @ x) <= 1.01e-8 * r0
         assert rel <= 1e-8
         np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
-        # (b) the exact solution as the guess: nothing to do
+        # (b) the exact solution as the guess: r_0 is rounding noise and the tolerance is relative to it -- whatever the
+        #     solver does with that noise, the solution stays where it was
         x, its, rel = ctx.gmres_x0(xd, rtol=1e-8, max_it=300, restart=100, use_prec=True)
-        assert its <= 1 and np.abs(x - xd).max() <= 1e-12 * np.abs(xd).max()
+        assert np.abs(x - xd).max() <= 1e-12 * np.abs(xd).max()
         # (c) x_0 = None: the vector on the device (the last solution)
         ctx.gmres(None, rtol=1e-4, max_it=300, restart=100, use_prec=True, want_x=False)
         x1 = ctx.solution_get()
@@ -140,11 +141,12 @@ def test_reported_residual_is_the_true_one(fedd_lib, ctx):
         tr = float(np.linalg.norm(b - A @ x) / np.linalg.norm(b))
         st = ctx.gmres_status()
         assert abs(rel - tr) <= 0.05 * tr + 2e-16, (rtol, rel, tr, st)
-        if st["floor_reached"]:
+        if st["floor_reached"] == 1:
             floors += 1
             assert st["recurrence_relres"] <= rtol and rel <= 100.0 * rtol
-        elif its < 1500:
+        elif st["floor_reached"] == 0 and its < 1500:
             assert rel <= rtol and st["recurrence_relres"] == -1.0
+        # (floor_reached 2: three restart cycles without progress -- the residual returned is still the true one)
     # (nothing to assert on `floors`: whether 1e-15 ends at the floor or at the iteration limit depends on the system)
 
 

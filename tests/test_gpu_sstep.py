@@ -115,7 +115,13 @@ def test_dependent_block_is_cut_not_trusted(fedd_lib, ctx):
         x, its, rel = ctx.gmres(None, rtol=1e-10, max_it=300, restart=100, use_prec=True)
     finally:
         ctx.set_option("gmres_chol_tol", 1e-13)
-    assert rel <= 1e-10 and ctx.gmres_info()["cut_blocks"] >= 1
+    # one-column blocks lean on the Pythagorean norm alone (no second vector to re-orthogonalise against): the recurrence
+    # drifts from the true residual near 1e-8.  The solver notices (its claims are checked against b - A x), restarts once
+    # from the true residual and then stops; what it returns is the TRUE residual, with the status saying why it stopped
+    st = ctx.gmres_status()
+    assert ctx.gmres_info()["cut_blocks"] >= 1
+    assert rel == pytest.approx(_true_relres(A_bc, rhs_bc, x), rel=1e-3)
+    assert rel <= 1e-10 or (st["floor_reached"] == 1 and st["recurrence_relres"] <= 1e-10 and rel <= 1e-8), (rel, st)
     xd = fo.direct_solve(A_bc, rhs_bc)
     np.testing.assert_allclose(x, xd, rtol=0, atol=1e-7 * np.abs(xd).max())
 

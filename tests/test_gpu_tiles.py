@@ -95,3 +95,28 @@ def test_a_new_mesh_gets_new_tiles(fedd_lib, ctx):
         A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
         assert np.abs(A @ np.ones(n)).max() <= 1e-13 * np.abs(val).max()       # Laplace rows sum to zero
         assert abs(A - A.T).max() <= 1e-15 * np.abs(val).max()
+
+
+def test_device_built_tiles_equal_host_built_tiles(fedd_lib, ctx):
+    """round 4: the tile structures are built by device kernels (k_tb_*), the round-3 host builder stays as option
+    "asm_tiles_host" 1: both give the same matrices bit for bit (the entries of a slot are added in adjacency order either way),
+    on the structured grids, on the graded cylinder mesh (whose cells are split), scalar and block forms, whatever the pattern
+    the first assembly happened to see (the tiles are built once per mesh, under the first pattern)"""
+    for name, m in _meshes(fedd_lib):
+        dim = m["dim"]
+        forms = ((fedd_lib.FORM_LAPLACE, 1, fedd_lib.BLOCK_SCALAR, None),
+                 (fedd_lib.FORM_LAPLACE_VEC, dim, fedd_lib.BLOCK_DIAG, None),
+                 (fedd_lib.FORM_LINELAS, dim, fedd_lib.BLOCK_FULL, [1.5, 1.0]))
+        for first in range(3):       # which pattern the tile build runs under
+            vals = {}
+            for host in (1, 0):
+                ctx.set_option("asm_tiles_host", host)
+                ctx.mesh_set_dict(m)
+                order = forms[first:] + forms[:first]
+                for form, dofs, mode, params in order:
+                    vals[(host, form)] = _values(ctx, fedd_lib, form, dofs, mode, params, 1)
+                info = ctx.mesh_setup_info()
+                assert info["tiles_state"] == 1 and info["n_tiles"] > 0 and info["tiles_ms"] > 0 and info["adjacency_ms"] > 0, (name, info)
+            for form, _, _, _ in forms:
+                assert np.array_equal(vals[(1, form)], vals[(0, form)]), (name, first, form)
+    ctx.set_option("asm_tiles_host", 0)
