@@ -62,6 +62,8 @@ def parse():
                          "host-staged transport (RCCL refuses several ranks on one device); numbers are not a measurement")
     ap.add_argument("--coarse", type=float, default=0.0, help="two-level variant: lattice cells (0 = library default)")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cells per direction of the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--no-multi-ab", action="store_true",
+                    help="N > 1: skip the A/B of the multi-GPU switches that follows the result line (stderr only)")
     ap.add_argument("--cpu-full", action="store_true",
                     help="time the CPU restatement on the full grid of the GPU run instead of the bounded sample (minutes)")
     return ap.parse_args()
@@ -314,6 +316,35 @@ def extra_cfg5_share(capi, dev, a):
     return out
 
 
+def extra_p2_cube(capi, dev, M=64):
+    """P2 assembly at an HBM-relevant size (the only P2 figure was the 27 618-tet cylinder, latency-bound): the
+    P2 mesh of an M^3-cell structured cube (fedd_mesh_p2_build: edge mid-points), pattern and FE::assemblyLaplace with the
+    5-point rule and 10 x 10 element matrices (FE_def.hpp:604-667 with :6262-6293, :5661-5713), plus the P2 mass matrix; device
+    ms per launch, algorithmic bytes 4 nen E + 8 dim N + 12 nnz + 4 (N + 1), fraction of the HBM peak."""
+    m1 = capi.structured_mesh(3, (1, 1, 1), [M] * 3, 0)
+    t0 = time.perf_counter()
+    mv = capi.p2_of_p1(m1, volume_id=0)
+    t_p2 = time.perf_counter() - t0
+    c = capi.Context(device=dev)
+    env_options(c)
+    c.mesh_set_dict(mv)
+    out = {"workload": "P2 tetrahedra on a %d^3-cell structured cube: %d nodes, %d elements" % (M, mv["n_global"], mv["conn"].shape[0]),
+           "p2_mesh_build_host_s": t_p2}
+    for name, form in (("laplace", capi.FORM_LAPLACE), ("mass", capi.FORM_MASS)):
+        def step():
+            c.pattern_build(1, capi.BLOCK_SCALAR)
+            c.assemble(form)
+        wall, _, tm = timed_passes(c, step, 3, 2)
+        nr, _, nnz = c.csr_sizes()
+        byt = 4.0 * mv["conn"].size + 8.0 * 3 * mv["xyz"].shape[0] + 12.0 * nnz + 4.0 * (nr + 1)
+        ms = tm["assemble"][0] / max(tm["assemble"][1], 1)
+        out[name] = {"assemble_ms": ms, "symbolic_ms": tm["symbolic"][0] / max(tm["symbolic"][1], 1), "nnz": int(nnz),
+                     "algorithmic_bytes": byt, "GBs": byt / ms / 1e6, "frac_hbm_peak": byt / ms / 1e6 / HBM_PEAK_GBS,
+                     "kernel": "k_assemble_pairs / k_assemble_slots (row-gather pair kernels; no P2 tile kernel)"}
+    c.close()
+    return out
+
+
 def extra_cfg4(capi, dev):
     """BASELINE cfg 4: P2 / P1 Stokes on DFG3DCylinder_6k.mesh (141 742 dofs), block assembly, merge, the driver's boundary
     conditions (no-slip on flags 1 and 4, parabolic inflow on flag 2; stokes/main.cpp:80-88, 267-296), monolithic one-level
@@ -388,6 +419,13 @@ def main():
                 idt.copy_(torch.frombuffer(bytearray(capi.nccl_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)
             nccl_id = bytes(idt.cpu().numpy().tobytes())
+
+    def nccl_id_ab():
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(capi.nccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        return bytes(idt.cpu().numpy().tobytes())
 
     def max_over_ranks(v):
         if N == 1:
@@ -680,6 +718,7 @@ def main():
         e4 = extra_cfg4(capi, dev)
         if e4 is not None:
             extras["cfg4_one_gpu"] = e4
+        extras["p2_cube"] = extra_p2_cube(capi, dev)
 
     if rank == 0:
         dominant = max(kern, key=lambda k: kern[k]["total_ms"])
@@ -781,6 +820,54 @@ def main():
                 out["cpu_baseline"]["with_16_threads"] = {"value": c16["value"], "seconds": c16["seconds"], "cores": c16["cores"]}
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
+    if N > 1 and not rehearse and not a.no_multi_ab:
+        # ---- after the one JSON line, to STDERR, under a watchdog: A/B of the multi-GPU switches that cannot be measured on the
+        # one-GPU development boxes (ghost import of r behind the interior subdomains, operator applications issued ahead of a
+        # block's host round trip, the one-vector solver).  Whatever happens here, the result above has been printed.
+        import threading
+
+        def _ab_timeout():
+            sys.stderr.write("[bench ab] rank %d: watchdog after 150 s, leaving\n" % rank)
+            sys.stderr.flush()
+            os._exit(0)
+
+        wd = threading.Timer(150.0, _ab_timeout)
+        wd.daemon = True
+        wd.start()
+        try:
+            m = capi.structured_mesh(3, dec, cells, rank, size=dom, ghosts=ghost_layers)
+            ab = {}
+            for name, opts in (("default", {}), ("halo_overlap=1", {"halo_overlap": 1}), ("gmres_spec=2", {"gmres_spec": 2}),
+                               ("halo_overlap=1,gmres_spec=2", {"halo_overlap": 1, "gmres_spec": 2}), ("gmres_kind=0", {"gmres_kind": 0})):
+                c = capi.Context(device=dev, rank=rank, nranks=N, nccl_id=nccl_id_ab())
+                for k, v in opts.items():
+                    c.set_option(k, v)
+                c.mesh_set_dict(m)
+                c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, cells, m["gid_rep"]))
+                c.halo_exchange_setup()
+                for _ in range(2):
+                    one_step(c, capi, a, False)
+                c.sync()
+                c.timing_enable(TIMING_STRIDE)
+                c.timing_reset()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    its_ab, rel_ab = one_step(c, capi, a, False)
+                c.sync()
+                barrier()
+                dt_ab = max_over_ranks(time.perf_counter() - t0) / 3 * 1e3
+                tm_ab = c.timing_get()
+                ab[name] = {"ms_per_step": round(dt_ab, 3), "its": its_ab, "relres": rel_ab,
+                            "device_ms": {k: round(v[0] / 3, 3) for k, v in tm_ab.items() if v[1]}}
+                c.close()
+            if rank == 0:
+                sys.stderr.write("[bench ab] " + json.dumps({"n_gpus": N, "ab": ab}) + "\n")
+                sys.stderr.flush()
+        except BaseException as e:      # (never let the A/B change the exit status of a finished measurement)
+            sys.stderr.write("[bench ab] rank %d: %r\n" % (rank, e))
+            sys.stderr.flush()
+        wd.cancel()
     if N > 1:
         dist.destroy_process_group()
 

@@ -1219,10 +1219,23 @@ __global__ __launch_bounds__(256) void k_ss_pass2(double* __restrict__ Sx, Off o
             // y = (Hbar_k C)(r, :): the same q for every lane, so that the coefficients C(q, :) are wave-uniform (scalar loads)
             // and only Hbar(r, q) is a per-lane load (coalesced over r); entries below the sub-diagonal are zero by structure
             // (with a per-lane loop start every lane fetched its own 15 coefficients per step: 89 us per block at k ~ 60)
-            for (int q = 0; q < k; ++q) {
-                const double h = (r <= k && q + 1 >= r) ? Hraw[(int64_t)q * ldh + r] : 0.0;
+            // (eight entries of the Hessenberg row requested before any is used: one global round trip per eight columns instead
+            // of one per column -- the kernel is a single workgroup, nothing else hides that latency)
+            for (int q0 = 0; q0 < k; q0 += 8) {
+                double h[8];
 #pragma unroll
-                for (int cidx = 0; cidx < S - 1; ++cidx) x[cidx] -= h * Sx[o3.Cc + q * S + cidx];
+                for (int u = 0; u < 8; ++u) {
+                    const int q = q0 + u;
+                    h[u] = (q < k && r <= k && q + 1 >= r) ? Hraw[(int64_t)q * ldh + r] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = q0 + u;
+                    if (q < k) {
+#pragma unroll
+                        for (int cidx = 0; cidx < S - 1; ++cidx) x[cidx] -= h[u] * Sx[o3.Cc + q * S + cidx];
+                    }
+                }
             }
 #pragma unroll
             for (int cidx = 0; cidx < S - 1; ++cidx) {

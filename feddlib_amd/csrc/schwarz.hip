@@ -1345,6 +1345,173 @@ __global__ __launch_bounds__(256, 2) void k_apply_ms(const int4* __restrict__ or
     }
 }
 
+
+// Warp-specialised form of the same batched product (round 4, the default where it applies: 33 ... 64 owned rows, up to 256
+// columns).  A workgroup of EIGHT waves: waves 0-3 multiply -- wave w owns row tile w of the shared inverse, its A fragments
+// for all column steps in registers -- and waves 4-7 load: they gather the 16 subdomains' restrictions of r for the batch
+// after next and park them in LDS as B[column][subdomain] (double-buffered) together with the output row ids.  The matrix-core
+// waves never wait for global memory, only for LDS; one barrier per batch; no partial tiles to add (the K-split kernel
+// k_apply_mfma spends two thirds of its time outside the matrix cores: 127 us at 214^3 cells against 49 us of MFMA issue).
+// Dof ids: first dof + the representative's offsets for conforming subdomains (the loader lanes keep the offsets of their
+// columns in registers), the stored lists otherwise.
+constexpr int WS_SPAN = 1024;     // most places of a workgroup of the warp-specialised apply kernel
+template <int NK>    // column steps of 4: columns <= 4 NK; owned rows <= 64 (four row tiles)
+__global__ __launch_bounds__(512, 1) void k_apply_ws(const int4* __restrict__ order, const int32_t* __restrict__ sub_dofs,
+                                                     const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
+                                                     const double* __restrict__ r, double* __restrict__ z, int32_t nsub, int span) {
+    constexpr int NC = 4 * NK, NG = NC / 16;    // columns, gathers per loader lane and batch
+    __shared__ double Bs[2][NC][16];
+    __shared__ int32_t ods[2][64][16];
+    __shared__ int4 rec[WS_SPAN];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const bool loader = wv >= 4;
+    const int nwg = gridDim.x, q_ = nwg >> 3, rem_ = nwg & 7, xcd_ = blockIdx.x & 7, within_ = blockIdx.x >> 3;
+    const int wg = (xcd_ < rem_ ? xcd_ * (q_ + 1) : rem_ * (q_ + 1) + (xcd_ - rem_) * q_) + within_;
+    const int32_t p0 = wg * span, cnt = min(span, nsub - p0);
+    if (cnt <= 0) return;
+    for (int i = tid; i < cnt; i += 512) rec[i] = order[p0 + i];
+    __syncthreads();
+    // a batch = up to 16 consecutive places with the same representative and sizes (one LDS read and a ballot per wave)
+    auto batch_len = [&](int pos_) -> int {
+        if (pos_ >= cnt) return 0;
+        const int4 h0 = rec[pos_];
+        const int4 hl = rec[min(pos_ + min(lane, AM_MB - 1), cnt - 1)];
+        const uint64_t diff = __ballot(lane < AM_MB && (pos_ + lane >= cnt || hl.y != h0.y || hl.z != h0.z));
+        return diff ? (int)__builtin_ctzll(diff) : AM_MB;
+    };
+    if (loader) {
+        // batches are gathered THREE iterations before they are multiplied (two register sets in flight, parked one iteration
+        // ahead): a batch of gathers takes longer to come back than a batch of matrix-core products takes
+        const int lt = tid - 256, gj = lt & 15, gc = lt >> 4;   // subdomain gj of the batch, columns gc + 16 u
+        int32_t so[NG];
+        int32_t so_rep = -1;
+        auto gather = [&](int pos_, int mb_, double (&g)[NG], int32_t (&id4)[4]) {
+            const int4 h = rec[pos_ + min(gj, mb_ - 1)];
+            const int n_ = h.z & 1023, nrow_ = (h.z >> 10) & 1023;
+            const bool conf = (h.z >> 20) & 1;
+            const int32_t* __restrict__ row = sub_dofs + (int64_t)h.x * NMAX;
+            if (__builtin_amdgcn_readfirstlane(h.y) != so_rep) {        // (uniform: a batch has one representative)
+                const int32_t* __restrict__ ref = sub_dofs + (int64_t)h.y * NMAX;
+                const int32_t r0 = ref[0];
+#pragma unroll
+                for (int u = 0; u < NG; ++u) so[u] = gc + 16 * u < n_ ? ref[gc + 16 * u] - r0 : 0;
+                so_rep = __builtin_amdgcn_readfirstlane(h.y);
+            }
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const int c = gc + 16 * u;
+                const bool on = gj < mb_ && c < n_;
+                const int32_t id = on ? (conf ? h.w + so[u] : row[c]) : 0;
+                g[u] = on ? r[id] : 0.0;
+                if (u < 4) id4[u] = (on && c < nrow_) ? id : -1;
+            }
+        };
+        auto park = [&](int buf_, const double (&g)[NG], const int32_t (&id4)[4]) {
+#pragma unroll
+            for (int u = 0; u < NG; ++u) Bs[buf_][gc + 16 * u][gj] = g[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ods[buf_][gc + 16 * u][gj] = id4[u];
+        };
+        double gA[NG], gB[NG];
+        int32_t iA[4], iB[4];
+        // batches 0, 1, 2: 0 parked now, 1 in set B, 2 in set A
+        int pos = 0, mb = batch_len(0);
+        gather(pos, mb, gA, iA);
+        park(0, gA, iA);
+        pos += mb;
+        int mb1 = batch_len(pos);                   // batch i + 1 (in set B)
+        if (mb1 > 0) gather(pos, mb1, gB, iB);
+        pos += mb1;
+        int mb2 = mb1 > 0 ? batch_len(pos) : 0;     // batch i + 2 (in set A)
+        if (mb2 > 0) gather(pos, mb2, gA, iA);
+        pos += mb2;
+        __syncthreads();
+        int buf = 0;
+        for (;;) {
+            // iteration i (even): park batch i + 1 from set B, request batch i + 3 into set B
+            if (mb1 == 0) break;
+            park(buf ^ 1, gB, iB);
+            int mb3 = mb2 > 0 ? batch_len(pos) : 0;
+            if (mb3 > 0) gather(pos, mb3, gB, iB);
+            pos += mb3;
+            __syncthreads();
+            buf ^= 1;
+            // iteration i + 1 (odd): park batch i + 2 from set A, request batch i + 4 into set A
+            if (mb2 == 0) break;
+            park(buf ^ 1, gA, iA);
+            int mb4 = mb3 > 0 ? batch_len(pos) : 0;
+            if (mb4 > 0) gather(pos, mb4, gA, iA);
+            pos += mb4;
+            __syncthreads();
+            buf ^= 1;
+            mb1 = mb3;
+            mb2 = mb4;
+        }
+    } else {
+        const int w = wv, lj = lane & 15, lk = lane >> 4;
+        double a[NK];
+        int32_t cur = -1;
+        int pos_a = 0, mb_a = batch_len(0);
+        int pos_b = mb_a, mb_b = batch_len(pos_b);
+        __syncthreads();
+        int buf = 0;
+        for (;;) {
+            const int4 h = rec[pos_a];
+            const int n = h.z & 1023, nrow = (h.z >> 10) & 1023;
+            if (h.y != cur) {       // (uniform) this wave's row tile of the new inverse
+                const double* __restrict__ src = inv + inv_ptr[h.x];
+                const int i = 16 * w + lj;
+#pragma unroll
+                for (int s = 0; s < NK; ++s) {
+                    const int c = 4 * s + lk;
+                    const bool on = c < n && i < nrow;
+                    const double v = src[on ? c * nrow + i : 0];
+                    a[s] = on ? v : 0.0;
+                }
+                cur = h.y;
+            }
+            if (16 * w < nrow) {    // (uniform over the wave)
+                int32_t od[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) od[q] = ods[buf][16 * w + lk + 4 * q][lj];
+                ap_d4 acc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = ap_d4{0.0, 0.0, 0.0, 0.0};
+                // eight column steps at a time, the next eight B fragments requested before the current products (the scheduling
+                // barriers keep the compiler from hoisting all NK reads to the front, which spilled 300 registers)
+                double b[8], bn[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) b[u] = Bs[buf][4 * u + lk][lj];
+#pragma unroll
+                for (int s0 = 0; s0 < NK; s0 += 8) {
+                    if (s0 + 8 < NK) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) bn[u] = Bs[buf][4 * (s0 + 8 + u) + lk][lj];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        acc[u & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s0 + u], b[u], acc[u & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) b[u] = bn[u];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (od[q] >= 0) z[od[q]] = (acc[0][q] + acc[1][q]) + (acc[2][q] + acc[3][q]);
+            }
+            if (mb_b == 0) break;
+            const int pos_c = pos_b + mb_b, mb_c = batch_len(pos_c);
+            __syncthreads();
+            buf ^= 1;
+            pos_a = pos_b;
+            mb_a = mb_b;
+            pos_b = pos_c;
+            mb_b = mb_c;
+        }
+    }
+}
+
 __global__ void k_count_mult(const int32_t* __restrict__ sub_n, const int32_t* __restrict__ sub_dofs, double* mult) {
     const int b = blockIdx.x;
     const int n = sub_n[b];
@@ -1809,7 +1976,25 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
                 // (row tiles, column steps per wave) by the largest subdomain: fewer steps = fewer registers = more waves
                 const int64_t mx = c->sw_max_size;
                 // 33 ... 64 owned rows: the row tiles split over the waves, B through LDS (k_apply_ms); "apply_kind" 6 = K-split
-                if (c->apply_kind != 6 && c->sw_max_own > 32 && c->sw_max_own <= 64 && mx <= 256 && span <= 128) {
+                if (c->apply_kind == 7 && c->sw_max_own > 32 && c->sw_max_own <= 64 && mx <= 256) {
+                    // one workgroup of eight waves per CU: whole rounds of 256 workgroups, at most 128 places each
+                    int span_ws = c->apply_span;
+                    if (span_ws <= 0) {
+                        const int64_t rounds = (count + 256 * WS_SPAN - 1) / (256 * WS_SPAN);
+                        span_ws = (int)((count + 256 * rounds - 1) / (256 * rounds));
+                    }
+                    span_ws = std::min(WS_SPAN, std::max(16, (span_ws + 15) / 16 * 16));
+                    const int nwg_ws = (int)((count + span_ws - 1) / span_ws);
+#define APPLY_WS(NK)                                                                                                          \
+    hipLaunchKernelGGL((k_apply_ws<NK>), dim3((unsigned)nwg_ws), dim3(512), 0, c->stream, records + p0, (const int32_t*)c->d_sub_dofs.p, \
+                       (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned, (int32_t)count, span_ws)
+                    if (mx <= 160) APPLY_WS(40);
+                    else if (mx <= 192) APPLY_WS(48);
+                    else APPLY_WS(64);
+#undef APPLY_WS
+                    return;
+                }
+                if (c->apply_kind == 5 && c->sw_max_own > 32 && c->sw_max_own <= 64 && mx <= 256 && span <= 128) {
 #define APPLY_MS(NK)                                                                                                          \
     hipLaunchKernelGGL((k_apply_ms<NK>), dim3((unsigned)nwg), blk, 0, c->stream, records + p0, (const int32_t*)c->d_sub_dofs.p, \
                        (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned, (int32_t)count, span)

@@ -840,3 +840,77 @@ def test_headline_configs_in_their_own_decomposition_at_size(fedd_lib, problem, 
         assert abs(max(o["xmax"] for o in out) - 0.05621) < 1e-4           # centre value of -lap u = 1 on the unit cube
     else:
         assert sum(o["nnz"] for o in out) == 903725973                     # ... and of cfg 5
+
+
+def _thread_rank_cut(capi, group, rank, dec, M, out, errs):
+    try:
+        world = group.world
+        m = capi.structured_mesh(3, dec, [M] * 3, rank, ghosts=4)
+        c = capi.Context(device=0, rank=rank, nranks=world, nccl_id=None)
+        c.mesh_set_dict(m)
+        c.halo_set_owners(m["gid_rep"], capi.structured_owner(3, dec, [M] * 3, m["gid_rep"]))
+        c.comm_set_thread_group(group)
+        selftest = c.comm_selftest(257)          # the all-reduce leg over the host-staged transport (no RCCL communicator here)
+        c.pattern_build(1, capi.BLOCK_SCALAR)
+        c.assemble(capi.FORM_LAPLACE)
+        c.assemble_rhs([1.0])
+        c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+        c.schwarz_set_target(27, 1.0)
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
+        res = {}
+        for name, opts, rtol in (("cut", {"gmres_s": 8, "gmres_chol_tol": 0.5}, 1e-10),
+                                 ("claims", {"gmres_s": 16, "gmres_tol_blocks": 0}, 1e-13),
+                                 ("spec", {"gmres_s": 8, "gmres_spec": 2}, 1e-10)):
+            for k, v in opts.items():
+                c.set_option(k, v)
+            x, its, rel = c.gmres(None, rtol=rtol, max_it=600, restart=50, use_prec=True)
+            res[name] = dict(x=x, its=its, rel=rel, info=c.gmres_info(), status=c.gmres_status())
+            c.set_option("gmres_chol_tol", 1e-13)
+            c.set_option("gmres_tol_blocks", 1)
+            c.set_option("gmres_spec", 0)
+            c.set_option("gmres_s", 0)
+        out[rank] = dict(gu=m["gid_uni"], res=res, selftest=selftest)
+        c.close()
+    except Exception as e:      # pragma: no cover
+        import traceback
+        errs.append("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+        try:
+            group._barrier.abort()
+        except Exception:
+            pass
+
+
+def test_cut_blocks_and_failed_claims_keep_the_ranks_in_step(fedd_lib):
+    """the s-step solver's host decisions (block cuts, convergence claims that the true residual does not confirm,
+    restarts, operator applications issued ahead of a block's outcome) are taken by every rank from all-reduced numbers.  Four
+    ranks, three solves that force those paths -- an absurd Cholesky threshold (every block cut), 16-vector blocks at 1e-13
+    (claims fail, restarts follow), speculative applications -- must finish (matched collectives), agree on every count, and
+    end at the one-rank solution."""
+    import threading
+    dec, M = (1, 2, 2), 6
+    group = fedd_lib.ThreadGroup(4)
+    out, errs = [None] * 4, []
+    th = [threading.Thread(target=_thread_rank_cut, args=(fedd_lib, group, r, dec, M, out, errs)) for r in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errs, "\n".join(errs)
+    assert all(o is not None for o in out)
+    ref = fedd_lib.structured_mesh(3, (1, 1, 1), [M, 2 * M, 2 * M], 0)
+    om = fo.Mesh(dim=3, fe="P1", conn=ref["conn"], xyz=ref["xyz"], gid_rep=ref["gid_rep"], flag_rep=ref["flag_rep"],
+                 gid_uni=ref["gid_uni"], flag_uni=ref["flag_uni"], xyz_uni=None, n_global=ref["n_global"])
+    A_bc, rhs_bc, _, _, _ = fo.laplace_problem(om)
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    assert max(o["selftest"] for o in out) <= 1e-9
+    for name, tol in (("cut", 1e-7), ("claims", 1e-10), ("spec", 1e-7)):
+        assert len({o["res"][name]["its"] for o in out}) == 1, name
+        assert len({o["res"][name]["rel"] for o in out}) == 1, name
+        assert len({(o["res"][name]["info"]["blocks"], o["res"][name]["info"]["cut_blocks"]) for o in out}) == 1, name
+        x = np.zeros_like(xd)
+        for o in out:
+            x[o["gu"]] = o["res"][name]["x"]
+        tr = np.linalg.norm(rhs_bc - A_bc @ x) / np.linalg.norm(rhs_bc)
+        assert abs(out[0]["res"][name]["rel"] - tr) <= 0.05 * tr + 1e-16, (name, out[0]["res"][name]["rel"], tr)
+        np.testing.assert_allclose(x, xd, rtol=0, atol=tol * np.abs(xd).max())
+    assert out[0]["res"]["cut"]["info"]["cut_blocks"] >= 1
