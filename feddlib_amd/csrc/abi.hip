@@ -782,7 +782,6 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
         c->cs_valid = false;
     }
     else if (k == "spmv_exact_public") c->spmv_exact_public = (int)value;
-    else if (k == "apply_dbg") c->apply_dbg = (int)value;
     else if (k == "asm_tiles_host") { c->asm_tiles_host = (int)value; c->tl_state = 0; }
     else if (k == "whole_boxes") c->whole_boxes = (int)value;
     else if (k == "gdsw_tol") {

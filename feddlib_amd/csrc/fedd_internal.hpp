@@ -258,7 +258,6 @@ struct fedd_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int64_t sw_nconf = 0;                       // subdomains whose dof list is their representative's list shifted (ids computed in the apply)
     int64_t sw_nint = -1;                       // subdomains without ghost dofs at the front of d_sw_order (-1: not split)
-    int apply_dbg = 0;                          // ablation switches of the warp-specialised apply kernel (development)
     int apply_span = 0;                         // grouped apply: subdomains per workgroup (0 = 64)
     int sw_dedupe = 1;                          // option "schwarz_dedupe": subdomains with the same local matrix share one slab
     int sw_fp_kind = 0;                         // option "schwarz_fp_kind": fingerprints from row hashes (0) or entry by entry (1)

@@ -1208,150 +1208,19 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
 }
 
 
-// The same batched product with the ROW TILES split over the waves (round 4; "apply_kind" 0 picks it where it applies, 6 = the
-// K-split kernel above).  Wave w owns row tile w of the shared inverse -- its A fragments for ALL column steps stay in registers
-// (48 doubles per lane at 192 columns) -- and the B operand, the 16 subdomains' restrictions of r, is staged once per batch in
-// LDS as B[column][subdomain] by all 256 lanes (gathers for the NEXT batch are issued before the matrix-core products of the
-// current one and parked behind them).  Every wave then reads its B fragments from LDS (64 consecutive doubles per read) and
-// writes its 16 rows x 16 subdomains straight from the accumulators: no partial tiles to exchange and add, one barrier per
-// batch instead of two, four independent accumulator chains.  Batches of subdomains that conform to the representative whose
-// offsets are in LDS compute their dof ids (first dof + offset); the others read their lists.
-template <int NK>    // column steps of 4: columns <= 4 NK; owned rows <= 64 (four row tiles)
-__global__ __launch_bounds__(256, 2) void k_apply_ms(const int4* __restrict__ order, const int32_t* __restrict__ sub_dofs,
-                                                     const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
-                                                     const double* __restrict__ r, double* __restrict__ z, int32_t nsub, int span) {
-    constexpr int NC = 4 * NK, NG = NC / 16;    // columns, gathers per lane and batch
-    __shared__ double Bs[2][NC][16];
-    __shared__ int32_t soff[NC];
-    __shared__ int4 rec[128];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lj = lane & 15, lk = lane >> 4;
-    const int gj = tid & 15, gc = tid >> 4;     // gathers: subdomain gj of the batch, columns gc + 16 u
-    const int nwg = gridDim.x, q_ = nwg >> 3, rem_ = nwg & 7, xcd_ = blockIdx.x & 7, within_ = blockIdx.x >> 3;
-    const int wg = (xcd_ < rem_ ? xcd_ * (q_ + 1) : rem_ * (q_ + 1) + (xcd_ - rem_) * q_) + within_;
-    const int32_t p0 = wg * span, cnt = min(span, nsub - p0);
-    if (cnt <= 0) return;
-    for (int i = tid; i < cnt; i += 256) rec[i] = order[p0 + i];
-    __syncthreads();
-    auto batch_len = [&](int pos_) {
-        const int4 h = rec[pos_];
-        int mb_ = 1;
-        while (mb_ < AM_MB && pos_ + mb_ < cnt && rec[pos_ + mb_].y == h.y && rec[pos_ + mb_].z == h.z) ++mb_;
-        return mb_;
-    };
-    double a[NK];
-    int32_t cur = -1;
-    // gathers of one batch: entries of r at the dof ids of subdomain gj, columns gc + 16 u
-    auto gather = [&](int pos_, int mb_, double (&g)[NG]) {
-        const int4 h = rec[pos_ + min(gj, mb_ - 1)];
-        const int n_ = h.z & 1023;
-        const bool conf = ((h.z >> 20) & 1) && h.y == cur;      // (cur: the representative whose offsets soff holds)
-        const int32_t* __restrict__ row = sub_dofs + (int64_t)h.x * NMAX;
-#pragma unroll
-        for (int u = 0; u < NG; ++u) {
-            const int c = gc + 16 * u;
-            const bool on = gj < mb_ && c < n_;
-            const int32_t id = on ? (conf ? h.w + soff[c] : row[c]) : 0;
-            g[u] = on ? r[id] : 0.0;
-        }
-    };
-    auto park = [&](int buf_, const double (&g)[NG]) {
-#pragma unroll
-        for (int u = 0; u < NG; ++u) Bs[buf_][gc + 16 * u][gj] = g[u];
-    };
-    // the representative's inverse (this wave's row tile) and dof offsets; uniform over the workgroup
-    auto load_rep = [&](int pos_) {
-        const int4 h = rec[pos_];
-        const int n_ = h.z & 1023, nrow_ = (h.z >> 10) & 1023;
-        const double* __restrict__ src = inv + inv_ptr[h.x];
-        const int32_t* __restrict__ ref = sub_dofs + (int64_t)h.y * NMAX;
-        const int32_t r0 = ref[0];
-        __syncthreads();        // (nobody reads the old offsets any more)
-        if (tid < NC) soff[tid] = tid < n_ ? ref[tid] - r0 : 0;
-        const int i = 16 * w + lj;
-#pragma unroll
-        for (int s = 0; s < NK; ++s) {
-            const int c = 4 * s + lk;
-            a[s] = (c < n_ && i < nrow_) ? src[c * nrow_ + i] : 0.0;
-        }
-        cur = h.y;
-        __syncthreads();
-    };
-    int pos = 0, mb = batch_len(0), buf = 0;
-    load_rep(0);
-    {
-        double g[NG];
-        gather(0, mb, g);
-        park(0, g);
-    }
-    __syncthreads();
-    for (;;) {
-        const int4 h = rec[pos];
-        const int n = h.z & 1023, nrow = (h.z >> 10) & 1023;
-        const int pos_n = pos + mb;
-        const bool last = pos_n >= cnt;
-        int mb_n = 0;
-        bool new_rep = false;
-        double g[NG];
-        if (!last) {
-            mb_n = batch_len(pos_n);
-            new_rep = rec[pos_n].y != cur;
-            // (a batch of another representative is gathered after its offsets have been loaded, below)
-            if (!new_rep) gather(pos_n, mb_n, g);
-        }
-        // output rows of this lane: row 16 w + lk + 4 q of subdomain lj
-        int32_t od[4];
-        {
-            const int4 hj = rec[pos + min(lj, mb - 1)];
-            const bool conf = ((hj.z >> 20) & 1) && hj.y == cur;
-            const int32_t* __restrict__ row = sub_dofs + (int64_t)hj.x * NMAX;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = 16 * w + lk + 4 * q;
-                od[q] = (lj < mb && i < nrow) ? (conf ? hj.w + soff[i] : row[i]) : -1;
-            }
-        }
-        ap_d4 acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = ap_d4{0.0, 0.0, 0.0, 0.0};
-        if (16 * w < nrow) {        // (uniform over the wave)
-            // eight column steps at a time: their B fragments as independent LDS reads, then the products (the compiler
-            // barrier keeps it from hoisting all NK reads to the front, which spilled 300 registers)
-#pragma unroll
-            for (int s0 = 0; s0 < NK; s0 += 8) {
-                if (4 * s0 < n) {
-                    double b[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) b[u] = Bs[buf][4 * (s0 + u) + lk][lj];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        acc[u & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s0 + u], b[u], acc[u & 3], 0, 0, 0);
-                }
-                asm volatile("" ::: "memory");
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (od[q] >= 0) z[od[q]] = (acc[0][q] + acc[1][q]) + (acc[2][q] + acc[3][q]);
-        if (last) break;
-        if (new_rep) {
-            load_rep(pos_n);
-            gather(pos_n, mb_n, g);
-        }
-        park(buf ^ 1, g);
-        __syncthreads();
-        buf ^= 1;
-        pos = pos_n;
-        mb = mb_n;
-    }
-}
-
-
-// Warp-specialised form of the same batched product (round 4, the default where it applies: 33 ... 64 owned rows, up to 256
-// columns).  A workgroup of EIGHT waves: waves 0-3 multiply -- wave w owns row tile w of the shared inverse, its A fragments
-// for all column steps in registers -- and waves 4-7 load: they gather the 16 subdomains' restrictions of r for the batch
-// after next and park them in LDS as B[column][subdomain] (double-buffered) together with the output row ids.  The matrix-core
-// waves never wait for global memory, only for LDS; one barrier per batch; no partial tiles to add (the K-split kernel
-// k_apply_mfma spends two thirds of its time outside the matrix cores: 127 us at 214^3 cells against 49 us of MFMA issue).
+// Warp-specialised form of the same batched product (round 4; option "apply_kind" 7 -- NOT the default: measured slower).
+// A workgroup of EIGHT waves, one per CU, persistent over up to 1024 places: waves 0-3 multiply -- wave w owns row tile w of the
+// shared inverse, its A fragments for all column steps in registers -- and waves 4-7 load: they gather the 16 subdomains'
+// restrictions of r three batches ahead (two register sets in flight) and park them in LDS as B[column][subdomain]
+// (double-buffered) together with the output row ids.  One barrier per batch, no partial tiles to add, the matrix-core loop is
+// back-to-back MFMAs behind software-pipelined LDS reads.  Measured at 214^3 cells / 166 375 subdomains: 224 us against the
+// 131 us of the K-split kernel above on the same box (33.9 against 46 us at 19 683 subdomains).  The counters say why
+// (tools/pmc_apply.sh, profiles/r04_pmc_apply.txt): both kernels do the same 3.7 M MFMA-busy cycles per SE and fetch 2.8-4.2 M
+// lines from L2 per apply -- r is re-fetched four to six times through the 16 KB L1s, 355-532 MB for the 80 MB vector -- and
+// the L1s spend 38 % (K-split) / 53 % (this kernel) of the time with their miss queues full (TCP_PENDING_STALL_CYCLES): the
+// apply is bound by outstanding L1 misses x L2/MALL latency per CU, and two independent workgroups per CU keep more of them
+// in flight than one workgroup with four loader waves.  Kept as an option for A/B; what would help either kernel is fetching
+// fewer lines (a workgroup owning a 3D block of boxes and staging the union of their overlap bricks once), not more overlap.
 // Dof ids: first dof + the representative's offsets for conforming subdomains (the loader lanes keep the offsets of their
 // columns in registers), the stored lists otherwise.
 constexpr int WS_SPAN = 1024;     // most places of a workgroup of the warp-specialised apply kernel
@@ -1977,7 +1846,7 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
                 const int64_t mx = c->sw_max_size;
                 // 33 ... 64 owned rows: the row tiles split over the waves, B through LDS (k_apply_ms); "apply_kind" 6 = K-split
                 if (c->apply_kind == 7 && c->sw_max_own > 32 && c->sw_max_own <= 64 && mx <= 256) {
-                    // one workgroup of eight waves per CU: whole rounds of 256 workgroups, at most 128 places each
+                    // one workgroup of eight waves per CU: whole rounds of 256 workgroups, at most WS_SPAN places each
                     int span_ws = c->apply_span;
                     if (span_ws <= 0) {
                         const int64_t rounds = (count + 256 * WS_SPAN - 1) / (256 * WS_SPAN);
@@ -1992,16 +1861,6 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
                     else if (mx <= 192) APPLY_WS(48);
                     else APPLY_WS(64);
 #undef APPLY_WS
-                    return;
-                }
-                if (c->apply_kind == 5 && c->sw_max_own > 32 && c->sw_max_own <= 64 && mx <= 256 && span <= 128) {
-#define APPLY_MS(NK)                                                                                                          \
-    hipLaunchKernelGGL((k_apply_ms<NK>), dim3((unsigned)nwg), blk, 0, c->stream, records + p0, (const int32_t*)c->d_sub_dofs.p, \
-                       (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned, (int32_t)count, span)
-                    if (mx <= 160) APPLY_MS(40);
-                    else if (mx <= 192) APPLY_MS(48);
-                    else APPLY_MS(64);
-#undef APPLY_MS
                     return;
                 }
                 if (c->sw_max_own <= 32) {

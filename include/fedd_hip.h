@@ -349,7 +349,8 @@ int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_bloc
  * loads are in flight together in the slot-addressed kernel (P1; default 1); "asm_dbg" ablation switches (development); "apply_kind" 0 = restricted Schwarz
  * apply by the setup's outcome (batched matrix-core kernel when at most a quarter of at least 4096 subdomains have distinct
  * local matrices, else the flat streaming kernel), 1 = strided, 2 = flat without the compact LDS layout, 4 = matrix-core
- * kernel whenever the inverses are shared (any number of subdomains); "apply_span" places per workgroup of that kernel
+ * kernel whenever the inverses are shared (any number of subdomains), 7 = the warp-specialised form of that kernel (four waves
+ * multiply, four gather r three batches ahead; 33 ... 64 owned rows per subdomain; measured slower, kept for A/B); "apply_span" places per workgroup of that kernel
  * (multiples of 16; 0 = 32 / 64 / 96 / 128 by the number of subdomains); "md2_gy" column groups in flight per row block of the
  * Gram-Schmidt dot sweep (0 = by vector length), "md2_nch" its 512-row chunks per workgroup (2 or 4; default 4);
  * "gmres_hostwrite" 1 (default) = the solver's small kernel writes the three numbers of the host's lagged convergence test
