@@ -176,6 +176,7 @@ static int mesh_set_impl(fedd_ctx* c, int dim, int nen, int64_t n_elem, const in
     c->n_rowg = 0;
     c->have_adj = c->have_pattern = c->have_schwarz = c->have_coarse = false;
     c->tl_state = 0;     // the assembly's tile structures belong to the old mesh
+    c->p2_state = 0;     // ... and so do the gather lists of the P2 row sums
     c->halo.reset();
 
     // column-local numbering: owned nodes in unique-map order, then ghosts sorted by global id
@@ -724,8 +725,9 @@ extern "C" int fedd_gmres_x0(fedd_ctx* c, const double* b_owned, double* x_owned
 extern "C" int fedd_mesh_setup_info(fedd_ctx* c, double* adjacency_ms, double* tiles_ms, int* tiles_state, int64_t* n_tiles) {
     FEDD_CHECK(c, "fedd_mesh_setup_info: null context");
     if (adjacency_ms) *adjacency_ms = c->have_adj ? c->adj_build_ms : 0.0;
-    if (tiles_ms) *tiles_ms = c->tl_state != 0 ? c->tl_build_ms : 0.0;
-    if (tiles_state) *tiles_state = c->tl_state;
+    // (P2 meshes: the gather lists of the row sums take the place of the tile structures)
+    if (tiles_ms) *tiles_ms = (c->tl_state != 0 || c->p2_state != 0) ? c->tl_build_ms : 0.0;
+    if (tiles_state) *tiles_state = c->tl_state != 0 ? c->tl_state : c->p2_state;
     if (n_tiles) *n_tiles = c->tl_state == 1 ? c->tl_ntile : 0;
     return 0;
 }
@@ -783,6 +785,11 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     }
     else if (k == "spmv_exact_public") c->spmv_exact_public = (int)value;
     else if (k == "asm_tiles_host") { c->asm_tiles_host = (int)value; c->tl_state = 0; }
+    else if (k == "asm_p2_elem") c->asm_p2_elem = (int)value;
+    else if (k == "asm_zero_eps") {
+        FEDD_CHECK(value >= 0.0, "fedd_set_option: asm_zero_eps %g", value);
+        c->asm_zero_eps = value;
+    }
     else if (k == "whole_boxes") c->whole_boxes = (int)value;
     else if (k == "gdsw_tol") {
         FEDD_CHECK(value > 0.0 && value < 1.0, "fedd_set_option: gdsw_tol %g", value);

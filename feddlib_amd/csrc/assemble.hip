@@ -44,7 +44,11 @@ struct AsmArgs {
     int32_t n_rows;
     int dofs;
     double p0, p1;  // LINELAS: lambda, mu
+    const double* ke;   // != nullptr: element matrices [E][NEN][NEN] computed beforehand by k_elem_matrix (P2 scalar forms)
+    double zero_eps; // > 0: element contributions of magnitude below it are set to zero before they are added (the reference's
+                     // optional setZeros_ / myeps_, FE_def.hpp:74-79, 719-721, 2002-2004, 2032-2034: vector Laplacian, B, B^T)
 };
+__device__ __forceinline__ double zero_small(const AsmArgs& a, double v) { return (a.zero_eps > 0.0 && fabs(v) < a.zero_eps) ? 0.0 : v; }
 
 __device__ __forceinline__ int find_slot(const int32_t* __restrict__ cols, int n, int32_t col) {
     int lo = 0, hi = n - 1;
@@ -298,7 +302,7 @@ __device__ __forceinline__ void compute_pair(const AsmArgs& a, const double* __r
 #pragma unroll
             for (int j = 0; j < NEN; ++j) {
                 cols[j] = nd[j] * dofs + comp;
-                vals[j] = v[j] * absdet;
+                vals[j] = zero_small(a, v[j] * absdet);
             }
         } else if constexpr (FORM == F_DIV) {
             // row = pressure node (vertex li): B_{i,(j,d)} = |detB| sum_q w_q psi_qi dphi_qjd  (FE_def.hpp:1992-2004)
@@ -328,7 +332,7 @@ __device__ __forceinline__ void compute_pair(const AsmArgs& a, const double* __r
 #pragma unroll
                 for (int d = 0; d < DIM; ++d) {
                     cols[j * DIM + d] = nd[j] * DIM + d;
-                    vals[j * DIM + d] = absdet * vd[j][d];
+                    vals[j * DIM + d] = zero_small(a, absdet * vd[j][d]);
                 }
         } else if constexpr (FORM == F_DIVT) {
             // row = velocity dof (node li, component comp): B^T_{(i,d),j} = |detB| sum_q w_q psi_qj dphi_qid  (:2022-2046)
@@ -347,7 +351,7 @@ __device__ __forceinline__ void compute_pair(const AsmArgs& a, const double* __r
 #pragma unroll
             for (int j = 0; j <= DIM; ++j) {
                 cols[j] = nd[j];
-                vals[j] = absdet * vj[j];
+                vals[j] = zero_small(a, absdet * vj[j]);
             }
         } else {
             const double lam = a.p0, mu = a.p1;
@@ -402,6 +406,17 @@ __device__ __forceinline__ void eval_pair(const AsmArgs& a, const double* __rest
     int32_t nd[NEN];
 #pragma unroll
     for (int j = 0; j < NEN; ++j) nd[j] = a.conn[(int64_t)e * NEN + j];
+    if constexpr ((FORM == F_LAPLACE || FORM == F_MASS) && NEN > DIM + 1) {
+        if (a.ke) {     // row li of the element matrix k_elem_matrix left behind: NEN contiguous values
+            const double* __restrict__ kr = a.ke + ((int64_t)e * NEN + li) * NEN;
+#pragma unroll
+            for (int j = 0; j < NEN; ++j) {
+                cols[j] = nd[j] * dofs + comp;
+                vals[j] = kr[j];
+            }
+            return;
+        }
+    }
     double X[DIM + 1][DIM];
 #pragma unroll
     for (int v = 0; v <= DIM; ++v)
@@ -766,6 +781,93 @@ __global__ void k_dirichlet_nodes(const int32_t* __restrict__ nodes, const int32
     isdir[row] = 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// P2 elements, scalar forms (FE::assemblyLaplace / assemblyMass with the 10 x 10 -- 2D: 6 x 6 -- element matrices of
+// FE_def.hpp:637-665, 485-499): element-major evaluation, ONE ELEMENT PER WAVEFRONT.  The quadrature weights and the reference
+// basis values / gradients are staged in LDS once per workgroup; a wave loads its element's vertices, forms B^-1 and |det B|,
+// parks the transformed gradients of all basis functions at all quadrature points in LDS (nq x NEN x DIM values), and its
+// lanes then take the NEN^2 entries of the element matrix, which leave as one contiguous 800-byte stream.  The rows of the
+// global matrix are then summed from these element matrices by the pair kernels (k_assemble_pairs reads row li of element e
+// instead of re-deriving it: the pair kernels alone evaluate every P2 element ten times, 11.4 ms at a 64^3-cell cube against
+// the figure in DESIGN.md section 4 with this kernel) -- in adjacency order, no atomics: bitwise reproducible as before.
+// ---------------------------------------------------------------------------------------------
+template <int DIM, int NEN, int FORM>
+__global__ __launch_bounds__(256) void k_elem_matrix(AsmArgs a, int64_t n_elem, double* __restrict__ ke) {
+    extern __shared__ double sm[];
+    const int nq = a.nq, ntab = nq * (1 + NEN + NEN * DIM + DIM + 1);
+    double* s_w = sm;
+    double* s_phi = s_w + nq;
+    double* s_dphi = s_phi + nq * NEN;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    double* Gs = sm + ntab + (ntab & 1) + (size_t)w * nq * NEN * DIM;       // this wave's transformed gradients [q][i][d]
+    for (int i = tid; i < ntab; i += 256) sm[i] = a.tab[i];
+    __syncthreads();
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    const int64_t trips = (n_elem + nwave - 1) / nwave;
+    for (int64_t k = 0; k < trips; ++k) {
+        const int64_t e = k * nwave + (int64_t)blockIdx.x * 4 + w;
+        const bool on = e < n_elem;
+        // vertices = the first DIM + 1 nodes of the element; lane l < (DIM + 1) DIM holds coordinate (l / DIM, l % DIM)
+        double xv = 0.0;
+        if (on && lane < (DIM + 1) * DIM) xv = a.xyz[(int64_t)a.conn[e * NEN + lane / DIM] * DIM + (lane % DIM)];
+        double X[DIM + 1][DIM];
+#pragma unroll
+        for (int v = 0; v <= DIM; ++v)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) X[v][d] = __shfl(xv, v * DIM + d, 64);
+        double absdet = 0.0;
+        if constexpr (FORM == F_LAPLACE) {
+            double Binv[DIM][DIM];
+            absdet = on ? fabs(affine<DIM>(X, Binv)) : 0.0;
+            if (on)
+                for (int t = lane; t < nq * NEN; t += 64) {
+                    double g[DIM];
+                    grad_t<DIM, NEN>(s_dphi, t / NEN, t % NEN, Binv, g);
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) Gs[t * DIM + d] = g[d];
+                }
+        } else {
+            absdet = on ? fabs(affine_det<DIM>(X)) : 0.0;
+        }
+        __syncthreads();
+        if (on) {
+            double* __restrict__ out = ke + e * (NEN * NEN);
+            for (int t = lane; t < NEN * NEN; t += 64) {
+                const int i = t / NEN, j = t - i * NEN;
+                double v = 0.0;
+                if constexpr (FORM == F_LAPLACE) {
+                    for (int q = 0; q < nq; ++q) {
+                        const double* gi = Gs + (q * NEN + i) * DIM;
+                        const double* gj = Gs + (q * NEN + j) * DIM;
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) v += s_w[q] * gi[d] * gj[d];
+                    }
+                    out[t] = zero_small(a, v * absdet);
+                } else {
+                    for (int q = 0; q < nq; ++q) v += s_w[q] * s_phi[q * NEN + i] * s_phi[q * NEN + j];
+                    out[t] = v * absdet - a.p0 * absdet * a.p1;
+                }
+            }
+        }
+        __syncthreads();        // Gs is rewritten by the next trip
+    }
+}
+
+// element matrices of the whole mesh into c->d_ke (P2, F_LAPLACE / F_MASS); returns the args with ke set
+template <int DIM, int NEN, int FORM>
+int launch_elem_matrices(fedd_ctx* c, AsmArgs& a, int ntab) {
+    FEDD_TRY(c->d_ke.ensure((size_t)c->n_elem * NEN * NEN));
+    const size_t lds = ((size_t)ntab + (ntab & 1) + 4 * (size_t)a.nq * NEN * DIM) * sizeof(double);
+    FEDD_CHECK(lds <= 64 * 1024, "element matrices: quadrature tables of %d points do not fit the LDS", a.nq);
+    const int64_t nwg = std::min<int64_t>((c->n_elem + 3) / 4, 256 * 8);
+    ScopedTimer t(c, FEDD_T_ASSEMBLE);
+    hipLaunchKernelGGL((k_elem_matrix<DIM, NEN, FORM>), dim3((unsigned)nwg), dim3(256), lds, c->stream, a, c->n_elem, c->d_ke.p);
+    t.stop();
+    FEDD_HIP(hipGetLastError());
+    a.ke = c->d_ke.p;
+    return 0;
+}
+
 template <int DIM, int NEN, int FORM>
 int launch_pairs(fedd_ctx* c, const AsmArgs& a, int ntab, int64_t n_rows, int rowcap) {
     constexpr int CPP = PairCfg<DIM, NEN, FORM>::CPP;
@@ -959,7 +1061,7 @@ __global__ __launch_bounds__(BS) void k_assemble_tiles(AsmArgs a, const TileHdr*
                         double v = 0.0;
 #pragma unroll
                         for (int d = 0; d < DIM; ++d) v += wg[d] * G[j][d];
-                        pk[pix(e, i * NEN + j)] = v * absdet;
+                        pk[pix(e, i * NEN + j)] = zero_small(a, v * absdet);
                     }
                 }
             } else {
@@ -1520,12 +1622,19 @@ __global__ __launch_bounds__(TB_BS) void k_tb_build(const int2* __restrict__ pie
         __syncthreads();
         fail = EL > TL_ELMAX;
     }
-    if (!fail) {    // the distinct vertices of those elements that are not nodes of the tile, ascending, behind the tile's nodes
+    if (!fail && s_nbp[R] > TB_SORT) fail = true;
+    if (!fail) {    // the distinct vertices of those elements that are not nodes of the tile, ascending, behind the tile's nodes:
+        // the union of the tile nodes' pattern rows (the neighbours of a node ARE the vertices of its elements; 405 entries to
+        // sort for a 27-node tile of the Kuhn cube instead of the 1296 vertices of its 324 elements)
+        const int nnb = s_nbp[R];
         int N = 2;
-        while (N < EL * NEN) N <<= 1;
+        while (N < nnb) N <<= 1;
         for (int i = tid; i < N; i += TB_BS) s_sort[i] = INT32_MAX;
         __syncthreads();
-        for (int t = tid; t < EL * NEN; t += TB_BS) s_sort[t] = conn[(size_t)s_els[t / NEN] * NEN + (t % NEN)];
+        for (int t = tid; t < nnb; t += TB_BS) {
+            const int p = tb_upper(s_nbp, R, t), sl = t - s_nbp[p];
+            s_sort[t] = colind[rowptr[s_nodes[p] * dofs] + (full ? sl * dofs : sl)] / dofs;
+        }
         __syncthreads();
         tb_bitonic(s_sort, N, tid);
         const int C = (N + TB_BS - 1) / TB_BS, i0 = tid * C, i1 = min(N, i0 + C);
@@ -1800,6 +1909,113 @@ int launch_matrix(fedd_ctx* c, const AsmArgs& a, int ntab, int64_t n_rows, int r
     return launch_pairs<DIM, NEN, FORM>(c, a, ntab, n_rows, rowcap);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row sums of the P2 scalar forms from the element matrices of k_elem_matrix, by GATHER LISTS built once per mesh
+// (k_p2_lists): for every node-level nonzero (node p, slot s) the (adjacency entry q, local column j) pairs that contribute
+// to it, in adjacency order -- 16 bits each, q << 4 | j, behind a 16-bit start per nonzero; a node's list starts at
+// NEN x its adjacency start, no scan needed.  k_p2_gather: a wave per node, a lane per slot, every lane adds its few (2.6 on
+// average) element-matrix entries in list order and writes its CSR slot(s): no search, no atomics, bitwise reproducible, and
+// the summation order of the pair kernels.  (The pair kernels spend their time searching the row for every one of the 157 M
+// contributions of a 64^3-cell P2 cube: 11.4 ms with or without the element matrices.)
+// ---------------------------------------------------------------------------------------------
+template <int NEN>
+__global__ __launch_bounds__(256) void k_p2_lists(const int32_t* __restrict__ conn, const int32_t* __restrict__ n2e_ptr,
+                                                  const int32_t* __restrict__ n2e, const int32_t* __restrict__ rowptr,
+                                                  const int32_t* __restrict__ colind, int dofs, int full, int32_t nn,
+                                                  uint16_t* __restrict__ soff, uint16_t* __restrict__ src, int32_t* __restrict__ bad) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + w; p < nn; p += (int64_t)gridDim.x * 4) {
+        const int32_t ab = n2e_ptr[p], deg = n2e_ptr[p + 1] - ab;
+        const int32_t row = (int32_t)p * dofs, rs = rowptr[row], len = rowptr[row + 1] - rs;
+        const int nslot = full ? len / dofs : len, step = full ? dofs : 1;
+        const int32_t nbn = dofs == 1 ? rs : (full ? rs / (dofs * dofs) : rs / dofs);
+        const int64_t base = (int64_t)ab * NEN;
+        if (deg > 4095 || deg * NEN > 65535) {
+            if (lane == 0) atomicMax(bad, 1);
+            continue;
+        }
+        int running = 0;
+        for (int s0 = 0; s0 < nslot; s0 += 64) {
+            const int sl = s0 + lane;
+            const bool on = sl < nslot;
+            const int32_t v = on ? colind[rs + sl * step] / dofs : -1;
+            int cnt = 0;
+            for (int q = 0; q < deg; ++q) {
+                const int32_t* __restrict__ en = conn + (int64_t)(n2e[ab + q] / NEN) * NEN;
+#pragma unroll
+                for (int j = 0; j < NEN; ++j) cnt += en[j] == v ? 1 : 0;
+            }
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            int k = running + incl - cnt;
+            if (on) soff[nbn + sl] = (uint16_t)k;
+            if (on)
+                for (int q = 0; q < deg; ++q) {
+                    const int32_t* __restrict__ en = conn + (int64_t)(n2e[ab + q] / NEN) * NEN;
+#pragma unroll
+                    for (int j = 0; j < NEN; ++j)
+                        if (en[j] == v) src[base + k++] = (uint16_t)((q << 4) | j);
+                }
+            running += __shfl(incl, 63, 64);
+        }
+    }
+}
+
+template <int NEN>
+__global__ __launch_bounds__(256) void k_p2_gather(const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e,
+                                                   const int32_t* __restrict__ rowptr, int dofs, int32_t nn,
+                                                   const uint16_t* __restrict__ soff, const uint16_t* __restrict__ src,
+                                                   const double* __restrict__ ke, double* __restrict__ val) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + w; p < nn; p += (int64_t)gridDim.x * 4) {
+        const int32_t ab = n2e_ptr[p], deg = n2e_ptr[p + 1] - ab;
+        const int32_t row = (int32_t)p * dofs, rs = rowptr[row], nslot = rowptr[row + 1] - rs;     // (scalar or diagonal blocks)
+        const int32_t nbn = dofs == 1 ? rs : rs / dofs;
+        const uint16_t* __restrict__ sp = src + (int64_t)ab * NEN;
+        const int total = deg * NEN;
+        for (int sl = lane; sl < nslot; sl += 64) {
+            const int b = soff[nbn + sl], e2 = sl + 1 < nslot ? (int)soff[nbn + sl + 1] : total;
+            double acc = 0.0;
+            for (int k = b; k < e2; ++k) {
+                const uint32_t sr = sp[k];
+                acc += ke[(int64_t)n2e[ab + (sr >> 4)] * NEN + (sr & 15u)];
+            }
+            for (int comp = 0; comp < dofs; ++comp) val[rowptr[row + comp] + sl] = acc;
+        }
+    }
+}
+
+// the gather lists of the current mesh (built at the first P2 assembly that uses them); c->p2_state = -1: not applicable
+template <int NEN>
+int p2_lists_build(fedd_ctx* c) {
+    c->p2_state = -1;
+    const int64_t nn = c->n_own + c->n_rowg;
+    if (!c->have_pattern || !c->have_adj || c->block_mode == FEDD_BLOCK_FULL || nn <= 0) return 0;
+    int32_t n2e_total = 0;
+    FEDD_HIP(hipMemcpyAsync(&n2e_total, c->d_n2e_ptr.p + nn, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    const int64_t node_nnz = c->nnz_ext / c->dofs;      // scalar: nnz; diagonal blocks: dofs rows of the node-level length each
+    FEDD_TRY(c->d_p2_soff.ensure((size_t)node_nnz + 2));
+    FEDD_TRY(c->d_p2_src.ensure((size_t)n2e_total * NEN + 2));
+    FEDD_TRY(c->d_flags.ensure(16));
+    int32_t* bad = c->d_flags.p + 6;
+    FEDD_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), c->stream));
+    const int nwg = (int)std::min<int64_t>((nn + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(k_p2_lists<NEN>, dim3((unsigned)nwg), dim3(256), 0, c->stream, (const int32_t*)c->d_conn.p,
+                       (const int32_t*)c->d_n2e_ptr.p, (const int32_t*)c->d_n2e.p, (const int32_t*)c->d_rowptr.p,
+                       (const int32_t*)c->d_colind.p, c->dofs, 0, (int32_t)nn, c->d_p2_soff.p, c->d_p2_src.p, bad);
+    int32_t h_bad = 0;
+    FEDD_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    FEDD_HIP(hipGetLastError());
+    if (!h_bad) c->p2_state = 1;
+    return 0;
+}
+
 template <int DIM, int NEN>
 int launch_assemble(fedd_ctx* c, int kform, const AsmArgs& a, int ntab) {
     if constexpr (NEN == DIM + 1) {
@@ -1807,6 +2023,39 @@ int launch_assemble(fedd_ctx* c, int kform, const AsmArgs& a, int ntab) {
         if ((c->asm_kind == 4 || (c->asm_kind == 0 && c->asm_tiles)) && a.nq == 1 && (kform == F_LAPLACE || kform == F_LINELAS)) {
             const int rc = kform == F_LAPLACE ? launch_tiles<DIM, F_LAPLACE>(c, a, ntab) : launch_tiles<DIM, F_LINELAS>(c, a, ntab);
             if (rc >= 0) return rc;
+        }
+    }
+    if constexpr (NEN > DIM + 1) {
+        // P2: the element matrices once per element (k_elem_matrix), the rows summed from them (option "asm_p2_elem" 0: the pair
+        // kernels re-derive the row of every (row, element) pair)
+        if (c->asm_p2_elem && c->asm_kind != 1 && (kform == F_LAPLACE || kform == F_MASS)) {
+            AsmArgs ae = a;
+            if (kform == F_LAPLACE) FEDD_TRY((launch_elem_matrices<DIM, NEN, F_LAPLACE>(c, ae, ntab)));
+            else FEDD_TRY((launch_elem_matrices<DIM, NEN, F_MASS>(c, ae, ntab)));
+            // rows from the gather lists (scalar rows or diagonal blocks; "asm_p2_elem" 2: through the pair kernels)
+            if (c->asm_p2_elem == 1 && c->block_mode != FEDD_BLOCK_FULL) {
+                if (c->p2_state == 0) {
+                    FEDD_HIP(hipStreamSynchronize(c->stream));
+                    const auto t0 = std::chrono::steady_clock::now();
+                    FEDD_TRY(p2_lists_build<NEN>(c));
+                    FEDD_HIP(hipStreamSynchronize(c->stream));
+                    c->tl_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                }
+                if (c->p2_state == 1) {
+                    const int64_t nn = c->n_own + c->n_rowg;
+                    const int nwg = (int)std::min<int64_t>((nn + 3) / 4, 256 * 32);
+                    ScopedTimer t(c, FEDD_T_ASSEMBLE);
+                    hipLaunchKernelGGL(k_p2_gather<NEN>, dim3((unsigned)nwg), dim3(256), 0, c->stream, (const int32_t*)c->d_n2e_ptr.p,
+                                       (const int32_t*)c->d_n2e.p, (const int32_t*)c->d_rowptr.p, c->dofs, (int32_t)nn,
+                                       (const uint16_t*)c->d_p2_soff.p, (const uint16_t*)c->d_p2_src.p, (const double*)c->d_ke.p,
+                                       c->d_val.p);
+                    t.stop();
+                    FEDD_HIP(hipGetLastError());
+                    return 0;
+                }
+            }
+            if (kform == F_LAPLACE) return launch_matrix<DIM, NEN, F_LAPLACE>(c, ae, ntab, c->n_rows_ext, c->max_row_nnz);
+            return launch_matrix<DIM, NEN, F_MASS>(c, ae, ntab, c->n_rows_ext, c->max_row_nnz);
         }
     }
     if (c->asm_kind != 1) {
@@ -1955,6 +2204,8 @@ int assemble_div(fedd_ctx* c, int64_t n_p, int slot_b, int slot_bt) {
     AsmArgs a;
     a.conn = c->d_conn.p; a.n2e_ptr = c->d_n2e_ptr.p; a.n2e = c->d_n2e.p; a.xyz = c->d_xyz.p; a.tab = c->d_dtmp0.p;
     a.nq = nq; a.p0 = a.p1 = 0.0;
+    a.ke = nullptr;
+    a.zero_eps = c->asm_zero_eps;       // doSetZeros: B and B^T threshold their element contributions (FE_def.hpp:2002-2004, 2032-2034)
     AsmArgs ab = a, at = a;
     ab.rowptr = B.rowptr.p; ab.colind = B.colind.p; ab.val = B.val.p; ab.n_rows = (int32_t)n_p; ab.dofs = 1;
     at.rowptr = BT.rowptr.p; at.colind = BT.colind.p; at.val = BT.val.p; at.n_rows = (int32_t)BT.n_rows; at.dofs = dim;
@@ -2015,6 +2266,9 @@ int assemble_matrix(fedd_ctx* c, int form, const double* params) {
     a.nq = nq; a.n_rows = (int32_t)c->n_rows_ext; a.dofs = c->dofs;
     a.p0 = params ? params[0] : 0.0;
     a.p1 = params ? params[1] : 0.0;
+    a.ke = nullptr;
+    // doSetZeros: of the matrix forms built here only the vector Laplacian thresholds (FE_def.hpp:719-721; assemblyLaplace does not)
+    a.zero_eps = form == FEDD_FORM_LAPLACE_VEC ? c->asm_zero_eps : 0.0;
     if (kform == F_MASS) {   // the constant the Bochev-Dohrmann block takes off every mass entry: |ref. element| x scale (FE_def.hpp:2183-2192)
         a.p0 = form == FEDD_FORM_BDSTAB ? (dim == 2 ? 0.5 : 1.0 / 6.0) : 0.0;
         a.p1 = form == FEDD_FORM_BDSTAB ? (dim == 2 ? 1.0 / 9.0 : 1.0 / 16.0) : 0.0;

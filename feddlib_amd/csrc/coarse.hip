@@ -584,6 +584,49 @@ __global__ void k_gd_rhs_cols(const double* __restrict__ imask, const double* __
     if (t < n_rows * MULTI_NR) B[t] = imask[t / MULTI_NR] != 0.0 ? -W[t] : 0.0;
 }
 
+// Sixteen stacked right-hand sides are solved as ONE system, so the solver's tolerance applies to the Frobenius norm of the
+// stacked residual: a column with a small right-hand side could stop at a much larger relative residual of its own (ADVICE
+// r03).  The columns are therefore scaled to unit norm before the solve and back after it: every column then ends within
+// sqrt(16) x the tolerance relative to ITS right-hand side, whatever shares its batch.
+// k_cols_sumsq: per-column sums of squares of X[row * 16 + j], partial per workgroup; k_cols_scale_setup: norms -> scale
+// factors (1 / norm, 0 for a zero column) and the norms themselves; k_cols_scale: X[row * 16 + j] *= f[j].
+constexpr int CS_ROWS = 4096;       // rows per workgroup of k_cols_sumsq
+__global__ __launch_bounds__(256) void k_cols_sumsq(const double* __restrict__ X, int64_t n_rows, double* __restrict__ part) {
+    __shared__ double sh[16][MULTI_NR + 1];
+    const int j = threadIdx.x & 15, a = threadIdx.x >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS, r1 = r0 + CS_ROWS < n_rows ? r0 + CS_ROWS : n_rows;
+    double s = 0.0;
+    for (int64_t r = r0 + a; r < r1; r += 16) {
+        const double v = X[r * MULTI_NR + j];
+        s += v * v;
+    }
+    sh[a][j] = s;
+    __syncthreads();
+    if (threadIdx.x < MULTI_NR) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += sh[q][threadIdx.x];
+        part[(int64_t)blockIdx.x * MULTI_NR + threadIdx.x] = t;
+    }
+}
+__global__ void k_cols_sum_parts(const double* __restrict__ part, int nblk, double* __restrict__ out) {   // 16 threads, fixed order
+    const int j = threadIdx.x;
+    if (j >= MULTI_NR) return;
+    double t = 0.0;
+    for (int b = 0; b < nblk; ++b) t += part[(int64_t)b * MULTI_NR + j];
+    out[j] = t;
+}
+__global__ void k_cols_scale_setup(double* __restrict__ f) {     // in: sums of squares [16]; out: f[0..15] = 1 / norm, f[16..31] = norm
+    const int j = threadIdx.x;
+    if (j >= MULTI_NR) return;
+    const double nrm = sqrt(f[j]);
+    f[j] = nrm > 0.0 ? 1.0 / nrm : 0.0;
+    f[MULTI_NR + j] = nrm;
+}
+__global__ void k_cols_scale(double* __restrict__ X, int64_t n, const double* __restrict__ f) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) X[t] *= f[t & (MULTI_NR - 1)];
+}
+
 // (tiles of 16 rows x 16 columns through LDS: the stacked vector is read and the Phi columns are written in whole lines)
 __global__ __launch_bounds__(256) void k_gd_store_cols(const double* __restrict__ imask, const double* __restrict__ X, int64_t n_rows,
                                                        double* __restrict__ phiT, int64_t ldp, int slot0, int nb) {
@@ -1241,6 +1284,16 @@ static int gdsw_setup(fedd_ctx* c) {
                                (const double*)c->d_gd_imask.p, n_rows, (const double*)c->d_co_mask.p, Vs);
             FEDD_TRY(spmm_owned(c, Vs, Ws, nullptr, nullptr));
             hipLaunchKernelGGL(k_gd_rhs_cols, gs, blk, 0, c->stream, (const double*)c->d_gd_imask.p, (const double*)Ws, n_rows, Bs);
+            // columns to unit norm (see k_cols_sumsq): the tolerance then holds per column
+            const int ncsb = (int)((n_rows + CS_ROWS - 1) / CS_ROWS);
+            FEDD_TRY(c->d_dtmp0.ensure(std::max<size_t>((size_t)ncsb * MULTI_NR + 4 * MULTI_NR, c->d_dtmp0.cap)));
+            double* csf = c->d_dtmp0.p;                         // [0, 16) 1 / norm, [16, 32) norm
+            double* cspart = csf + 4 * MULTI_NR;
+            hipLaunchKernelGGL(k_cols_sumsq, dim3((unsigned)ncsb), blk, 0, c->stream, (const double*)Bs, n_rows, cspart);
+            hipLaunchKernelGGL(k_cols_sum_parts, dim3(1), dim3(64), 0, c->stream, (const double*)cspart, ncsb, csf);
+            FEDD_TRY(allreduce_sum(c, csf, MULTI_NR));
+            hipLaunchKernelGGL(k_cols_scale_setup, dim3(1), dim3(64), 0, c->stream, csf);
+            hipLaunchKernelGGL(k_cols_scale, gs, blk, 0, c->stream, Bs, ns, (const double*)csf);
             int its = 0;
             double rel = 0.0;
             c->gm_mask = c->d_gd_imask.p;
@@ -1252,6 +1305,7 @@ static int gdsw_setup(fedd_ctx* c) {
             c->gm_mask = nullptr;
             c->gm_nr = 0;
             if (rc) return rc;
+            hipLaunchKernelGGL(k_cols_scale, gs, blk, 0, c->stream, Xs, ns, (const double*)(csf + MULTI_NR));
             its_max = std::max(its_max, its);
             rel_max = std::max(rel_max, rel);
             hipLaunchKernelGGL(k_gd_store_cols, dim3((unsigned)((n_rows + 15) / 16)), blk, 0, c->stream, (const double*)c->d_gd_imask.p,

@@ -181,6 +181,11 @@ struct fedd_ctx {
     int asm_u = 1;                              // slot-addressed assembly: pairs per lane with their loads in flight together (P1)
     int asm_kind = 0;                           // 0 = slot-addressed pair-parallel assembly, 2 = pair-parallel with slot sweep, 1 = lane-per-row gather
     // element-major tile structures of the current mesh (assemble.hip build_tiles): 0 = not built, 1 = ready, -1 = mesh does not fit
+    int asm_p2_elem = 1;                        // option "asm_p2_elem": P2 scalar forms take their element matrices from k_elem_matrix (one element per wavefront); 0 = pair kernels alone
+    int p2_state = 0;                           // gather lists of the P2 row sums (assemble.hip k_p2_lists): 0 = not built, 1 = ready, -1 = not applicable
+    fedd::DevBuf<uint16_t> d_p2_soff, d_p2_src; // per node-level nonzero the start of its sources; the sources (adjacency entry << 4 | local column)
+    fedd::DevBuf<double> d_ke;                  // [n_elem * nen * nen] element matrices of the assembly in progress (P2)
+    double asm_zero_eps = 0.0;                  // option "asm_zero_eps": FE::doSetZeros(eps) -- element contributions below eps are dropped (vector Laplacian, B, B^T); 0 = off
     int asm_tiles_host = 0;                     // option "asm_tiles_host": 1 = the tile structures are built on the host (the round-3 builder; A/B and tests), 0 = on the device
     double tl_build_ms = 0.0, adj_build_ms = 0.0;   // wall ms of the per-mesh structures of the current mesh: tile build, node -> element adjacency
     int tl_state = 0, asm_tiles = 1;            // option "asm_tiles": the P1 Laplace / elasticity forms take the element-major tile kernel (0: pair kernels)

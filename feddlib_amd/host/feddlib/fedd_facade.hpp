@@ -616,7 +616,8 @@ public:
     void assemblyLaplaceVecField(int dim, std::string FEType, int degree, MatrixPtr_Type& A, bool callFillComplete = true) {
         TEUCHOS_TEST_FOR_EXCEPTION(FEType == "P1-disc" || FEType == "P0", std::logic_error, "Not implemented for P0 or P1-disc");
         (void)degree;
-        TEUCHOS_TEST_FOR_EXCEPTION(setZeros_, std::logic_error, "doSetZeros thresholding is not built into the device assembly");
+        // doSetZeros (FE_def.hpp:74-79, 719-721): element contributions below myeps_ are dropped before they are added
+        feddCheck(fedd_set_option(domainVec_.at(checkFE(dim, FEType))->device()->ctx, "asm_zero_eps", setZeros_ ? myeps_ : 0.), "fedd_set_option");
         assembleInto(checkFE(dim, FEType), dim, FEDD_BLOCK_DIAG, FEDD_FORM_LAPLACE_VEC, nullptr, A, callFillComplete);
     }
     void assemblyMass(int dim, std::string FEType, std::string fieldType, MatrixPtr_Type& A, bool callFillComplete = true) {
@@ -645,6 +646,7 @@ public:
         const UN loc1 = checkFE(dim, FEType1);
         auto dom = domainVec_.at(loc1);
         const int64_t n_p = (int64_t)map2->getNodeNumElements();
+        feddCheck(fedd_set_option(dom->device()->ctx, "asm_zero_eps", setZeros_ ? myeps_ : 0.), "fedd_set_option");   // (FE_def.hpp:2002-2004, 2032-2034)
         feddCheck(fedd_assemble_div(dom->device()->ctx, n_p, 1, 2), "fedd_assemble_div");
         dom->device()->generation++;
         Bmat->bindSlot(dom->device(), 1);

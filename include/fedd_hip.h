@@ -394,7 +394,15 @@ int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_bloc
  * ghost entries of r are imported on a second stream, the others after the import (same operator bit for bit); 0 (default) =
  * import, then all subdomains.  An A/B switch for multi-GPU runs: on one GPU there is nothing to hide;
  * "whole_boxes" 1 (default) = with row ghosts, a box that a rank boundary crosses is built whole (with its full
- * overlap) on every rank that owns a part of it wherever the stored rows reach, 0 = each rank takes its part. */
+ * overlap) on every rank that owns a part of it wherever the stored rows reach, 0 = each rank takes its part;
+ * "asm_zero_eps" eps > 0 = FE::doSetZeros(eps) (FE_def.hpp:74-79): element contributions of magnitude below eps are set to zero
+ * before they are added, in the forms the reference thresholds -- the vector Laplacian (FEDD_FORM_LAPLACE_VEC, :719-721) and the
+ * divergence blocks (fedd_assemble_div, :2002-2004, 2032-2034); 0 (default) = off;
+ * "asm_p2_elem" 1 (default) = the P2 scalar forms (Laplace, vector Laplace, mass) evaluate every element once, one element per
+ * wavefront with the reference gradients and quadrature weights staged in LDS (k_elem_matrix), and the rows are summed from
+ * those element matrices; 0 = the pair kernels alone re-derive the row of every (row, element) pair;
+ * "asm_tiles_host" 1 = the tile structures of the assembly kernel are built by the round-3 host builder instead of the device
+ * kernels (A/B and tests; see fedd_mesh_setup_info). */
 int fedd_set_option(fedd_ctx* ctx, const char* key, double value);
 
 /* device-time accounting (HIP events on the context's stream around each kernel class) */

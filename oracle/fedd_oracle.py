@@ -589,9 +589,13 @@ def assembly_laplace(m: Mesh, fe: str | None = None) -> sp.csr_matrix:
     return fill_complete(r, c, v, m.n_global)
 
 
-def assembly_laplace_vecfield(m: Mesh, fe: str | None = None) -> sp.csr_matrix:
-    """FE::assemblyLaplaceVecField (FE_def.hpp:670-734): scalar K on the dim diagonal blocks only."""
+def assembly_laplace_vecfield(m: Mesh, fe: str | None = None, set_zeros_eps: float = 0.0) -> sp.csr_matrix:
+    """FE::assemblyLaplaceVecField (FE_def.hpp:670-734): scalar K on the dim diagonal blocks only.
+    set_zeros_eps > 0: FE::doSetZeros(eps) (:74-79) -- an element value with |value| < eps is set to zero before it is
+    inserted (:719-721)."""
     K = local_laplace(m, fe)
+    if set_zeros_eps > 0.0:
+        K = np.where(np.abs(K) < set_zeros_eps, 0.0, K)
     r, c, v = _local_to_triplets(m, K, dofs=m.dim)
     return fill_complete(r, c, v, m.dim * m.n_global)
 
@@ -696,7 +700,7 @@ def assembly_linelas(m: Mesh, lam: float, mu: float, fe: str | None = None) -> s
     return fill_complete(R.ravel(), C.ravel(), V.ravel(), dim * m.n_global)
 
 
-def assembly_div_and_divt(mv: Mesh, mp: Mesh):
+def assembly_div_and_divt(mv: Mesh, mp: Mesh, set_zeros_eps: float = 0.0):
     """FE::assemblyDivAndDivT (FE_def.hpp:1932-2057): velocity mesh `mv` (FEType1), pressure
     mesh `mp` (FEType2) over the same elements.  B[row p_i, col dim*v_j+d] =
     |detB| sum_q w_q psi_qi dphi_qjd ; BT its transpose pattern/value.  (Unscaled; the -1 is
@@ -706,6 +710,8 @@ def assembly_div_and_divt(mv: Mesh, mp: Mesh):
     G, w, absdet = dphi_trans(mv, mv.fe, deg)
     psi, _ = get_phi(dim, mp.fe, deg)
     V = np.einsum("q,qi,eqjd->eijd", w, psi, G) * absdet[:, None, None, None]
+    if set_zeros_eps > 0.0:        # doSetZeros: :2002-2004 (B) and :2032-2034 (B^T), the same element values
+        V = np.where(np.abs(V) < set_zeros_eps, 0.0, V)
     gp = mp.gid_rep[mp.conn]
     gv = mv.gid_rep[mv.conn]
     R = np.broadcast_to(gp[:, :, None, None], V.shape)

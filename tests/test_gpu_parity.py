@@ -422,6 +422,21 @@ def test_full_size_properties_cfg5_share(fedd_lib):
         assert rel_r <= 1e-6
         assert np.linalg.norm(b - Kbc @ xr) / np.linalg.norm(b) <= 1e-5
         assert np.abs(xr - xs).max() <= 1e-3 * np.abs(xs).max()          # two solves of the same system to 1e-6
+        # ... and the coarse space BASELINE configs[4] names, GDSW proper, at size (it ran only inside bench.py):
+        # 7^3 coarse cells (the library's default for 3 dofs per node), all (2 g - 1)^3 = 2197 interface entities x 3
+        # translations = 6591 coarse dofs, 78 extension columns in five stacked batches, the 6591^2 dense inverse,
+        # k_gd_restrict_cells_cols with 78 columns; true residual, same solution
+        c.schwarz_setup(overlap=1, combine=fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=fedd_lib.COARSE_GDSW)
+        g, n0 = c.schwarz_coarse_sizes()
+        assert list(g) == [7, 7, 7] and n0 == 13 ** 3 * 3
+        xg, its_g, rel_g = c.gmres(None, rtol=1e-6, max_it=1000, restart=100, use_prec=True)
+        assert rel_g <= 1e-6 and its_g < 260, (its_g, rel_g)
+        assert np.linalg.norm(b - Kbc @ xg) / np.linalg.norm(b) <= 1e-5
+        assert np.abs(xg - xs).max() <= 1e-3 * np.abs(xs).max()
+        # the coarse level earns its keep: the one-level operator alone is far from converged after as many iterations
+        c.schwarz_setup(overlap=1, combine=fedd_lib.COMBINE_RESTRICTED)
+        _, its_1, rel_1 = c.gmres(None, rtol=1e-6, max_it=its_g, restart=100, use_prec=True, want_x=False)
+        assert rel_1 > 1e-4, (its_1, rel_1)
     finally:
         c.close()
 

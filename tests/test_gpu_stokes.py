@@ -346,3 +346,86 @@ def test_bd_stabilization_and_p1p1_stokes(fedd_lib, ctx, dim, M):
     # unpreconditioned GMRES on the stabilised saddle-point system: error <= cond x residual; measured 1e-9 (3D) / 1e-10 (2D) at a
     # 1e-12 residual -- the 1e-10 bar is met in 2D, the 3D system is the worse conditioned one
     np.testing.assert_allclose(x, xd, rtol=0, atol=(1e-10 if dim == 2 else 1e-9) * np.abs(xd).max())
+
+
+@pytest.mark.parametrize("which", ["cube_p1", "cylinder_p2p1"])
+def test_set_zeros_thresholding(fedd_lib, ctx, cylinder, which):
+    """FE::doSetZeros(eps) (FE_def.hpp:74-79): the vector Laplacian (:719-721) and the divergence blocks (:2002-2004, 2032-2034)
+    set ELEMENT contributions below eps to zero before they are added; option "asm_zero_eps" does the same on the device (tile
+    kernel on P1, pair kernels on P2 and for B / B^T).  The threshold is chosen inside the range of the element values so that
+    it changes the matrix; the scalar Laplacian does not threshold (the reference's assemblyLaplace does not either)."""
+    if which == "cube_p1":
+        m1 = fedd_lib.structured_mesh(3, 1, 5)
+        mv = m1
+    else:
+        m1, mv = cylinder
+    dim = m1["dim"]
+    omv, omp = oracle_mesh(mv), oracle_mesh(m1)
+    n_p = m1["xyz"].shape[0]
+    def threshold(values, q):
+        """a threshold inside the range of the element values, in the middle of the widest gap near the q-quantile: no element
+        value within rounding distance of it (the oracle and the device sum in different orders)"""
+        v = np.unique(np.abs(values)[np.abs(values) > 1e-8 * np.abs(values).max()])
+        k = int(q * (v.shape[0] - 1))
+        lo, hi = max(0, k - 50), min(v.shape[0] - 1, k + 50)
+        i = lo + int(np.argmax(v[lo + 1:hi + 1] / v[lo:hi]))
+        return float(np.sqrt(v[i] * v[i + 1]))
+
+    eps = threshold(fo.local_laplace(omv), 0.3)
+    try:
+        ctx.mesh_set_dict(mv)
+        ctx.pattern_build(dim, fedd_lib.BLOCK_DIAG)
+        ctx.set_option("asm_zero_eps", 0.0)
+        ctx.assemble(fedd_lib.FORM_LAPLACE_VEC)
+        A0, _ = csr_global(ctx, dim * omv.n_global)
+        ctx.set_option("asm_zero_eps", eps)
+        ctx.assemble(fedd_lib.FORM_LAPLACE_VEC)
+        A1, _ = csr_global(ctx, dim * omv.n_global)
+        assert_matrix_close(A0, fo.assembly_laplace_vecfield(omv))
+        assert_matrix_close(A1, fo.assembly_laplace_vecfield(omv, set_zeros_eps=eps))
+        assert abs(A1 - A0).max() > 1e-3 * abs(A0).max()                 # the threshold did something
+        Bo0, _ = fo.assembly_div_and_divt(omv, omp)
+        deg = fo.determine_degree(omv.fe, omp.fe, "Grad", "Std")
+        G, wq, absdet = fo.dphi_trans(omv, omv.fe, deg)
+        psi, _ = fo.get_phi(dim, omp.fe, deg)
+        eps_b = threshold(np.einsum("q,qi,eqjd->eijd", wq, psi, G) * absdet[:, None, None, None], 0.3)
+        ctx.set_option("asm_zero_eps", eps_b)
+        ctx.assemble_div(n_p, 1, 2)
+        Bo, BTo = fo.assembly_div_and_divt(omv, omp, set_zeros_eps=eps_b)
+        assert_matrix_close(ctx.matrix_get(1), Bo)
+        assert_matrix_close(ctx.matrix_get(2), BTo)
+        # the scalar Laplacian is not thresholded
+        ctx.set_option("asm_zero_eps", eps)
+        ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+        ctx.assemble(fedd_lib.FORM_LAPLACE)
+        As, _ = csr_global(ctx, omv.n_global)
+        assert_matrix_close(As, fo.assembly_laplace(omv))
+    finally:
+        ctx.set_option("asm_zero_eps", 0.0)
+
+
+def test_p2_element_major_kernel_against_the_pair_kernels(fedd_lib, ctx, cylinder):
+    """P2 scalar forms: k_elem_matrix (one element per wavefront, the 10 x 10 -- 2D: 6 x 6 -- element matrices once per element)
+    + row sums against the pair kernels that re-derive every row (option "asm_p2_elem" 0), and both against the oracle:
+    FE::assemblyLaplace / assemblyLaplaceVecField / assemblyMass on P2 (FE_def.hpp:604-734, 454-524)."""
+    m1, m2 = cylinder
+    sq = fedd_lib.p2_of_p1(fedd_lib.read_mesh(os.path.join(GOLD, "square.mesh"), 2), volume_id=10)
+    for mv in (m2, sq):
+        dim = mv["dim"]
+        om = oracle_mesh(mv)
+        ctx.mesh_set_dict(mv)
+        for form, dofs, mode, ref in ((fedd_lib.FORM_LAPLACE, 1, fedd_lib.BLOCK_SCALAR, fo.assembly_laplace(om)),
+                                      (fedd_lib.FORM_MASS, 1, fedd_lib.BLOCK_SCALAR, fo.assembly_mass(om)),
+                                      (fedd_lib.FORM_LAPLACE_VEC, dim, fedd_lib.BLOCK_DIAG, fo.assembly_laplace_vecfield(om))):
+            vals = {}
+            for elem in (0, 1):
+                ctx.set_option("asm_p2_elem", elem)
+                ctx.pattern_build(dofs, mode)
+                ctx.assemble(form)
+                A, _ = csr_global(ctx, dofs * om.n_global)
+                assert_matrix_close(A, ref)
+                vals[elem] = ctx.csr_get()[2].copy()
+                ctx.assemble(form)
+                assert np.array_equal(vals[elem], ctx.csr_get()[2])          # bitwise reproducible
+            assert np.abs(vals[1] - vals[0]).max() <= 1e-14 * np.abs(vals[0]).max(), (dim, form)
+    ctx.set_option("asm_p2_elem", 1)
