@@ -86,6 +86,7 @@ SIGNATURES = {
     "fedd_schwarz_sizes": [C.c_void_p, _i64p, _i64p],
     "fedd_schwarz_conforming": [C.c_void_p, _i64p],
     "fedd_spmv_patterns": [C.c_void_p, _i64p, _i64p],
+    "fedd_spmv_classes": [C.c_void_p, _i64p, _i64p, _i64p],
     "fedd_spmv_col_bytes": [C.c_void_p, C.POINTER(C.c_int), _i64p],
     "fedd_gmres": [C.c_void_p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int, _ip, _f64p],
     "fedd_set_option": [C.c_void_p, C.c_char_p, C.c_double],
@@ -477,8 +478,11 @@ class Context:
         _chk(self._L.fedd_spmv_patterns(self._h, C.byref(p), C.byref(e)))
         cb, wide = C.c_int(), C.c_int64()
         _chk(self._L.fedd_spmv_col_bytes(self._h, C.byref(cb), C.byref(wide)))
+        nc, rc, rest = C.c_int64(), C.c_int64(), C.c_int64()
+        _chk(self._L.fedd_spmv_classes(self._h, C.byref(nc), C.byref(rc), C.byref(rest)))
         return dict(nnz_pattern=a.value, nnz_streamed=b.value, column_patterns=p.value, rows_with_explicit_columns=e.value,
-                    column_index_bytes=cb.value, entries_with_32bit_columns=wide.value)
+                    column_index_bytes=cb.value, entries_with_32bit_columns=wide.value, row_classes=nc.value,
+                    rows_in_classes=rc.value, nnz_streamed_outside_classes=rest.value)
 
     def spmv_device(self, reps):
         _chk(self._L.fedd_spmv_device(self._h, reps))

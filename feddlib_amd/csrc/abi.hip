@@ -575,6 +575,16 @@ extern "C" int fedd_spmv_patterns(fedd_ctx* c, int64_t* n_patterns, int64_t* n_r
     return 0;
 }
 
+extern "C" int fedd_spmv_classes(fedd_ctx* c, int64_t* n_classes, int64_t* n_rows_in_classes, int64_t* nnz_streamed_rest) {
+    NEED_DEVICE(c);
+    FEDD_CHECK(c->have_pattern, "fedd_spmv_classes: no matrix");
+    const bool on = c->cs_valid && c->cs_npat > 0 && c->spmv_pattern && c->cs_ncls > 0 && c->spmv_classes;
+    if (n_classes) *n_classes = on ? c->cs_ncls : 0;
+    if (n_rows_in_classes) *n_rows_in_classes = on ? c->cs_cls_rows : 0;
+    if (nnz_streamed_rest) *nnz_streamed_rest = on ? c->cs_cls_rest : c->cs_nnz;
+    return 0;
+}
+
 extern "C" int fedd_spmv_col_bytes(fedd_ctx* c, int* bytes_per_column_index, int64_t* entries_with_32bit_columns) {
     NEED_DEVICE(c);
     FEDD_CHECK(c->have_pattern && bytes_per_column_index, "fedd_spmv_col_bytes: no matrix / null output");
@@ -784,6 +794,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
         c->cs_valid = false;
     }
     else if (k == "spmv_exact_public") c->spmv_exact_public = (int)value;
+    else if (k == "spmv_classes") { c->spmv_classes = (int)value; c->cs_valid = false; }
     else if (k == "asm_tiles_host") { c->asm_tiles_host = (int)value; c->tl_state = 0; }
     else if (k == "asm_p2_elem") c->asm_p2_elem = (int)value;
     else if (k == "asm_zero_eps") {

@@ -222,6 +222,13 @@ struct fedd_ctx {
     fedd::DevBuf<uint64_t> d_cs_hash;           // row hashes [n] | table keys
     fedd::DevBuf<int32_t> d_cs_pati;            // slot of row [n] | table min row | pattern of slot | lengths | offset lists | counters
     fedd::DevBuf<uint16_t> d_cs_pat;            // pattern id per row (0xffff: explicit columns)
+    int spmv_classes = 1;                       // option "spmv_classes": rows that repeat their column pattern AND their values bit for bit share a class (spmv.hip k_spmv_cls)
+    int32_t cs_ncls = 0, cs_cls_rows = 0, cs_cls_rest = 0;   // classes in use (0: off), rows in a class, stream entries of the other rows
+    fedd::DevBuf<uint32_t> d_cs_cls;            // per row: class << 8 | column pattern (0xffffffff: none)
+    fedd::DevBuf<uint16_t> d_cs_clspat;         // column pattern of a class
+    fedd::DevBuf<double> d_cs_clsval;           // [classes][8] values of a class
+    fedd::DevBuf<int32_t> d_cs_clsi;            // slot of row [n] | table min row | class of slot | counters
+    fedd::DevBuf<uint64_t> d_cs_clskey;         // table keys
     fedd::DevCsr aux[fedd::MAX_AUX];            // stored blocks (A, B, B^T, C) of a mixed problem
     bool merged = false;                        // system matrix = merged blocks (dof -> node map below)
     int64_t merged_nA = 0;                      // rows of block row 0

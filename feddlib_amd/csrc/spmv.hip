@@ -635,6 +635,214 @@ __global__ __launch_bounds__(256) void k_spmv_pat(const int32_t* __restrict__ ro
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row classes (round 4).  On a structured grid not only the column offsets of the rows repeat, their VALUES do too: the
+// assembled Laplace matrix of the 214^3-cell cube has 2 174 bitwise-distinct rows among its 9.66 million interior ones
+// (tools/experiments/row_classes.py; they differ in the last bits, by where the coordinates i h round).  Rows with the same
+// column pattern AND the same values, bit for bit, form a class; the solver's SpMV then reads a 4-byte (class, pattern) word per row and
+// takes the row's values from a table of at most CLS_MAX classes (64 bytes each: L2 resident, the frequent ones in L1) instead of streaming 8
+// bytes per entry -- the same products in the same order, so y is the same bit for bit (a row whose hash collides keeps its
+// stream entries: every classed row is verified entry by entry against the table).  Built with the column patterns, per
+// assembled matrix: k_cls_hash -> k_cls_insert (the pattern table's insert) -> k_cls_table -> k_cls_rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int CLS_L = 8;            // longest row that can join a class
+constexpr int CLS_MAX = 16384;      // classes (16-bit ids; their pattern ids live in LDS: 32 KB)
+constexpr int CLS_TS = 65536;       // hash table slots
+constexpr uint32_t CLS_NONE = 0xffffffffu;     // per row: class << 8 | column pattern, or none
+
+__global__ void k_cls_hash(const int32_t* __restrict__ rowptr, const double* __restrict__ val, const uint16_t* __restrict__ pat,
+                           int32_t n, unsigned long long* __restrict__ hash) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int32_t b = rowptr[r], len = rowptr[r + 1] - b;
+    const uint16_t id = pat[r];
+    unsigned long long h = 0ull;
+    if (id != SPAT_EXPL && len >= 1 && len <= CLS_L) {
+        h = sp_mix(((unsigned long long)id << 8) | (unsigned long long)len);
+        for (int j = 0; j < len; ++j) h = sp_mix(h ^ (unsigned long long)__double_as_longlong(val[b + j])) + (unsigned long long)(j + 1);
+        h |= 1ull;
+    }
+    hash[r] = h;
+}
+
+// (k_pat_insert with the larger table)
+__global__ void k_cls_insert(const unsigned long long* __restrict__ hash, int32_t n, unsigned long long* __restrict__ tkey,
+                             int32_t* __restrict__ tmin, int32_t* __restrict__ slot_of, int32_t* __restrict__ n_claimed) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long h = r < n ? hash[r] : 0ull;
+    const bool active = h != 0ull;
+    uint64_t todo = __ballot(active);
+    int32_t mine = -1;
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const unsigned long long lh = __shfl(h, leader, 64);
+        const uint64_t same = __ballot(active && h == lh) & todo;
+        int32_t s_found = -1;
+        if (lane == leader && __hip_atomic_load(n_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 2 * CLS_MAX) {
+            int s = (int)(lh % CLS_TS);
+            for (int probe = 0; probe < 128; ++probe) {
+                unsigned long long old = __hip_atomic_load(&tkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == 0ull) {
+                    old = atomicCAS(&tkey[s], 0ull, lh);
+                    if (old == 0ull) atomicAdd(n_claimed, 1);
+                }
+                if (old == 0ull || old == lh) {
+                    if (__hip_atomic_load(&tmin[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > r) atomicMin(&tmin[s], r);
+                    s_found = s;
+                    break;
+                }
+                s = s + 1 == CLS_TS ? 0 : s + 1;
+            }
+        }
+        s_found = __shfl(s_found, leader, 64);
+        if ((same >> lane) & 1ull) mine = s_found;
+        todo &= ~same;
+    }
+    if (r < n) slot_of[r] = mine;
+}
+
+// one workgroup: class ids in slot order, values and pattern id from the representative rows (the lowest row of a slot)
+__global__ __launch_bounds__(1024) void k_cls_table(const unsigned long long* __restrict__ tkey, const int32_t* __restrict__ tmin,
+                                                    const int32_t* __restrict__ rowptr, const double* __restrict__ val,
+                                                    const uint16_t* __restrict__ pat, int32_t* __restrict__ cls_of_slot,
+                                                    double* __restrict__ cls_val, uint16_t* __restrict__ cls_pat,
+                                                    int32_t* __restrict__ n_cls) {
+    __shared__ int32_t part[1024];
+    const int tid = threadIdx.x;
+    constexpr int PER = CLS_TS / 1024;
+    int cnt = 0;
+    for (int k = 0; k < PER; ++k) cnt += tkey[tid * PER + k] != 0ull ? 1 : 0;
+    part[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int t = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    int run = part[tid] - cnt;
+    if (tid == 1023) *n_cls = part[1023];
+    for (int k = 0; k < PER; ++k) {
+        const int sl = tid * PER + k;
+        int id = -1;
+        if (tkey[sl] != 0ull) {
+            id = run < CLS_MAX ? run : -1;
+            ++run;
+        }
+        cls_of_slot[sl] = id;
+        if (id >= 0) {
+            const int32_t r = tmin[sl], b = rowptr[r], len = rowptr[r + 1] - b;
+            for (int j = 0; j < CLS_L; ++j) cls_val[id * CLS_L + j] = j < len ? val[b + j] : 0.0;
+            cls_pat[id] = pat[r];
+        }
+    }
+}
+
+// per row: its class, verified bit for bit against the table; counters: [0] classed rows, [1] stream entries of the others
+__global__ void k_cls_rows(const int32_t* __restrict__ rowptr, const double* __restrict__ val, const uint16_t* __restrict__ pat,
+                           int32_t n, const int32_t* __restrict__ slot_of, const int32_t* __restrict__ cls_of_slot,
+                           const double* __restrict__ cls_val, const uint16_t* __restrict__ cls_pat, uint32_t* __restrict__ cls,
+                           int32_t* __restrict__ counters) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    bool in = false;
+    int32_t len = 0;
+    if (r < n) {
+        const int32_t b = rowptr[r];
+        len = rowptr[r + 1] - b;
+        const int32_t sl = slot_of[r];
+        const int32_t id = sl >= 0 ? cls_of_slot[sl] : -1;
+        if (id >= 0 && len <= CLS_L && cls_pat[id] == pat[r]) {
+            in = true;
+            for (int j = 0; j < len; ++j)
+                in = in && __double_as_longlong(val[b + j]) == __double_as_longlong(cls_val[id * CLS_L + j]);
+            for (int j = len; j < CLS_L; ++j) in = in && cls_val[id * CLS_L + j] == 0.0;
+        }
+        cls[r] = in ? ((uint32_t)id << 8) | (uint32_t)pat[r] : CLS_NONE;
+    }
+    const uint64_t m = __ballot(in);
+    int rest = (r < n && !in) ? len : 0;
+    for (int off = 32; off > 0; off >>= 1) rest += __shfl_xor(rest, off, 64);
+    if ((threadIdx.x & 63) == 0) {
+        if (m) atomicAdd(counters, (int32_t)__builtin_popcountll(m));
+        if (rest) atomicAdd(counters + 1, rest);
+    }
+}
+
+// SpMV over row classes: a lane per row, RPT rows per lane 256 apart; a classed row reads its 4-byte (class, pattern) word, the
+// column pattern (LDS) and the class's values (table), and x at row + offset (consecutive lanes = consecutive rows: coalesced); the other
+// rows take their entries from the compacted stream.  Products and sums separate and in entry order: the bits of k_spmv_pat
+// and k_spmv_win.
+template <int RPT>
+__global__ __launch_bounds__(256) void k_spmv_cls(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                                  const double* __restrict__ val, const uint16_t* __restrict__ pat,
+                                                  const uint32_t* __restrict__ cls, const double* __restrict__ cls_val,
+                                                  const int32_t* __restrict__ plen, const int32_t* __restrict__ pdelta, int32_t n_pat,
+                                                  const double* __restrict__ x, double* __restrict__ y, int32_t n, SpmvEpi epi) {
+    __shared__ int32_t sdelta[SPAT_P * SPAT_L];
+    __shared__ int32_t slen[SPAT_P];
+    const int tid = threadIdx.x;
+    const int32_t nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int32_t lb = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
+    const int32_t r0 = lb * (256 * RPT);
+    uint32_t id[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int32_t r = r0 + tid + 256 * u;
+        id[u] = r < n ? cls[r] : CLS_NONE;
+    }
+    for (int i = tid; i < n_pat * SPAT_L; i += 256) sdelta[i] = pdelta[i];
+    for (int i = tid; i < n_pat; i += 256) slen[i] = plen[i];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int32_t r = r0 + tid + 256 * u;
+        if (r >= n) continue;
+        double s = 0.0;
+        {
+#pragma clang fp contract(off)
+            if (id[u] != CLS_NONE) {
+                const int pid = (int)(id[u] & 255u);
+                const int len = slen[pid];
+                const int32_t* __restrict__ dl = sdelta + pid * SPAT_L;
+                // (a class entry is 64 bytes, aligned: four 16-byte loads, its padding is zero)
+                const vd2* __restrict__ cv = reinterpret_cast<const vd2*>(cls_val + (size_t)(id[u] >> 8) * CLS_L);
+                double xv[CLS_L], av[CLS_L];
+#pragma unroll
+                for (int j = 0; j < CLS_L; j += 2) {
+                    const vd2 a2 = j < len ? cv[j >> 1] : vd2{0.0, 0.0};
+                    av[j] = a2.x;
+                    av[j + 1] = a2.y;
+                }
+#pragma unroll
+                for (int j = 0; j < CLS_L; ++j) xv[j] = j < len ? x[r + dl[j]] : 0.0;
+#pragma unroll
+                for (int j = 0; j < CLS_L; ++j)
+                    if (j < len) {
+                        const double pr = av[j] * xv[j];
+                        s = s + pr;
+                    }
+            } else {
+                const int32_t b = rowptr[r], e = rowptr[r + 1];
+                const uint16_t pid = pat[r];
+                if (pid != SPAT_EXPL) {
+                    const int32_t* __restrict__ dl = sdelta + (int)pid * SPAT_L;
+                    for (int32_t p = b; p < e; ++p) {
+                        const double pr = val[p] * x[r + dl[p - b]];
+                        s = s + pr;
+                    }
+                } else {
+                    for (int32_t p = b; p < e; ++p) {
+                        const double pr = val[p] * x[colind[p]];
+                        s = s + pr;
+                    }
+                }
+            }
+        }
+        y[r] = epi_apply(epi, s, r);
+    }
+}
+
 // window -> first row table of the parity CSR (one-off per pattern)
 static int spmv_window_rows(fedd_ctx* c) {
     const int32_t nb = (int32_t)(c->nnz / SP_CHUNK + 1);
@@ -676,13 +884,17 @@ static int spmv_compact_build(fedd_ctx* c) {
                        (const int32_t*)c->d_cs_rowptr.p, n, nbc, c->d_cs_rows.p, 256 * c->cs_win_nu);
     // column patterns (see k_spmv_pat)
     c->cs_npat = 0;
+    c->cs_ncls = 0;
     // (matrices that fit the Infinity Cache keep the per-entry kernel -- measured: 100^3 cells 20.5 us against 25 us --,
     // so the dictionary is not built for them; option value 2 forces it)
     const bool big = 12.0 * (double)total > 256.0 * 1024.0 * 1024.0 || c->spmv_pattern == 2;
     // (rows longer than a pattern holds -- 16 entries; vector problems with full node blocks have 36 and more -- find none: the
     // three passes over the stream that would establish that cost 3.7 ms at cfg 5's share, so they are skipped by the average)
     const bool short_rows = total <= (int64_t)SPAT_L * std::max<int32_t>(n, 1);
-    if (c->spmv_pattern && total > 0 && big && short_rows) {
+    // (round 4: matrices in the Infinity Cache build the dictionary too when the row classes may pay -- they did on every
+    // structured grid tried: 107^3 cells 23.2 -> 16.2 us --; without classes such a matrix goes back to the per-entry kernel)
+    const bool try_classes = c->spmv_classes && !big && n >= 65536;
+    if (c->spmv_pattern && total > 0 && (big || try_classes) && short_rows) {
         FEDD_TRY(c->d_cs_hash.ensure((size_t)n + SPAT_TS));
         FEDD_TRY(c->d_cs_pati.ensure((size_t)n + 2 * SPAT_TS + SPAT_P * (SPAT_L + 1) + 16));
         FEDD_TRY(c->d_cs_pat.ensure((size_t)n + 1));
@@ -725,6 +937,44 @@ static int spmv_compact_build(fedd_ctx* c) {
             hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nbp + 1 + 255) / 256)), dim3(256), 0, c->stream,
                                (const int32_t*)c->d_cs_rowptr.p, n, nbp, c->d_cs_prows.p, 512 * c->cs_pat_nu);
         }
+        // row classes on top of the column patterns (see k_cls_hash): rows that repeat their values bit for bit
+        c->cs_ncls = 0;
+        c->cs_cls_rows = 0;
+        if (c->cs_npat > 0 && c->spmv_classes) {
+            FEDD_TRY(c->d_cs_cls.ensure((size_t)n + 1));
+            FEDD_TRY(c->d_cs_clsval.ensure((size_t)CLS_MAX * CLS_L));
+            FEDD_TRY(c->d_cs_clspat.ensure((size_t)CLS_MAX));
+            FEDD_TRY(c->d_cs_clsi.ensure((size_t)n + 2 * CLS_TS + 16));
+            FEDD_TRY(c->d_cs_clskey.ensure((size_t)CLS_TS));
+            unsigned long long* ckey = (unsigned long long*)c->d_cs_clskey.p;
+            int32_t* cslot = c->d_cs_clsi.p;
+            int32_t* cmin = cslot + n;
+            int32_t* cof = cmin + CLS_TS;
+            int32_t* ccnt = cof + CLS_TS;       // claimed | classes | classed rows | stream entries of the other rows
+            FEDD_HIP(hipMemsetAsync(ckey, 0, CLS_TS * sizeof(unsigned long long), c->stream));
+            FEDD_HIP(hipMemsetAsync(cmin, 0x7f, CLS_TS * sizeof(int32_t), c->stream));
+            FEDD_HIP(hipMemsetAsync(ccnt, 0, 8 * sizeof(int32_t), c->stream));
+            hipLaunchKernelGGL(k_cls_hash, gr, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p,
+                               (const uint16_t*)c->d_cs_pat.p, n, hash);
+            hipLaunchKernelGGL(k_cls_insert, gr, b256, 0, c->stream, (const unsigned long long*)hash, n, ckey, cmin, cslot, ccnt);
+            hipLaunchKernelGGL(k_cls_table, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long*)ckey, (const int32_t*)cmin,
+                               (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p, (const uint16_t*)c->d_cs_pat.p, cof,
+                               c->d_cs_clsval.p, c->d_cs_clspat.p, ccnt + 1);
+            hipLaunchKernelGGL(k_cls_rows, gr, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p,
+                               (const uint16_t*)c->d_cs_pat.p, n, (const int32_t*)cslot, (const int32_t*)cof,
+                               (const double*)c->d_cs_clsval.p, (const uint16_t*)c->d_cs_clspat.p, c->d_cs_cls.p, ccnt + 2);
+            int32_t hc[4] = {0, 0, 0, 0};
+            FEDD_HIP(hipMemcpyAsync(hc, ccnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+            FEDD_HIP(hipStreamSynchronize(c->stream));
+            if (getenv("FEDD_SPMV_DEBUG")) fprintf(stderr, "[spmv classes] n %d: slots claimed %d, classes %d, rows in classes %d, stream entries outside %d\n", n, hc[0], hc[1], hc[2], hc[3]);
+            // worth it when nearly every row is in a class (the other rows go through a per-row loop)
+            if (hc[1] >= 1 && (int64_t)hc[2] * 10 >= (int64_t)n * 9) {
+                c->cs_ncls = std::min<int32_t>(hc[1], CLS_MAX);
+                c->cs_cls_rows = hc[2];
+                c->cs_cls_rest = hc[3];
+            }
+        }
+        if (!big && c->cs_ncls == 0) c->cs_npat = 0;        // (the dictionary was only tried for the classes' sake)
     }
     // 16-bit columns for the per-entry window kernel (option "spmv_col16"; decided by the data: every window's column span)
     // (not for a stream that goes through the column patterns: k_spmv_pat reads no column of a row that has one)
@@ -782,6 +1032,15 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
         if (c->cs_nnz == 0) {
             if (epi.sub) hipLaunchKernelGGL(k_epi_only, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_y_owned, epi, n);
             else FEDD_HIP(hipMemsetAsync(d_y_owned, 0, (size_t)n * sizeof(double), c->stream));
+        } else if (c->cs_npat > 0 && c->spmv_pattern && c->cs_ncls > 0 && c->spmv_classes) {
+            const int32_t* plen = c->d_cs_pati.p + n + 2 * SPAT_TS;
+            const int32_t* pdelta = plen + SPAT_P;
+            constexpr int RPT = 4;
+            const int32_t nwg = (n + 256 * RPT - 1) / (256 * RPT);
+            hipLaunchKernelGGL(k_spmv_cls<RPT>, dim3((unsigned)nwg), dim3(256), 0, c->stream, (const int32_t*)c->d_cs_rowptr.p,
+                               (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, (const uint16_t*)c->d_cs_pat.p,
+                               (const uint32_t*)c->d_cs_cls.p, (const double*)c->d_cs_clsval.p, plen, pdelta, c->cs_npat, x,
+                               d_y_owned, n, epi);
         } else if (c->cs_npat > 0 && c->spmv_pattern) {
             const int32_t* plen = c->d_cs_pati.p + n + 2 * SPAT_TS;
             const int32_t* pdelta = plen + SPAT_P;

@@ -425,6 +425,13 @@ int fedd_timing_get_sampled(fedd_ctx* ctx, int timer, double* sampled_ms, int64_
  * 16-bit pattern id per row).  n_patterns = 0: not in use (option off, no solve yet, or the matrix has no repeated rows);
  * n_rows_explicit = rows that keep explicit column indices. */
 int fedd_spmv_patterns(fedd_ctx* ctx, int64_t* n_patterns, int64_t* n_rows_explicit);
+/* Row classes of the solver's stream (option "spmv_classes", default on; built with the column patterns, so for matrices beyond
+ * the Infinity Cache): rows with the same column pattern AND the same values, bit for bit, share a class -- on a structured
+ * grid the assembled matrix has a few thousand distinct rows among millions.  The SpMV then reads a 4-byte (class, pattern) word per row and
+ * the row's values from a table of at most 16384 classes instead of 8 bytes per entry; same products, same order: y identical
+ * bit for bit.  n_classes = 0: not in use (fewer than 90 % of the rows repeat); n_rows_in_classes: rows served from the table;
+ * nnz_streamed_rest: stream entries of the other rows.  Outputs may be NULL. */
+int fedd_spmv_classes(fedd_ctx* ctx, int64_t* n_classes, int64_t* n_rows_in_classes, int64_t* nnz_streamed_rest);
 /* bytes per column index of the solver's SpMV stream: 0 = column patterns in use (above), 2 = 16-bit offsets from a base per
  * window of the stream (option "spmv_col16", default 1; 10 instead of 12 bytes per entry) in every window whose columns span less
  * than 65536 -- any mesh numbered with some locality; entries_with_32bit_columns (nullable) = the entries of the windows that

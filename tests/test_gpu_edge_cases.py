@@ -349,6 +349,7 @@ def test_spmv_sixteen_bit_columns_are_not_taken_where_a_window_spans_too_many_co
     ctx.assemble(fedd_lib.FORM_LAPLACE)
     x = np.random.default_rng(18).standard_normal(ctx.csr_sizes()[0])
     ctx.set_option("spmv_exact_public", 0)
+    ctx.set_option("spmv_classes", 0)          # (this test is about the per-entry kernel's column indices)
     try:
         y = ctx.spmv(x)
         # the natural numbering of the cube couples nodes 43^2 apart: windows of 2048 entries span ~2 * 1849 + a few hundred columns
@@ -375,4 +376,75 @@ def test_spmv_sixteen_bit_columns_are_not_taken_where_a_window_spans_too_many_co
         assert np.array_equal(ctx.spmv(x[perm]), y2) and ctx.spmv_info()["column_index_bytes"] == 4
         ctx.set_option("spmv_col16", 1)
     finally:
+        ctx.set_option("spmv_exact_public", 1)
+        ctx.set_option("spmv_classes", 1)
+
+
+@pytest.mark.parametrize("dim,M", [(3, 21), (3, 16), (2, 75)])
+def test_spmv_row_classes_give_the_same_bits(fedd_lib, ctx, dim, M):
+    """spmv_classes (round 4): rows that repeat their column pattern AND their values bit for bit share a class, the SpMV reads a
+    2-byte class id per row and the values from a table.  On a structured grid whose spacing is no power of two the assembled
+    rows differ in their last bits by where the coordinates round -- several hundred classes --, with a power of two there is
+    one class per pattern; either way y is the y of the pattern kernel and of the per-entry kernel BIT FOR BIT, a whole solve
+    gives the same iterates (bitwise the same solution), and the rows that are in no class keep their stream entries."""
+    m = fedd_lib.structured_mesh(dim, 1, M)
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+    ctx.assemble(fedd_lib.FORM_LAPLACE)
+    ctx.assemble_rhs([1.0])
+    ctx.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+    nr = ctx.csr_sizes()[0]
+    x = np.random.default_rng(9).standard_normal(nr)
+    ctx.set_option("spmv_exact_public", 0)     # fedd_spmv = the solver's stream in this test
+    try:
+        ctx.set_option("spmv_pattern", 0)
+        y0 = ctx.spmv(x)
+        ctx.set_option("spmv_pattern", 2)
+        ctx.set_option("spmv_classes", 0)
+        y1 = ctx.spmv(x)
+        info1 = ctx.spmv_info()
+        assert info1["column_patterns"] >= 1 and info1["row_classes"] == 0
+        ctx.set_option("spmv_classes", 1)
+        y2 = ctx.spmv(x)
+        info2 = ctx.spmv_info()
+        assert np.array_equal(y1, y0) and np.array_equal(y2, y0)
+        assert 1 <= info2["row_classes"] <= 16384 and info2["rows_in_classes"] >= 0.9 * nr, info2
+        # every stream entry is accounted for: in a class or outside
+        rowptr, col, val, _ = ctx.csr_get()
+        assert info2["nnz_streamed_outside_classes"] <= info2["nnz_streamed"]
+        if M & (M - 1) == 0:      # h a power of two: the arithmetic is exact, one class per (pattern, Dirichlet or not)
+            assert info2["row_classes"] <= 2 * info2["column_patterns"], info2
+        # a solve on either stream: the same bits all the way (the shifted epilogue of the Newton basis included)
+        ctx.schwarz_set_target(27 if dim == 3 else 16, 1.0)
+        ctx.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED)
+        ctx.set_option("gmres_s", 16)
+        sol = {}
+        for cls in (0, 1):
+            ctx.set_option("spmv_classes", cls)
+            sol[cls] = ctx.gmres(None, rtol=1e-10, max_it=400, restart=100, use_prec=True)
+        assert sol[0][1] == sol[1][1] and np.array_equal(sol[0][0], sol[1][0])
+    finally:
+        ctx.set_option("spmv_pattern", 1)
+        ctx.set_option("spmv_classes", 1)
+        ctx.set_option("spmv_exact_public", 1)
+        ctx.set_option("gmres_s", 0)
+
+
+def test_spmv_row_classes_stay_off_where_rows_do_not_repeat(fedd_lib, ctx):
+    m = fedd_lib.read_mesh(os.path.join(GOLD, "DFG3DCylinder_1k.mesh"), 3)
+    ctx.mesh_set_dict(m)
+    ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+    ctx.assemble(fedd_lib.FORM_LAPLACE)
+    ctx.dirichlet([1, 2, 4], [0.0, 0.0, 0.0])
+    nr = ctx.csr_sizes()[0]
+    x = np.random.default_rng(8).standard_normal(nr)
+    ctx.set_option("spmv_exact_public", 0)
+    try:
+        ctx.set_option("spmv_pattern", 0)
+        y0 = ctx.spmv(x)
+        ctx.set_option("spmv_pattern", 2)
+        y1 = ctx.spmv(x)
+        assert np.array_equal(y1, y0) and ctx.spmv_info()["row_classes"] == 0
+    finally:
+        ctx.set_option("spmv_pattern", 1)
         ctx.set_option("spmv_exact_public", 1)

@@ -42,7 +42,7 @@ for rep in range(2):
         else:
             b = 12.0 * si["nnz_streamed"] + 20.0 * nr
         err = np.abs(y - y0).max() / np.abs(y0).max()
-        print("M %d %-40s %.2f us  %.0f GB/s streamed (%.3f of 8 TB/s, %.3f of ceiling)  diff vs first: %.1e  patterns %d explicit rows %d"
+        print("M %d %-40s %.2f us  %.0f GB/s streamed (%.3f of 8 TB/s, %.3f of ceiling)  diff vs first: %.1e  patterns %d explicit rows %d  classes %d rows in classes %d"
               % (M, cfg, ms * 1e3, b / ms / 1e6, b / ms / 8e9, b / ms / 1e6 / ceiling, err, si["column_patterns"],
-                 si["rows_with_explicit_columns"]), flush=True)
+                 si["rows_with_explicit_columns"], si.get("row_classes", 0), si.get("rows_in_classes", 0)), flush=True)
 c.close()
