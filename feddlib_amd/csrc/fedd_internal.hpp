@@ -71,7 +71,7 @@ struct DevBuf {
 
 constexpr int MAX_BC = 16;
 constexpr int MAX_DOFS = 3;
-constexpr int SPMV_PAT_LMAX = 16;       // longest offset list of the SpMV pattern table (spmv.hip SPAT_L)
+constexpr int SPMV_PAT_LMAX = 48;       // longest offset list of the SpMV pattern table (spmv.hip SPAT_L)
 constexpr int SCHWARZ_NMAX = 256;  // largest overlapping subdomain (dofs) the register / LDS dense kernels take
 constexpr int SCHWARZ_NMAX_BIG = 1024;  // ... and the batched matrix-core inversion of the large-subdomain path
 
@@ -223,6 +223,10 @@ struct fedd_ctx {
     fedd::DevBuf<int32_t> d_cs_pati;            // slot of row [n] | table min row | pattern of slot | lengths | offset lists | counters
     fedd::DevBuf<uint16_t> d_cs_pat;            // pattern id per row (0xffff: explicit columns)
     int spmv_classes = 1;                       // option "spmv_classes": rows that repeat their column pattern AND their values bit for bit share a class (spmv.hip k_spmv_cls)
+    int32_t cs_cls_tab_n = -1, cs_cls_tab_len = 0, cs_cls_tab_ncls = 0, cs_cls_tab_rows = 0;   // the class table and row words on the device: rows, stride, classes and classed rows of the build they come from (kept while the next matrix still matches them bit for bit)
+    int32_t cs_pat_tab_n = -1, cs_pat_tab_npat = 0, cs_pat_tab_nexpl = 0, cs_pat_tab_len = 0;   // the column-pattern dictionary on the device: rows, patterns, explicit rows, longest pattern of the build it comes from (kept while the next matrix still matches it)
+    int spmv_keep_dict = 0;                     // option "spmv_keep_dictionary": 1 = the previous matrix' pattern dictionary and row classes are kept while the new stream matches them bit for bit (one verifying pass instead of the build: time loops that reassemble the same operator); 0 (default) = built per matrix
+    int cs_cls_len = 8;                         // stride of the class table (8, 16 or 48 values)
     int32_t cs_ncls = 0, cs_cls_rows = 0, cs_cls_rest = 0;   // classes in use (0: off), rows in a class, stream entries of the other rows
     fedd::DevBuf<uint32_t> d_cs_cls;            // per row: class << 8 | column pattern (0xffffffff: none)
     fedd::DevBuf<uint16_t> d_cs_clspat;         // column pattern of a class

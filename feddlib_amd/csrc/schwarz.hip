@@ -604,8 +604,11 @@ __global__ void k_pack_order(const int32_t* __restrict__ ord, const int32_t* __r
         a0 = mine[0];
         const int32_t r0 = ref[0];
         same = sub_n[rp] == nn;
-        if (same)
-            for (int k = e; k < nn; k += 16) same = same && (mine[k] - a0 == ref[k] - r0);
+        if (same) {     // (differences OR-ed, no short-circuit: the loads of all entries fly together)
+            int32_t diff = 0;
+            for (int k = e; k < nn; k += 16) diff |= (mine[k] - a0) ^ (ref[k] - r0);
+            same = diff == 0;
+        }
     }
     unsigned bad = same ? 0u : 1u;
     for (int off = 8; off > 0; off >>= 1) bad |= __shfl_xor(bad, off, 16);

@@ -414,7 +414,9 @@ int read_bandwidth(fedd_ctx* c, int64_t bytes, int reps, double* gbs) {
 // 12 -> 8 bytes per entry.  Rows whose list is not in the table (more than SPAT_L entries, or the table full) keep
 // their explicit columns (id SPAT_EXPL); more than SPAT_P patterns (an unstructured mesh): the dictionary is not used.
 // The sum of a row runs over its entries in order with separate multiply and add, exactly like k_spmv_win: same bits.
-constexpr int SPAT_P = 64, SPAT_L = 16, SPAT_TS = 1024;
+constexpr int SPAT_P = 64, SPAT_L = 48, SPAT_TS = 1024;
+constexpr int SPAT_LK = 16;     // longest pattern k_spmv_pat unrolls; longer patterns (vector problems: 3 x 15 entries per row) exist for the
+                                // row classes' sake only (k_spmv_cls) -- without classes such a matrix goes back to the per-entry kernel
 constexpr uint16_t SPAT_EXPL = 0xffff;
 
 __device__ __forceinline__ uint64_t sp_mix(uint64_t x) {
@@ -525,15 +527,25 @@ __global__ __launch_bounds__(256) void k_pat_table(const unsigned long long* __r
 __global__ void k_pat_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int32_t n,
                            const int32_t* __restrict__ slot_of, const int32_t* __restrict__ pat_of_slot,
                            const int32_t* __restrict__ plen, const int32_t* __restrict__ pdelta, uint16_t* __restrict__ pat,
-                           int32_t* __restrict__ n_expl) {
+                           int32_t* __restrict__ n_expl, const uint16_t* prev, int32_t n_prev_pat) {
     // 8 lanes per row (consecutive lanes read consecutive column ids)
+    // prev != nullptr (may be pat itself): the candidate of a row is its id of the PREVIOUS matrix' dictionary (slot_of /
+    // pat_of_slot are not read): the dictionary is kept while every row that had a pattern still matches it -- n_expl[3] counts
+    // the rows that do not (any: the caller rebuilds)
     const int32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     const int e = threadIdx.x & 7;
     int id = -1, len = 0;
     bool ok = true;
+    bool had = false;
     if (r < n) {
-        const int32_t s = slot_of[r];
-        id = s >= 0 ? pat_of_slot[s] : -1;
+        if (prev) {
+            const uint16_t pv = prev[r];
+            id = (pv != SPAT_EXPL && (int)pv < n_prev_pat) ? (int)pv : -1;
+            had = pv != SPAT_EXPL;
+        } else {
+            const int32_t s = slot_of[r];
+            id = s >= 0 ? pat_of_slot[s] : -1;
+        }
         const int32_t b = rowptr[r];
         len = rowptr[r + 1] - b;
         if (id >= 0) {
@@ -547,6 +559,10 @@ __global__ void k_pat_rows(const int32_t* __restrict__ rowptr, const int32_t* __
     if (bad) id = -1;
     const bool writer = r < n && e == 0;
     if (writer) pat[r] = id >= 0 ? (uint16_t)id : SPAT_EXPL;
+    if (prev) {
+        const uint64_t lost = __ballot(writer && had && id < 0);
+        if (lost && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(lost)) atomicAdd(n_expl + 3, (int32_t)__builtin_popcountll(lost));
+    }
     // one atomic per wave for the count (every row of an unstructured mesh lands here)
     const uint64_t expl = __ballot(writer && id < 0);
     if (expl && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(expl)) atomicAdd(n_expl, (int32_t)__builtin_popcountll(expl));
@@ -562,7 +578,7 @@ __global__ void k_pat_rows(const int32_t* __restrict__ rowptr, const int32_t* __
 // which the per-entry gathers of k_spmv_win are not.  CH = 256 NU with NU = the usual row length: a window then holds
 // about 256 rows, one per lane.  (A variant with 256 ROWS per workgroup was slower, 174 against 152 us at 214^3: its value
 // loads depend on two row pointers.)
-template <bool NT, int NU, int LU /* unrolled entries per row: 8 when no pattern is longer, else SPAT_L */>
+template <bool NT, int NU, int LU /* unrolled entries per row: 8 when no pattern is longer, else SPAT_LK */>
 __global__ __launch_bounds__(256) void k_spmv_pat(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                   const double* __restrict__ val, const uint16_t* __restrict__ pat,
                                                   const int32_t* __restrict__ plen, const int32_t* __restrict__ pdelta,
@@ -570,7 +586,7 @@ __global__ __launch_bounds__(256) void k_spmv_pat(const int32_t* __restrict__ ro
                                                   const int32_t* __restrict__ block_row, int32_t nb, int32_t nnz, int32_t ovh,
                                                   SpmvEpi epi) {
     extern __shared__ double sval[];                    // [CH + ovh]
-    __shared__ int32_t sdelta[SPAT_P * SPAT_L];
+    __shared__ int32_t sdelta[SPAT_P * SPAT_LK];      // (this kernel runs patterns of at most SPAT_LK entries)
     __shared__ int32_t slen[SPAT_P];
     constexpr int CH = 512 * NU;                        // NU 16-byte loads per lane (the value array is padded by a window)
     const int tid = threadIdx.x;
@@ -591,7 +607,7 @@ __global__ __launch_bounds__(256) void k_spmv_pat(const int32_t* __restrict__ ro
     const int32_t r_a = max(min(R0 + tid, R1 - 1), 0), r_b = max(min(R0 + tid + 256, R1 - 1), 0);
     const int32_t rb0 = rowptr[r_a], rb1 = rowptr[r_b];
     const uint16_t id0 = pat[r_a], id1 = pat[r_b];
-    for (int i = tid; i < n_pat * SPAT_L; i += 256) sdelta[i] = pdelta[i];
+    for (int i = tid; i < n_pat * SPAT_LK; i += 256) sdelta[i] = pdelta[(i / SPAT_LK) * SPAT_L + (i % SPAT_LK)];
     for (int i = tid; i < n_pat; i += 256) slen[i] = plen[i];
 #pragma unroll
     for (int u = 0; u < NU; ++u) reinterpret_cast<vd2*>(sval)[tid + u * 256] = v[u];
@@ -609,7 +625,7 @@ __global__ __launch_bounds__(256) void k_spmv_pat(const int32_t* __restrict__ ro
 #pragma clang fp contract(off)
             if (id != SPAT_EXPL) {
                 const int len = slen[id];
-                const int32_t* __restrict__ dl = sdelta + (int)id * SPAT_L;
+                const int32_t* __restrict__ dl = sdelta + (int)id * SPAT_LK;
                 double xv[LU], av[LU];
 #pragma unroll
                 for (int j = 0; j < LU; ++j) {          // all loads of the row in flight together
@@ -643,70 +659,64 @@ __global__ __launch_bounds__(256) void k_spmv_pat(const int32_t* __restrict__ ro
 // takes the row's values from a table of at most CLS_MAX classes (64 bytes each: L2 resident, the frequent ones in L1) instead of streaming 8
 // bytes per entry -- the same products in the same order, so y is the same bit for bit (a row whose hash collides keeps its
 // stream entries: every classed row is verified entry by entry against the table).  Built with the column patterns, per
-// assembled matrix: k_cls_hash -> k_cls_insert (the pattern table's insert) -> k_cls_table -> k_cls_rows.
+// assembled matrix: k_cls_insert -> k_cls_table -> k_cls_rows.
 // ------------------------------------------------------------------------------------------------
-constexpr int CLS_L = 8;            // longest row that can join a class
+constexpr int CLS_L = SPAT_L;       // longest row that can join a class; the table stride is the longest pattern rounded up to 8
 constexpr int CLS_MAX = 16384;      // classes (16-bit ids; their pattern ids live in LDS: 32 KB)
 constexpr int CLS_TS = 65536;       // hash table slots
 constexpr uint32_t CLS_NONE = 0xffffffffu;     // per row: class << 8 | column pattern, or none
 
-__global__ void k_cls_hash(const int32_t* __restrict__ rowptr, const double* __restrict__ val, const uint16_t* __restrict__ pat,
-                           int32_t n, unsigned long long* __restrict__ hash) {
-    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int32_t b = rowptr[r], len = rowptr[r + 1] - b;
-    const uint16_t id = pat[r];
+// hash of a row's (pattern, length, value bits) and its slot in the table.  Eight lanes per row read its values (consecutive
+// lanes, consecutive entries: coalesced; a lane per row reading 56 bytes at a 56-byte stride ran at 1 TB/s) and add their
+// position-keyed mixes (order independent, like k_pat_hash); lane 0 of the row probes, on its own: ordinary cached loads first
+// -- a key never changes once it is set, so a non-zero value seen is right and a stale zero is resolved by the compare-and-swap
+// (atomic loads of the dozen hot keys would all queue at their L2 channels) --, a compare-and-swap only for an empty slot; the
+// slot keeps the lowest row seen (its representative).  (A leader-per-distinct-hash loop as in k_pat_insert serialises here: a
+// wave of 64 consecutive rows holds a dozen classes, not one or two patterns.)
+__global__ __launch_bounds__(256) void k_cls_insert(const int32_t* __restrict__ rowptr, const double* __restrict__ val,
+                                                    const uint16_t* __restrict__ pat, int32_t n, unsigned long long* __restrict__ tkey,
+                                                    int32_t* __restrict__ tmin, int32_t* __restrict__ slot_of,
+                                                    int32_t* __restrict__ n_claimed) {
+    const int32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int e = threadIdx.x & 7;
     unsigned long long h = 0ull;
-    if (id != SPAT_EXPL && len >= 1 && len <= CLS_L) {
-        h = sp_mix(((unsigned long long)id << 8) | (unsigned long long)len);
-        for (int j = 0; j < len; ++j) h = sp_mix(h ^ (unsigned long long)__double_as_longlong(val[b + j])) + (unsigned long long)(j + 1);
-        h |= 1ull;
+    int32_t len = 0;
+    uint16_t id = SPAT_EXPL;
+    if (r < n) {
+        const int32_t b = rowptr[r];
+        len = rowptr[r + 1] - b;
+        id = pat[r];
+        if (id != SPAT_EXPL && len >= 1 && len <= CLS_L)
+            for (int j = e; j < len; j += 8)
+                h += sp_mix(((unsigned long long)(j + 1) * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)__double_as_longlong(val[b + j]));
     }
-    hash[r] = h;
-}
-
-// (k_pat_insert with the larger table)
-__global__ void k_cls_insert(const unsigned long long* __restrict__ hash, int32_t n, unsigned long long* __restrict__ tkey,
-                             int32_t* __restrict__ tmin, int32_t* __restrict__ slot_of, int32_t* __restrict__ n_claimed) {
-    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long h = r < n ? hash[r] : 0ull;
-    const bool active = h != 0ull;
-    uint64_t todo = __ballot(active);
-    int32_t mine = -1;
-    while (todo) {
-        const int leader = __builtin_ctzll(todo);
-        const unsigned long long lh = __shfl(h, leader, 64);
-        const uint64_t same = __ballot(active && h == lh) & todo;
-        int32_t s_found = -1;
-        if (lane == leader && __hip_atomic_load(n_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 2 * CLS_MAX) {
-            int s = (int)(lh % CLS_TS);
+    for (int off = 4; off > 0; off >>= 1) h += __shfl_xor(h, off, 8);
+    if (r >= n || e != 0) return;
+    int32_t found = -1;
+    if (id != SPAT_EXPL && len >= 1 && len <= CLS_L) {
+        h = sp_mix(h + (((unsigned long long)id << 8) | (unsigned long long)len)) | 1ull;
+        if (*n_claimed <= 2 * CLS_MAX) {
+            int s2 = (int)(h % CLS_TS);
             for (int probe = 0; probe < 128; ++probe) {
-                unsigned long long old = __hip_atomic_load(&tkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long old = tkey[s2];
                 if (old == 0ull) {
-                    old = atomicCAS(&tkey[s], 0ull, lh);
+                    old = atomicCAS(&tkey[s2], 0ull, h);
                     if (old == 0ull) atomicAdd(n_claimed, 1);
                 }
-                if (old == 0ull || old == lh) {
-                    if (__hip_atomic_load(&tmin[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > r) atomicMin(&tmin[s], r);
-                    s_found = s;
+                if (old == 0ull || old == h) {
+                    if (tmin[s2] > r) atomicMin(&tmin[s2], r);
+                    found = s2;
                     break;
                 }
-                s = s + 1 == CLS_TS ? 0 : s + 1;
+                s2 = s2 + 1 == CLS_TS ? 0 : s2 + 1;
             }
         }
-        s_found = __shfl(s_found, leader, 64);
-        if ((same >> lane) & 1ull) mine = s_found;
-        todo &= ~same;
     }
-    if (r < n) slot_of[r] = mine;
+    slot_of[r] = found;
 }
 
-// one workgroup: class ids in slot order, values and pattern id from the representative rows (the lowest row of a slot)
-__global__ __launch_bounds__(1024) void k_cls_table(const unsigned long long* __restrict__ tkey, const int32_t* __restrict__ tmin,
-                                                    const int32_t* __restrict__ rowptr, const double* __restrict__ val,
-                                                    const uint16_t* __restrict__ pat, int32_t* __restrict__ cls_of_slot,
-                                                    double* __restrict__ cls_val, uint16_t* __restrict__ cls_pat,
+// one workgroup: class ids in slot order
+__global__ __launch_bounds__(1024) void k_cls_table(const unsigned long long* __restrict__ tkey, int32_t* __restrict__ cls_of_slot,
                                                     int32_t* __restrict__ n_cls) {
     __shared__ int32_t part[1024];
     const int tid = threadIdx.x;
@@ -731,37 +741,51 @@ __global__ __launch_bounds__(1024) void k_cls_table(const unsigned long long* __
             ++run;
         }
         cls_of_slot[sl] = id;
-        if (id >= 0) {
-            const int32_t r = tmin[sl], b = rowptr[r], len = rowptr[r + 1] - b;
-            for (int j = 0; j < CLS_L; ++j) cls_val[id * CLS_L + j] = j < len ? val[b + j] : 0.0;
-            cls_pat[id] = pat[r];
-        }
     }
 }
 
-// per row: its class, verified bit for bit against the table; counters: [0] classed rows, [1] stream entries of the others
-__global__ void k_cls_rows(const int32_t* __restrict__ rowptr, const double* __restrict__ val, const uint16_t* __restrict__ pat,
-                           int32_t n, const int32_t* __restrict__ slot_of, const int32_t* __restrict__ cls_of_slot,
-                           const double* __restrict__ cls_val, const uint16_t* __restrict__ cls_pat, uint32_t* __restrict__ cls,
-                           int32_t* __restrict__ counters) {
-    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    bool in = false;
-    int32_t len = 0;
+// a thread per slot: values and pattern id of a class from its representative row (the lowest row of the slot)
+__global__ void k_cls_fill(const int32_t* __restrict__ cls_of_slot, const int32_t* __restrict__ tmin, const int32_t* __restrict__ rowptr,
+                           const double* __restrict__ val, const uint16_t* __restrict__ pat, double* __restrict__ cls_val,
+                           uint16_t* __restrict__ cls_pat, int cl) {
+    const int sl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sl >= CLS_TS) return;
+    const int id = cls_of_slot[sl];
+    if (id < 0) return;
+    const int32_t r = tmin[sl], b = rowptr[r], len = rowptr[r + 1] - b;
+    for (int j = 0; j < cl; ++j) cls_val[(size_t)id * cl + j] = j < len ? val[b + j] : 0.0;
+    cls_pat[id] = pat[r];
+}
+
+// per row (eight lanes): its class, verified bit for bit against the table (differences OR-ed, no short-circuit: all loads fly
+// together); counters: [0] classed rows, [1] stream entries of the others
+__global__ __launch_bounds__(256) void k_cls_rows(const int32_t* __restrict__ rowptr, const double* __restrict__ val,
+                                                  const uint16_t* __restrict__ pat, int32_t n, const int32_t* __restrict__ slot_of,
+                                                  const int32_t* __restrict__ cls_of_slot, const double* __restrict__ cls_val,
+                                                  const uint16_t* __restrict__ cls_pat, uint32_t* __restrict__ cls,
+                                                  int32_t* __restrict__ counters, int cl) {
+    const int32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int e = threadIdx.x & 7;
+    bool cand = false;
+    int32_t len = 0, id = -1;
+    long long diff = 0;
+    uint16_t pid = SPAT_EXPL;
     if (r < n) {
         const int32_t b = rowptr[r];
         len = rowptr[r + 1] - b;
         const int32_t sl = slot_of[r];
-        const int32_t id = sl >= 0 ? cls_of_slot[sl] : -1;
-        if (id >= 0 && len <= CLS_L && cls_pat[id] == pat[r]) {
-            in = true;
-            for (int j = 0; j < len; ++j)
-                in = in && __double_as_longlong(val[b + j]) == __double_as_longlong(cls_val[id * CLS_L + j]);
-            for (int j = len; j < CLS_L; ++j) in = in && cls_val[id * CLS_L + j] == 0.0;
-        }
-        cls[r] = in ? ((uint32_t)id << 8) | (uint32_t)pat[r] : CLS_NONE;
+        id = sl >= 0 ? cls_of_slot[sl] : -1;
+        pid = pat[r];
+        cand = id >= 0 && len <= cl && cls_pat[id] == pid;
+        if (cand)
+            for (int j = e; j < len; j += 8) diff |= __double_as_longlong(val[b + j]) ^ __double_as_longlong(cls_val[(size_t)id * cl + j]);
     }
-    const uint64_t m = __ballot(in);
-    int rest = (r < n && !in) ? len : 0;
+    for (int off = 4; off > 0; off >>= 1) diff |= __shfl_xor(diff, off, 8);
+    const bool writer = r < n && e == 0;
+    const bool in = cand && diff == 0;      // (the padding of a table entry is zero by construction: k_cls_fill)
+    if (writer) cls[r] = in ? ((uint32_t)id << 8) | (uint32_t)pid : CLS_NONE;
+    const uint64_t m = __ballot(writer && in);
+    int rest = (writer && !in) ? len : 0;
     for (int off = 32; off > 0; off >>= 1) rest += __shfl_xor(rest, off, 64);
     if ((threadIdx.x & 63) == 0) {
         if (m) atomicAdd(counters, (int32_t)__builtin_popcountll(m));
@@ -769,11 +793,46 @@ __global__ void k_cls_rows(const int32_t* __restrict__ rowptr, const double* __r
     }
 }
 
+// The classes of the previous matrix still hold?  Per row: its word of the previous build against the new stream -- pattern id,
+// length and every value bit for bit.  counters: [0] rows that match, [1] previously classed rows that do not (any: rebuild),
+// [2] stream entries of the rows without a class.  (A driver that reassembles the same operator -- a time loop, the bench --
+// pays one pass over the stream instead of the build: 2.9 -> 0.3 ms at 214^3 cells.)
+__global__ void k_cls_verify(const int32_t* __restrict__ rowptr, const double* __restrict__ val, const uint16_t* __restrict__ pat,
+                             int32_t n, const uint32_t* __restrict__ cls, const double* __restrict__ cls_val,
+                             const uint16_t* __restrict__ cls_pat, int32_t n_cls, int32_t* __restrict__ counters, int cl) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = false, bad = false;
+    int32_t len = 0;
+    if (r < n) {
+        const int32_t b = rowptr[r];
+        len = rowptr[r + 1] - b;
+        const uint32_t w = cls[r];
+        if (w != CLS_NONE) {
+            const int32_t id = (int32_t)(w >> 8);
+            ok = id < n_cls && len <= cl && (uint32_t)pat[r] == (w & 255u) && cls_pat[id] == pat[r];
+            if (ok) {
+                long long diff = 0;
+                for (int j = 0; j < len; ++j) diff |= __double_as_longlong(val[b + j]) ^ __double_as_longlong(cls_val[(size_t)id * cl + j]);
+                ok = diff == 0;
+            }
+            bad = !ok;
+        }
+    }
+    const uint64_t m = __ballot(ok), mb = __ballot(bad);
+    int rest = (r < n && !ok) ? len : 0;
+    for (int off = 32; off > 0; off >>= 1) rest += __shfl_xor(rest, off, 64);
+    if ((threadIdx.x & 63) == 0) {
+        if (m) atomicAdd(counters, (int32_t)__builtin_popcountll(m));
+        if (mb) atomicAdd(counters + 1, (int32_t)__builtin_popcountll(mb));
+        if (rest) atomicAdd(counters + 2, rest);
+    }
+}
+
 // SpMV over row classes: a lane per row, RPT rows per lane 256 apart; a classed row reads its 4-byte (class, pattern) word, the
 // column pattern (LDS) and the class's values (table), and x at row + offset (consecutive lanes = consecutive rows: coalesced); the other
 // rows take their entries from the compacted stream.  Products and sums separate and in entry order: the bits of k_spmv_pat
 // and k_spmv_win.
-template <int RPT>
+template <int RPT, int CL /* table stride = most entries of a classed row: 8, 16 or SPAT_L */>
 __global__ __launch_bounds__(256) void k_spmv_cls(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                   const double* __restrict__ val, const uint16_t* __restrict__ pat,
                                                   const uint32_t* __restrict__ cls, const double* __restrict__ cls_val,
@@ -805,23 +864,28 @@ __global__ __launch_bounds__(256) void k_spmv_cls(const int32_t* __restrict__ ro
                 const int pid = (int)(id[u] & 255u);
                 const int len = slen[pid];
                 const int32_t* __restrict__ dl = sdelta + pid * SPAT_L;
-                // (a class entry is 64 bytes, aligned: four 16-byte loads, its padding is zero)
-                const vd2* __restrict__ cv = reinterpret_cast<const vd2*>(cls_val + (size_t)(id[u] >> 8) * CLS_L);
-                double xv[CLS_L], av[CLS_L];
+                // (a class entry is CL doubles, 16-byte aligned, its padding zero: 16-byte loads, eight entries at a time)
+                const vd2* __restrict__ cv = reinterpret_cast<const vd2*>(cls_val + (size_t)(id[u] >> 8) * CL);
 #pragma unroll
-                for (int j = 0; j < CLS_L; j += 2) {
-                    const vd2 a2 = j < len ? cv[j >> 1] : vd2{0.0, 0.0};
-                    av[j] = a2.x;
-                    av[j + 1] = a2.y;
-                }
+                for (int j0 = 0; j0 < CL; j0 += 8) {
+                    if (j0 < len) {
+                        double xv[8], av[8];
 #pragma unroll
-                for (int j = 0; j < CLS_L; ++j) xv[j] = j < len ? x[r + dl[j]] : 0.0;
+                        for (int j = 0; j < 8; j += 2) {
+                            const vd2 a2 = j0 + j < len ? cv[(j0 + j) >> 1] : vd2{0.0, 0.0};
+                            av[j] = a2.x;
+                            av[j + 1] = a2.y;
+                        }
 #pragma unroll
-                for (int j = 0; j < CLS_L; ++j)
-                    if (j < len) {
-                        const double pr = av[j] * xv[j];
-                        s = s + pr;
+                        for (int j = 0; j < 8; ++j) xv[j] = j0 + j < len ? x[r + dl[j0 + j]] : 0.0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (j0 + j < len) {
+                                const double pr = av[j] * xv[j];
+                                s = s + pr;
+                            }
                     }
+                }
             } else {
                 const int32_t b = rowptr[r], e = rowptr[r + 1];
                 const uint16_t pid = pat[r];
@@ -906,10 +970,28 @@ static int spmv_compact_build(fedd_ctx* c) {
         int32_t* plen = pat_of_slot + SPAT_TS;
         int32_t* pdelta = plen + SPAT_P;
         int32_t* counters = pdelta + SPAT_P * SPAT_L;      // claimed slots | patterns | explicit rows
+        const dim3 b256(256), gr((unsigned)((n + 255) / 256)), gr8((unsigned)(((int64_t)n * 8 + 255) / 256));
+        int32_t h[6] = {0, 0, 0, 0, 0, 0};    // claimed slots | patterns | explicit rows | longest row | longest pattern | rows that lost their pattern
+        // the previous matrix' dictionary first: kept while every row that had a pattern still has it (one pass instead of four)
+        bool pat_kept = false;
+        if (c->spmv_keep_dict && c->cs_pat_tab_n == n && c->cs_pat_tab_npat > 0) {
+            FEDD_HIP(hipMemsetAsync(counters + 2, 0, 4 * sizeof(int32_t), c->stream));
+            hipLaunchKernelGGL(k_pat_rows, gr8, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const int32_t*)c->d_cs_col.p, n,
+                               (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)plen, (const int32_t*)pdelta,
+                               c->d_cs_pat.p, counters + 2, (const uint16_t*)c->d_cs_pat.p, c->cs_pat_tab_npat);
+            FEDD_HIP(hipMemcpyAsync(h + 2, counters + 2, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            FEDD_HIP(hipStreamSynchronize(c->stream));
+            if (h[5] == 0 && h[2] == c->cs_pat_tab_nexpl) {
+                pat_kept = true;
+                h[1] = c->cs_pat_tab_npat;
+                h[4] = c->cs_pat_tab_len;
+            }
+        }
+        if (!pat_kept) {
+        c->cs_pat_tab_n = -1;
         FEDD_HIP(hipMemsetAsync(tkey, 0, SPAT_TS * sizeof(unsigned long long), c->stream));
         FEDD_HIP(hipMemsetAsync(tmin, 0x7f, SPAT_TS * sizeof(int32_t), c->stream));
         FEDD_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int32_t), c->stream));
-        const dim3 b256(256), gr((unsigned)((n + 255) / 256)), gr8((unsigned)(((int64_t)n * 8 + 255) / 256));
         hipLaunchKernelGGL(k_pat_hash, gr8, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const int32_t*)c->d_cs_col.p, n, hash);
         // (a table that fills up means "no repeated patterns": the rows that find no slot keep explicit columns)
         hipLaunchKernelGGL(k_pat_insert, gr, b256, 0, c->stream, (const unsigned long long*)hash, n, tkey, tmin, slot_of, counters);
@@ -917,15 +999,21 @@ static int spmv_compact_build(fedd_ctx* c) {
                            (const int32_t*)c->d_cs_rowptr.p, (const int32_t*)c->d_cs_col.p, pat_of_slot, plen, pdelta, counters + 1);
         hipLaunchKernelGGL(k_pat_rows, gr8, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const int32_t*)c->d_cs_col.p, n,
                            (const int32_t*)slot_of, (const int32_t*)pat_of_slot, (const int32_t*)plen, (const int32_t*)pdelta,
-                           c->d_cs_pat.p, counters + 2);
-        int32_t h[5] = {0, 0, 0, 0, 0};    // claimed slots | patterns | explicit rows | longest row | longest pattern
-        FEDD_HIP(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+                           c->d_cs_pat.p, counters + 2, (const uint16_t*)nullptr, 0);
+        FEDD_HIP(hipMemcpyAsync(h, counters, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         FEDD_HIP(hipStreamSynchronize(c->stream));
+        }
         // worth it when most rows found a pattern (an unstructured mesh fills the table and finds none)
         c->cs_max_len = std::max(1, h[3]);
         c->cs_npat = (h[1] >= 1 && (int64_t)h[2] * 4 <= (int64_t)n) ? std::min<int32_t>(h[1], SPAT_P) : 0;
         c->cs_nexpl = h[2];
         c->cs_pat_len = h[4];
+        if (!pat_kept && c->cs_npat > 0) {      // (remembered for the next matrix)
+            c->cs_pat_tab_n = n;
+            c->cs_pat_tab_npat = c->cs_npat;
+            c->cs_pat_tab_nexpl = h[2];
+            c->cs_pat_tab_len = h[4];
+        }
         if (c->cs_npat > 0) {
             c->cs_pat_nu = (c->spmv_pat_nu >= 2 && c->spmv_pat_nu <= 8)
                                ? c->spmv_pat_nu
@@ -937,12 +1025,14 @@ static int spmv_compact_build(fedd_ctx* c) {
             hipLaunchKernelGGL(k_spmv_block_rows, dim3((unsigned)((nbp + 1 + 255) / 256)), dim3(256), 0, c->stream,
                                (const int32_t*)c->d_cs_rowptr.p, n, nbp, c->d_cs_prows.p, 512 * c->cs_pat_nu);
         }
-        // row classes on top of the column patterns (see k_cls_hash): rows that repeat their values bit for bit
+        // row classes on top of the column patterns (see k_cls_insert): rows that repeat their values bit for bit
         c->cs_ncls = 0;
         c->cs_cls_rows = 0;
         if (c->cs_npat > 0 && c->spmv_classes) {
             FEDD_TRY(c->d_cs_cls.ensure((size_t)n + 1));
-            FEDD_TRY(c->d_cs_clsval.ensure((size_t)CLS_MAX * CLS_L));
+            const int cl = c->cs_pat_len <= 8 ? 8 : (c->cs_pat_len <= 16 ? 16 : SPAT_L);       // table stride
+            c->cs_cls_len = cl;
+            FEDD_TRY(c->d_cs_clsval.ensure((size_t)CLS_MAX * cl));
             FEDD_TRY(c->d_cs_clspat.ensure((size_t)CLS_MAX));
             FEDD_TRY(c->d_cs_clsi.ensure((size_t)n + 2 * CLS_TS + 16));
             FEDD_TRY(c->d_cs_clskey.ensure((size_t)CLS_TS));
@@ -951,18 +1041,37 @@ static int spmv_compact_build(fedd_ctx* c) {
             int32_t* cmin = cslot + n;
             int32_t* cof = cmin + CLS_TS;
             int32_t* ccnt = cof + CLS_TS;       // claimed | classes | classed rows | stream entries of the other rows
+            // the previous matrix' classes first: if every row that had a class still matches it bit for bit, they are kept
+            bool kept = false;
+            if (c->spmv_keep_dict && c->cs_cls_tab_n == n && c->cs_cls_tab_len == cl && c->cs_cls_tab_ncls > 0 && c->cs_cls_tab_rows > 0) {
+                FEDD_HIP(hipMemsetAsync(ccnt, 0, 8 * sizeof(int32_t), c->stream));
+                hipLaunchKernelGGL(k_cls_verify, gr, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p,
+                                   (const uint16_t*)c->d_cs_pat.p, n, (const uint32_t*)c->d_cs_cls.p, (const double*)c->d_cs_clsval.p,
+                                   (const uint16_t*)c->d_cs_clspat.p, c->cs_cls_tab_ncls, ccnt, cl);
+                int32_t hv[3] = {0, 0, 0};
+                FEDD_HIP(hipMemcpyAsync(hv, ccnt, sizeof(hv), hipMemcpyDeviceToHost, c->stream));
+                FEDD_HIP(hipStreamSynchronize(c->stream));
+                if (hv[1] == 0 && hv[0] == c->cs_cls_tab_rows) {
+                    kept = true;
+                    c->cs_ncls = c->cs_cls_tab_ncls;
+                    c->cs_cls_rows = hv[0];
+                    c->cs_cls_rest = hv[2];
+                }
+            }
+            if (!kept) {
+            c->cs_cls_tab_ncls = 0;
             FEDD_HIP(hipMemsetAsync(ckey, 0, CLS_TS * sizeof(unsigned long long), c->stream));
             FEDD_HIP(hipMemsetAsync(cmin, 0x7f, CLS_TS * sizeof(int32_t), c->stream));
             FEDD_HIP(hipMemsetAsync(ccnt, 0, 8 * sizeof(int32_t), c->stream));
-            hipLaunchKernelGGL(k_cls_hash, gr, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p,
-                               (const uint16_t*)c->d_cs_pat.p, n, hash);
-            hipLaunchKernelGGL(k_cls_insert, gr, b256, 0, c->stream, (const unsigned long long*)hash, n, ckey, cmin, cslot, ccnt);
-            hipLaunchKernelGGL(k_cls_table, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long*)ckey, (const int32_t*)cmin,
-                               (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p, (const uint16_t*)c->d_cs_pat.p, cof,
-                               c->d_cs_clsval.p, c->d_cs_clspat.p, ccnt + 1);
-            hipLaunchKernelGGL(k_cls_rows, gr, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p,
+            hipLaunchKernelGGL(k_cls_insert, gr8, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p,
+                               (const uint16_t*)c->d_cs_pat.p, n, ckey, cmin, cslot, ccnt);
+            hipLaunchKernelGGL(k_cls_table, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long*)ckey, cof, ccnt + 1);
+            hipLaunchKernelGGL(k_cls_fill, dim3(CLS_TS / 256), b256, 0, c->stream, (const int32_t*)cof, (const int32_t*)cmin,
+                               (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p, (const uint16_t*)c->d_cs_pat.p,
+                               c->d_cs_clsval.p, c->d_cs_clspat.p, cl);
+            hipLaunchKernelGGL(k_cls_rows, gr8, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p,
                                (const uint16_t*)c->d_cs_pat.p, n, (const int32_t*)cslot, (const int32_t*)cof,
-                               (const double*)c->d_cs_clsval.p, (const uint16_t*)c->d_cs_clspat.p, c->d_cs_cls.p, ccnt + 2);
+                               (const double*)c->d_cs_clsval.p, (const uint16_t*)c->d_cs_clspat.p, c->d_cs_cls.p, ccnt + 2, cl);
             int32_t hc[4] = {0, 0, 0, 0};
             FEDD_HIP(hipMemcpyAsync(hc, ccnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
             FEDD_HIP(hipStreamSynchronize(c->stream));
@@ -972,9 +1081,15 @@ static int spmv_compact_build(fedd_ctx* c) {
                 c->cs_ncls = std::min<int32_t>(hc[1], CLS_MAX);
                 c->cs_cls_rows = hc[2];
                 c->cs_cls_rest = hc[3];
+                c->cs_cls_tab_n = n;
+                c->cs_cls_tab_len = cl;
+                c->cs_cls_tab_ncls = c->cs_ncls;
+                c->cs_cls_tab_rows = hc[2];
             }
+            }   // (!kept)
         }
-        if (!big && c->cs_ncls == 0) c->cs_npat = 0;        // (the dictionary was only tried for the classes' sake)
+        // (the dictionary was only tried for the classes' sake: a matrix in the Infinity Cache, or rows longer than k_spmv_pat unrolls)
+        if ((!big || c->cs_pat_len > SPAT_LK) && c->cs_ncls == 0) c->cs_npat = 0;
     }
     // 16-bit columns for the per-entry window kernel (option "spmv_col16"; decided by the data: every window's column span)
     // (not for a stream that goes through the column patterns: k_spmv_pat reads no column of a row that has one)
@@ -1035,12 +1150,15 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
         } else if (c->cs_npat > 0 && c->spmv_pattern && c->cs_ncls > 0 && c->spmv_classes) {
             const int32_t* plen = c->d_cs_pati.p + n + 2 * SPAT_TS;
             const int32_t* pdelta = plen + SPAT_P;
-            constexpr int RPT = 4;
-            const int32_t nwg = (n + 256 * RPT - 1) / (256 * RPT);
-            hipLaunchKernelGGL(k_spmv_cls<RPT>, dim3((unsigned)nwg), dim3(256), 0, c->stream, (const int32_t*)c->d_cs_rowptr.p,
-                               (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, (const uint16_t*)c->d_cs_pat.p,
-                               (const uint32_t*)c->d_cs_cls.p, (const double*)c->d_cs_clsval.p, plen, pdelta, c->cs_npat, x,
-                               d_y_owned, n, epi);
+#define SPMV_CLS(RPT_, CL_)                                                                                                     \
+    hipLaunchKernelGGL((k_spmv_cls<RPT_, CL_>), dim3((unsigned)((n + 256 * RPT_ - 1) / (256 * RPT_))), dim3(256), 0, c->stream,     \
+                       (const int32_t*)c->d_cs_rowptr.p, (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p,                 \
+                       (const uint16_t*)c->d_cs_pat.p, (const uint32_t*)c->d_cs_cls.p, (const double*)c->d_cs_clsval.p, plen, pdelta, \
+                       c->cs_npat, x, d_y_owned, n, epi)
+            if (c->cs_cls_len <= 8) SPMV_CLS(4, 8);
+            else if (c->cs_cls_len <= 16) SPMV_CLS(4, 16);
+            else SPMV_CLS(2, SPAT_L);
+#undef SPMV_CLS
         } else if (c->cs_npat > 0 && c->spmv_pattern) {
             const int32_t* plen = c->d_cs_pati.p + n + 2 * SPAT_TS;
             const int32_t* pdelta = plen + SPAT_P;
@@ -1053,7 +1171,7 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
                        pdelta, c->cs_npat, x, d_y_owned, (const int32_t*)c->d_cs_prows.p, nbp, (int32_t)c->cs_nnz, ovh, epi)
 #define SPMV_PAT(NT_, NU_)                                 \
     if (c->cs_pat_len <= 8) SPMV_PAT1(NT_, NU_, 8);         \
-    else SPMV_PAT1(NT_, NU_, SPAT_L)
+    else SPMV_PAT1(NT_, NU_, SPAT_LK)
 #define SPMV_PAT_NU(NT_)                 \
     switch (nu) {                        \
         case 2: SPMV_PAT(NT_, 2); break; \

@@ -430,7 +430,9 @@ int fedd_spmv_patterns(fedd_ctx* ctx, int64_t* n_patterns, int64_t* n_rows_expli
  * grid the assembled matrix has a few thousand distinct rows among millions.  The SpMV then reads a 4-byte (class, pattern) word per row and
  * the row's values from a table of at most 16384 classes instead of 8 bytes per entry; same products, same order: y identical
  * bit for bit.  n_classes = 0: not in use (fewer than 90 % of the rows repeat); n_rows_in_classes: rows served from the table;
- * nnz_streamed_rest: stream entries of the other rows.  Outputs may be NULL. */
+ * nnz_streamed_rest: stream entries of the other rows.  Outputs may be NULL.  Option "spmv_keep_dictionary" 1: the pattern
+ * dictionary and the classes of the previous matrix are kept while the new matrix still matches them bit for bit (one
+ * verifying pass instead of the build -- for drivers that reassemble the same operator); default 0: built for every matrix. */
 int fedd_spmv_classes(fedd_ctx* ctx, int64_t* n_classes, int64_t* n_rows_in_classes, int64_t* nnz_streamed_rest);
 /* bytes per column index of the solver's SpMV stream: 0 = column patterns in use (above), 2 = 16-bit offsets from a base per
  * window of the stream (option "spmv_col16", default 1; 10 instead of 12 bytes per entry) in every window whose columns span less
