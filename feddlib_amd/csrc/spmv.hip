@@ -764,32 +764,42 @@ __global__ __launch_bounds__(256) void k_cls_rows(const int32_t* __restrict__ ro
                                                   const int32_t* __restrict__ cls_of_slot, const double* __restrict__ cls_val,
                                                   const uint16_t* __restrict__ cls_pat, uint32_t* __restrict__ cls,
                                                   int32_t* __restrict__ counters, int cl) {
-    const int32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    // (grid-stride over the rows, the two counts summed per lane, per wave, per workgroup: ONE atomic pair per workgroup -- an
+    // atomic per wave on one address was 14 of the kernel's 14.1 ms at 214^3 cells)
+    __shared__ int32_t s_in[4], s_rest[4];
     const int e = threadIdx.x & 7;
-    bool cand = false;
-    int32_t len = 0, id = -1;
-    long long diff = 0;
-    uint16_t pid = SPAT_EXPL;
-    if (r < n) {
-        const int32_t b = rowptr[r];
-        len = rowptr[r + 1] - b;
+    int my_in = 0, my_rest = 0;
+    for (int64_t r64 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; r64 < n; r64 += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+        const int32_t r = (int32_t)r64;
+        const int32_t b = rowptr[r], len = rowptr[r + 1] - b;
         const int32_t sl = slot_of[r];
-        id = sl >= 0 ? cls_of_slot[sl] : -1;
-        pid = pat[r];
-        cand = id >= 0 && len <= cl && cls_pat[id] == pid;
+        const int32_t id = sl >= 0 ? cls_of_slot[sl] : -1;
+        const uint16_t pid = pat[r];
+        const bool cand = id >= 0 && len <= cl && cls_pat[id] == pid;
+        long long diff = 0;
         if (cand)
             for (int j = e; j < len; j += 8) diff |= __double_as_longlong(val[b + j]) ^ __double_as_longlong(cls_val[(size_t)id * cl + j]);
+        for (int off = 4; off > 0; off >>= 1) diff |= __shfl_xor(diff, off, 8);
+        const bool in = cand && diff == 0;      // (the padding of a table entry is zero by construction: k_cls_fill)
+        if (e == 0) {
+            cls[r] = in ? ((uint32_t)id << 8) | (uint32_t)pid : CLS_NONE;
+            my_in += in ? 1 : 0;
+            my_rest += in ? 0 : len;
+        }
     }
-    for (int off = 4; off > 0; off >>= 1) diff |= __shfl_xor(diff, off, 8);
-    const bool writer = r < n && e == 0;
-    const bool in = cand && diff == 0;      // (the padding of a table entry is zero by construction: k_cls_fill)
-    if (writer) cls[r] = in ? ((uint32_t)id << 8) | (uint32_t)pid : CLS_NONE;
-    const uint64_t m = __ballot(writer && in);
-    int rest = (writer && !in) ? len : 0;
-    for (int off = 32; off > 0; off >>= 1) rest += __shfl_xor(rest, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        my_in += __shfl_xor(my_in, off, 64);
+        my_rest += __shfl_xor(my_rest, off, 64);
+    }
     if ((threadIdx.x & 63) == 0) {
-        if (m) atomicAdd(counters, (int32_t)__builtin_popcountll(m));
-        if (rest) atomicAdd(counters + 1, rest);
+        s_in[threadIdx.x >> 6] = my_in;
+        s_rest[threadIdx.x >> 6] = my_rest;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int a = s_in[0] + s_in[1] + s_in[2] + s_in[3], bq = s_rest[0] + s_rest[1] + s_rest[2] + s_rest[3];
+        if (a) atomicAdd(counters, a);
+        if (bq) atomicAdd(counters + 1, bq);
     }
 }
 
@@ -797,34 +807,44 @@ __global__ __launch_bounds__(256) void k_cls_rows(const int32_t* __restrict__ ro
 // length and every value bit for bit.  counters: [0] rows that match, [1] previously classed rows that do not (any: rebuild),
 // [2] stream entries of the rows without a class.  (A driver that reassembles the same operator -- a time loop, the bench --
 // pays one pass over the stream instead of the build: 2.9 -> 0.3 ms at 214^3 cells.)
-__global__ void k_cls_verify(const int32_t* __restrict__ rowptr, const double* __restrict__ val, const uint16_t* __restrict__ pat,
-                             int32_t n, const uint32_t* __restrict__ cls, const double* __restrict__ cls_val,
-                             const uint16_t* __restrict__ cls_pat, int32_t n_cls, int32_t* __restrict__ counters, int cl) {
-    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    bool ok = false, bad = false;
-    int32_t len = 0;
-    if (r < n) {
-        const int32_t b = rowptr[r];
-        len = rowptr[r + 1] - b;
+__global__ __launch_bounds__(256) void k_cls_verify(const int32_t* __restrict__ rowptr, const double* __restrict__ val,
+                                                    const uint16_t* __restrict__ pat, int32_t n, const uint32_t* __restrict__ cls,
+                                                    const double* __restrict__ cls_val, const uint16_t* __restrict__ cls_pat,
+                                                    int32_t n_cls, int32_t* __restrict__ counters, int cl) {
+    __shared__ int32_t s_c[3][4];
+    const int e = threadIdx.x & 7;
+    int my_ok = 0, my_bad = 0, my_rest = 0;
+    for (int64_t r64 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; r64 < n; r64 += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+        const int32_t r = (int32_t)r64;
+        const int32_t b = rowptr[r], len = rowptr[r + 1] - b;
         const uint32_t w = cls[r];
-        if (w != CLS_NONE) {
-            const int32_t id = (int32_t)(w >> 8);
-            ok = id < n_cls && len <= cl && (uint32_t)pat[r] == (w & 255u) && cls_pat[id] == pat[r];
-            if (ok) {
-                long long diff = 0;
-                for (int j = 0; j < len; ++j) diff |= __double_as_longlong(val[b + j]) ^ __double_as_longlong(cls_val[(size_t)id * cl + j]);
-                ok = diff == 0;
-            }
-            bad = !ok;
+        const int32_t id = (int32_t)(w >> 8);
+        bool ok = w != CLS_NONE && id < n_cls && len <= cl && (uint32_t)pat[r] == (w & 255u) && cls_pat[id] == pat[r];
+        long long diff = 0;
+        if (ok)
+            for (int j = e; j < len; j += 8) diff |= __double_as_longlong(val[b + j]) ^ __double_as_longlong(cls_val[(size_t)id * cl + j]);
+        for (int off = 4; off > 0; off >>= 1) diff |= __shfl_xor(diff, off, 8);
+        ok = ok && diff == 0;
+        if (e == 0) {
+            my_ok += ok ? 1 : 0;
+            my_bad += (w != CLS_NONE && !ok) ? 1 : 0;
+            my_rest += ok ? 0 : len;
         }
     }
-    const uint64_t m = __ballot(ok), mb = __ballot(bad);
-    int rest = (r < n && !ok) ? len : 0;
-    for (int off = 32; off > 0; off >>= 1) rest += __shfl_xor(rest, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        my_ok += __shfl_xor(my_ok, off, 64);
+        my_bad += __shfl_xor(my_bad, off, 64);
+        my_rest += __shfl_xor(my_rest, off, 64);
+    }
     if ((threadIdx.x & 63) == 0) {
-        if (m) atomicAdd(counters, (int32_t)__builtin_popcountll(m));
-        if (mb) atomicAdd(counters + 1, (int32_t)__builtin_popcountll(mb));
-        if (rest) atomicAdd(counters + 2, rest);
+        s_c[0][threadIdx.x >> 6] = my_ok;
+        s_c[1][threadIdx.x >> 6] = my_bad;
+        s_c[2][threadIdx.x >> 6] = my_rest;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int v = s_c[threadIdx.x][0] + s_c[threadIdx.x][1] + s_c[threadIdx.x][2] + s_c[threadIdx.x][3];
+        if (v) atomicAdd(counters + threadIdx.x, v);
     }
 }
 
@@ -1045,7 +1065,7 @@ static int spmv_compact_build(fedd_ctx* c) {
             bool kept = false;
             if (c->spmv_keep_dict && c->cs_cls_tab_n == n && c->cs_cls_tab_len == cl && c->cs_cls_tab_ncls > 0 && c->cs_cls_tab_rows > 0) {
                 FEDD_HIP(hipMemsetAsync(ccnt, 0, 8 * sizeof(int32_t), c->stream));
-                hipLaunchKernelGGL(k_cls_verify, gr, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p,
+                hipLaunchKernelGGL(k_cls_verify, dim3(std::min<unsigned>(gr8.x, 8192u)), b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p,
                                    (const uint16_t*)c->d_cs_pat.p, n, (const uint32_t*)c->d_cs_cls.p, (const double*)c->d_cs_clsval.p,
                                    (const uint16_t*)c->d_cs_clspat.p, c->cs_cls_tab_ncls, ccnt, cl);
                 int32_t hv[3] = {0, 0, 0};
@@ -1069,7 +1089,7 @@ static int spmv_compact_build(fedd_ctx* c) {
             hipLaunchKernelGGL(k_cls_fill, dim3(CLS_TS / 256), b256, 0, c->stream, (const int32_t*)cof, (const int32_t*)cmin,
                                (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p, (const uint16_t*)c->d_cs_pat.p,
                                c->d_cs_clsval.p, c->d_cs_clspat.p, cl);
-            hipLaunchKernelGGL(k_cls_rows, gr8, b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p,
+            hipLaunchKernelGGL(k_cls_rows, dim3(std::min<unsigned>(gr8.x, 8192u)), b256, 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const double*)c->d_cs_val.p,
                                (const uint16_t*)c->d_cs_pat.p, n, (const int32_t*)cslot, (const int32_t*)cof,
                                (const double*)c->d_cs_clsval.p, (const uint16_t*)c->d_cs_clspat.p, c->d_cs_cls.p, ccnt + 2, cl);
             int32_t hc[4] = {0, 0, 0, 0};

@@ -456,3 +456,36 @@ def test_spmv_row_classes_stay_off_where_rows_do_not_repeat(fedd_lib, ctx):
     finally:
         ctx.set_option("spmv_pattern", 1)
         ctx.set_option("spmv_exact_public", 1)
+
+
+def test_spmv_dictionary_is_kept_only_while_the_matrix_matches_it(fedd_lib, ctx):
+    """option spmv_keep_dictionary: a reassembled matrix that matches the previous pattern dictionary and row classes bit for bit
+    keeps them (one verifying pass instead of the build); a matrix with other values gets new ones.  The products are the same
+    bits either way."""
+    m = fedd_lib.structured_mesh(3, 1, 19)
+    ctx.mesh_set_dict(m)
+    x = np.random.default_rng(21).standard_normal(20 ** 3)
+    ctx.set_option("spmv_exact_public", 0)
+    ctx.set_option("spmv_pattern", 2)
+    try:
+        ys = {}
+        for keep in (0, 1):
+            ctx.set_option("spmv_keep_dictionary", keep)
+            for rep in range(3):        # (keep: build, verify, verify)
+                ctx.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+                ctx.assemble(fedd_lib.FORM_LAPLACE)
+                ctx.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+                ys[(keep, rep)] = ctx.spmv(x)
+                info = ctx.spmv_info()
+                assert info["row_classes"] >= 1 and info["rows_in_classes"] >= 0.9 * x.shape[0]
+            # other values (an exact scaling): the kept classes no longer match, new ones are built
+            ctx.matrix_scale(-1, 2.0)
+            ys[(keep, "scaled")] = ctx.spmv(x)
+            assert ctx.spmv_info()["row_classes"] >= 1
+        y0 = ys[(0, 0)]
+        for key, y in ys.items():
+            assert np.array_equal(y, 2.0 * y0 if key[1] == "scaled" else y0), key
+    finally:
+        ctx.set_option("spmv_keep_dictionary", 0)
+        ctx.set_option("spmv_pattern", 1)
+        ctx.set_option("spmv_exact_public", 1)
