@@ -970,7 +970,7 @@ struct TileHdr {
 
 constexpr int TL_BLOBMAX = 4096;  // words of the largest blob this path takes (the next tile's blob waits in registers: BLOBMAX / BS per lane)
 
-template <int DIM, int FORM, int BS>
+template <int DIM, int FORM, int BS, bool ZE = false /* doSetZeros thresholding compiled in (asm_zero_eps > 0) */>
 __global__ __launch_bounds__(BS) void k_assemble_tiles(AsmArgs a, const TileHdr* __restrict__ hdr, const uint32_t* __restrict__ blob,
                                                         int32_t ntile, int tiles_per_wg, int block_mode, int lds_el, int lds_blob, int dbg) {
     constexpr int NEN = DIM + 1, TL_PFW = (TL_BLOBMAX + BS - 1) / BS;
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(BS) void k_assemble_tiles(AsmArgs a, const TileHdr*
                         double v = 0.0;
 #pragma unroll
                         for (int d = 0; d < DIM; ++d) v += wg[d] * G[j][d];
-                        pk[pix(e, i * NEN + j)] = zero_small(a, v * absdet);
+                        pk[pix(e, i * NEN + j)] = ZE ? zero_small(a, v * absdet) : v * absdet;
                     }
                 }
             } else {
@@ -1879,7 +1879,9 @@ int launch_tiles(fedd_ctx* c, const AsmArgs& a, int ntab) {
     // Laplace: 448 lanes, the 324 elements and the 405 slots of a 3^3-node tile of the Kuhn cube each take one pass (4.27 -> 4.12 ms
     // at cfg 3); elasticity (9 items per slot: several passes anyway) is faster with 256 (94^3 cells: 2.86 against 3.34 ms)
     constexpr int BS = FORM == F_LAPLACE ? 448 : 256;
-    auto kern = k_assemble_tiles<DIM, FORM, BS>;
+    // (the thresholded variant is its own instantiation: two compares and a select per element-matrix entry cost the
+    // element phase 10 % -- 4.1 -> 4.5 ms at cfg 3 -- when they were compiled into the only one)
+    auto kern = (FORM == F_LAPLACE && a.zero_eps > 0.0) ? k_assemble_tiles<DIM, FORM, BS, true> : k_assemble_tiles<DIM, FORM, BS, false>;
     if (lds > 64 * 1024) FEDD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent workgroups: as many as fit the GPU at once (256 CUs x what the LDS allows), each a contiguous run of tiles
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
