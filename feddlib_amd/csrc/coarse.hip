@@ -18,7 +18,6 @@
 // (v_mfma_f64_16x16x4_f64) -- the one genuinely dense contraction of the solver.
 // Apply: cell-wise restriction (fixed summation order), dense K0^-1 r0, prolongation.
 #include "fedd_internal.hpp"
-#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -1085,20 +1084,16 @@ __global__ void k_prolong_add(CoarseGeom cg, int dofs, int64_t n_rows, const dou
 
 
 // owned nodes grouped by cell, in node order within a cell: a stable radix sort of (cell, node) over the bits a cell id takes
-// (rocPRIM through hipCUB; the bit-by-bit split it replaces took three launches per bit, 2.5 ms for 9.9 M nodes and 1728 cells)
+// (the in-tree radix sort of scan.hip, 8 bits per pass; rounds 2-3: rocPRIM through hipCUB; round 1: a bit-by-bit split, three
+// launches per bit, 2.5 ms for 9.9 M nodes and 1728 cells)
 static int sort_nodes_by_cell(fedd_ctx* c, int32_t n_own, int64_t ncell, int* cur_out) {
     int bits = 0;
     while (((int64_t)1 << bits) < ncell) ++bits;
     *cur_out = 0;
     if (bits == 0 || n_own == 0) return 0;
-    size_t tmp_bytes = 0;
-    FEDD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const int32_t*)c->d_co_key[0].p, c->d_co_key[1].p,
-                                                (const int32_t*)c->d_co_val[0].p, c->d_co_val[1].p, (int)n_own, 0, bits, c->stream));
-    FEDD_TRY(c->d_dense_ws.ensure((tmp_bytes + sizeof(double) - 1) / sizeof(double)));
-    FEDD_HIP(hipcub::DeviceRadixSort::SortPairs((void*)c->d_dense_ws.p, tmp_bytes, (const int32_t*)c->d_co_key[0].p, c->d_co_key[1].p,
-                                                (const int32_t*)c->d_co_val[0].p, c->d_co_val[1].p, (int)n_own, 0, bits, c->stream));
-    *cur_out = 1;
-    return 0;
+    int32_t* keys[2] = {c->d_co_key[0].p, c->d_co_key[1].p};
+    int32_t* vals[2] = {c->d_co_val[0].p, c->d_co_val[1].p};
+    return radix_sort_pairs_i32(c, keys, vals, n_own, bits, cur_out);
 }
 
 // ---- GDSW: setup and application (kernels and definitions: "GDSW coarse space" above) ----

@@ -334,6 +334,7 @@ struct fedd_ctx {
     // ---- generic scratch ----
     fedd::DevBuf<int32_t> d_itmp0, d_itmp1, d_itmp2;
     fedd::DevBuf<int64_t> d_scan[3];            // block sums of the device scan, one per level
+    fedd::DevBuf<int32_t> d_rs_hist;            // radix sort: digit histograms [256][tiles]
     fedd::DevBuf<double> d_dtmp0;
     fedd::DevBuf<int32_t> d_flags;              // [16] device flags: 0 max scratch, 1 bad pivot, 2 DGKS gate, 3-5 coarse setup, 8-11 Schwarz setup counters, 12 s-step block length
 
@@ -407,6 +408,9 @@ int timing_flush(fedd_ctx* c);
 int exclusive_scan_i32(fedd_ctx* c, const int32_t* d_in, int32_t* d_out, int64_t n, int64_t* total_out);
 int exclusive_scan_i64(fedd_ctx* c, const int64_t* d_in, int64_t* d_out, int64_t n, int64_t* total_out);
 int reduce_max_i32(fedd_ctx* c, const int32_t* d_in, int64_t n, int32_t* out);
+// stable radix sort of (key, value) pairs on bits [0, bits) of the non-negative keys; keys[0] / vals[0] = input, the passes
+// ping-pong between the two buffers, *cur_out = the one that holds the result
+int radix_sort_pairs_i32(fedd_ctx* c, int32_t* keys[2], int32_t* vals[2], int32_t n, int bits, int* cur_out);
 
 // symbolic.hip
 int build_adjacency(fedd_ctx* c);

@@ -107,6 +107,96 @@ int exclusive_scan_i64(fedd_ctx* c, const int64_t* d_in, int64_t* d_out, int64_t
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stable LSD radix sort of (key, value) pairs of int32 (non-negative keys), 8 bits per pass, hand-written (rounds 1-3 called
+// rocPRIM through hipCUB here: the one non-native dependency of the path).  A pass: k_rs_count (a 256-bin histogram per
+// workgroup tile of RS_TILE items, LDS atomics) -> device scan of the bin-major table [bin][tile] -> k_rs_scatter (the tile
+// again, 256 items at a time in order; within a round the lanes of a wave that carry the same digit find each other with eight
+// ballots, the lowest of them takes the digit's running offset from LDS, and the four waves go one after the other: ranks
+// follow the input order, so the sort is stable).  Used by the Schwarz setup (subdomains by representative) and the coarse
+// levels (nodes by lattice cell).
+// ------------------------------------------------------------------------------------------------
+constexpr int RS_ITEMS = 8, RS_TILE = 256 * RS_ITEMS;
+
+__global__ __launch_bounds__(256) void k_rs_count(const int32_t* __restrict__ keys, int32_t n, int shift, int32_t ntile,
+                                                  int32_t* __restrict__ hist /* [256][ntile] */) {
+    __shared__ int32_t h[256];
+    const int tid = threadIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int u = 0; u < RS_ITEMS; ++u) {
+        const int64_t i = base + u * 256 + tid;
+        if (i < n) atomicAdd(&h[((uint32_t)keys[i] >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    hist[(int64_t)tid * ntile + blockIdx.x] = h[tid];
+}
+
+__global__ __launch_bounds__(256) void k_rs_scatter(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals, int32_t n,
+                                                    int shift, int32_t ntile, const int32_t* __restrict__ offs /* scanned hist */,
+                                                    int32_t* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+    __shared__ int32_t run[256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    run[tid] = offs[(int64_t)tid * ntile + blockIdx.x];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    for (int u = 0; u < RS_ITEMS; ++u) {
+        const int64_t i = base + u * 256 + tid;
+        const bool on = i < n;
+        const int32_t k = on ? keys[i] : 0, v = on ? vals[i] : 0;
+        const uint32_t d = ((uint32_t)k >> shift) & 255u;
+        // lanes of this wave with the same digit (and in range)
+        uint64_t same = __ballot(on);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const int rank = __builtin_popcountll(same & ((1ull << lane) - 1ull));
+        const int cnt = __builtin_popcountll(same);
+        const int leader = on ? __builtin_ctzll(same) : 0;
+        int32_t pos = 0;
+        for (int ww = 0; ww < 4; ++ww) {        // the waves in order: stable
+            if (w == ww && on) {
+                int32_t b0 = 0;
+                if (lane == leader) {
+                    b0 = run[d];
+                    run[d] = b0 + cnt;
+                }
+                pos = __shfl(b0, leader, 64) + rank;
+            }
+            __syncthreads();
+        }
+        if (on) {
+            keys_out[pos] = k;
+            vals_out[pos] = v;
+        }
+    }
+}
+
+// keys[0] / vals[0] hold the input; the passes ping-pong between buffers 0 and 1; *cur_out = the buffer that holds the result.
+// Bits [0, bits) of the keys take part.
+int radix_sort_pairs_i32(fedd_ctx* c, int32_t* keys[2], int32_t* vals[2], int32_t n, int bits, int* cur_out) {
+    *cur_out = 0;
+    if (n <= 1 || bits <= 0) return 0;
+    const int32_t ntile = (int32_t)(((int64_t)n + RS_TILE - 1) / RS_TILE);
+    FEDD_TRY(c->d_rs_hist.ensure((size_t)256 * ntile + 2));
+    int cur = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(k_rs_count, dim3((unsigned)ntile), dim3(256), 0, c->stream, (const int32_t*)keys[cur], n, shift, ntile,
+                           c->d_rs_hist.p);
+        FEDD_TRY(exclusive_scan_i32(c, c->d_rs_hist.p, c->d_rs_hist.p, (int64_t)256 * ntile, nullptr));
+        hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)ntile), dim3(256), 0, c->stream, (const int32_t*)keys[cur],
+                           (const int32_t*)vals[cur], n, shift, ntile, (const int32_t*)c->d_rs_hist.p, keys[cur ^ 1], vals[cur ^ 1]);
+        cur ^= 1;
+    }
+    FEDD_HIP(hipGetLastError());
+    *cur_out = cur;
+    return 0;
+}
+
 int reduce_max_i32(fedd_ctx* c, const int32_t* d_in, int64_t n, int32_t* out) {
     FEDD_TRY(c->d_flags.ensure(16));
     int32_t* d = c->d_flags.p;

@@ -14,7 +14,6 @@
 // Apply = one workgroup per subdomain streaming its slab of A_i^-1 once from HBM (HBM-bound).
 // With fedd_schwarz_setup(two_level = 1) the coarse level of coarse.hip is added to the result.
 #include "fedd_internal.hpp"
-#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -1688,12 +1687,17 @@ int schwarz_setup(fedd_ctx* c) {
             hipLaunchKernelGGL(k_iota, gs, blk, 0, c->stream, iota, (int32_t)nsub);
             hipLaunchKernelGGL(k_order_key, gs, blk, 0, c->stream, (const int32_t*)c->d_sub_n.p, (const int32_t*)c->d_sub_dofs.p, rep,
                                (int32_t)nsub, (int32_t)n_rows, split ? 1 : 0, keys_in, n_int);
-            size_t tmp_bytes = 0;
-            FEDD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const int32_t*)keys_in, keys_out, (const int32_t*)iota, ord,
-                                                        (int)nsub, 0, 32, c->stream));
-            FEDD_TRY(c->d_dense_ws.ensure((tmp_bytes + sizeof(double) - 1) / sizeof(double)));
-            FEDD_HIP(hipcub::DeviceRadixSort::SortPairs((void*)c->d_dense_ws.p, tmp_bytes, (const int32_t*)keys_in, keys_out,
-                                                        (const int32_t*)iota, ord, (int)nsub, 0, 32, c->stream));
+            {
+                // stable sort by key (scan.hip; keys: representative [+ 2^30 for the subdomains with ghost dofs]); the result goes to `ord`
+                int bits = 0;
+                while (((int64_t)1 << bits) <= (int64_t)nsub) ++bits;
+                if (split) bits = 31;
+                int32_t* kk[2] = {keys_in, keys_out};
+                int32_t* vv[2] = {iota, ord};
+                int cur = 0;
+                FEDD_TRY(radix_sort_pairs_i32(c, kk, vv, (int32_t)nsub, bits, &cur));
+                if (cur == 0) FEDD_HIP(hipMemcpyAsync(ord, iota, (size_t)nsub * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+            }
             // records (subdomain, representative, columns, owned rows) in that order: one 16-byte load per place
             hipLaunchKernelGGL(k_pack_order, dim3((unsigned)(((int64_t)nsub * 16 + 255) / 256)), blk, 0, c->stream, (const int32_t*)ord, rep,
                                (const int32_t*)c->d_sub_n.p, (const int32_t*)c->d_sub_nown.p, (const int32_t*)c->d_sub_dofs.p,

@@ -13,7 +13,9 @@ def load(d, name):
     return acc
 
 fe = load(sys.argv[1], "FETCH_SIZE"); wr = load(sys.argv[2], "WRITE_SIZE")
-classes = {"spmv": ("k_spmv_win<", "k_spmv_pat<"), "schwarz_apply": "k_apply", "assemble": ("k_assemble_pairs<", "k_assemble_tiles<"), "multidot": "k_multidot(",
+# (spmv: the solver's kernel -- k_spmv_cls on row classes since round 4; k_spmv_win<true, 8, false> is then the parity-CSR
+#  product of the acceptance residual and is listed on its own)
+classes = {"spmv": ("k_spmv_cls<", "k_spmv_pat<"), "spmv_parity_csr": "k_spmv_win<", "schwarz_apply": "k_apply", "assemble": ("k_assemble_pairs<", "k_assemble_tiles<"), "multidot": "k_multidot(",
            "multiaxpy": "k_multiaxpy(", "gs_dot": ("k_multidot2", "k_blockdot<"), "gs_update": ("k_axpy2", "k_blockaxpy<"), "invert": "k_invert_reg<7"}
 # (gs_dot / gs_update: the basis grows from launch to launch; the figure is the mean over all launches of the solve, like
 # bench.py's byte model.  schwarz_apply with shared inverses is a gather kernel: the doubling of FETCH_SIZE is calibrated
