@@ -103,6 +103,28 @@ extern "C" int fedd_ctx_create(fedd_ctx** out, int device, const void* nccl_uniq
         }
     }
     *out = c;
+    // FEDD_OPTIONS=key=value,...: fedd_set_option calls applied to every new context (the solver defaults stay
+    // switchable from the environment of a multi-GPU run -- e.g. FEDD_OPTIONS=gmres_kind=0,halo_overlap=1 -- without a rebuild)
+    if (const char* env = getenv("FEDD_OPTIONS")) {
+        std::string all(env);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string kv = all.substr(pos, end - pos);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos && eq > 0) {
+                char* endp = nullptr;
+                const double v = strtod(kv.c_str() + eq + 1, &endp);
+                if (endp != kv.c_str() + eq + 1 && fedd_set_option(c, kv.substr(0, eq).c_str(), v) != 0) {
+                    fedd_ctx_destroy(c);
+                    *out = nullptr;
+                    return 1;       // (fedd_set_option set the message: an unknown key is an error, not ignored)
+                }
+            }
+            pos = end + 1;
+        }
+    }
     return 0;
 }
 
@@ -839,6 +861,9 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
         c->gmres_spec = (int)value;
     } else if (k == "gmres_tol_blocks") {
         c->gmres_tol_blocks = (int)value;
+    } else if (k == "gmres_dot_gy") {
+        FEDD_CHECK(value >= 0 && value <= 8, "fedd_set_option: gmres_dot_gy %g", value);
+        c->gmres_dot_gy = (int)value;
     } else if (k == "gmres_dotv") {
         c->gmres_dotv = (int)value;
     } else if (k == "gmres_newton") {

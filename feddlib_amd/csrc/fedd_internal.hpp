@@ -250,6 +250,7 @@ struct fedd_ctx {
     int gmres_kind = 2;                         // Gram-Schmidt: 0 = delayed second pass (DCGS2), 1 = two passes (CGS2), 2 = s-step blocks (BCGS-PIP2)
     int gmres_s = 0;                            // s-step GMRES: Krylov vectors per block (1 ... 16; 0 = 16 from 1.2 M rows per rank, else 8)
     int gmres_tol_blocks = 1;                   // ... tolerances below 1e-9 / 1e-11 take blocks of at most 5 / 3 vectors (0: no cap)
+    int gmres_dot_gy = 0;                       // ... column groups in flight per row block of the block dot kernel (0 = by vector length) (A/B)
     int gmres_dotv = 0;                         // ... launch shape of the block dot kernel (A/B)
     int gmres_s_used = 0;                       // ... the block length of the last solve
     int gmres_spec = 0;                         // ... operator applications of the next block issued before the host reads a block's outcome (A/B switch for multi-GPU runs)

@@ -1531,7 +1531,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     } ev_guard{ev};
     // column groups in flight per row block of the dot kernel: one when the vectors are long (every workgroup then
     // reads its rows of W once), more to fill the GPU when they are short
-    const int gy_dot = (int)std::max<int64_t>(1, std::min<int64_t>(8, (2048 + nblkd - 1) / nblkd));
+    const int gy_dot = c->gmres_dot_gy > 0 ? c->gmres_dot_gy : (int)std::max<int64_t>(1, std::min<int64_t>(8, (2048 + nblkd - 1) / nblkd));
     double* hout = c->h_pinned + 16;                                  // host mirror of the block result
     double* hout_dev = c->h_pinned_dev ? c->h_pinned_dev + 16 : nullptr;
 

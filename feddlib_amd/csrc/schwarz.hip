@@ -59,6 +59,21 @@ __global__ void k_minmax(const double* __restrict__ xyz, int32_t n, int dim, dou
         }
 }
 
+// consecutive lanes of a wave that carry the same key form a run (nodes are numbered along x: four to six in a row share a
+// box); one atomic per run instead of one per lane.  Returns the lane that starts this lane's run and the run's length.
+__device__ __forceinline__ void wave_run(int32_t key, bool valid, int& start_lane, int& run_len) {
+    const int lane = threadIdx.x & 63;
+    const int32_t prev = __shfl_up(key, 1, 64);
+    const bool pvalid = __shfl_up(valid ? 1 : 0, 1, 64) != 0;
+    const uint64_t starts = __ballot(valid && (lane == 0 || !pvalid || key != prev));
+    const uint64_t vmask = __ballot(valid);
+    const uint64_t upto = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    start_lane = upto ? 63 - __builtin_clzll(upto) : lane;
+    // the run ends before the next start or the first invalid lane after start_lane
+    const uint64_t stop = (starts | ~vmask) & ((start_lane == 63) ? 0ull : (~0ull << (start_lane + 1)));
+    run_len = stop ? __builtin_ctzll(stop) - start_lane : 64 - start_lane;
+}
+
 // box of every owned DOF = box of the node that carries it (dof / dofs, or the dof -> node map of a
 // merged block system)
 // n dofs get a box, the first n_count of them (the owned ones) are counted: a box exists where it holds an
@@ -66,8 +81,8 @@ __global__ void k_minmax(const double* __restrict__ xyz, int32_t n, int dim, dou
 __global__ void k_bin_id(const double* __restrict__ xyz, int32_t n, int32_t n_count, int dofs,
                          const int32_t* __restrict__ dof_node, BinGeom gm, int32_t* __restrict__ raw, int32_t* cnt) {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int32_t i = dof_node ? dof_node[r] : r / dofs;
+    const bool in = r < n;
+    const int32_t i = in ? (dof_node ? dof_node[r] : r / dofs) : 0;
     int32_t b = 0, mul = 1;
     for (int d = 0; d < gm.dim; ++d) {
         // a node on a box boundary (within 1e-9 box widths) goes to the box on the centre side: with the odd
@@ -81,8 +96,11 @@ __global__ void k_bin_id(const double* __restrict__ xyz, int32_t n, int32_t n_co
         b += mul * ix;
         mul *= gm.g[d];
     }
-    raw[r] = b;
-    if (r < n_count) atomicAdd(&cnt[b], 1);
+    if (in) raw[r] = b;
+    // (one atomic per run of equal boxes among consecutive lanes)
+    int sl, len;
+    wave_run(b, r < n_count, sl, len);
+    if (r < n_count && (int)(threadIdx.x & 63) == sl) atomicAdd(&cnt[b], len);
 }
 
 // row-ghost dofs r in [n0, n1) whose box exists on this rank: count per box / fill the per-box lists
@@ -117,10 +135,17 @@ __global__ void k_compact_counts(const int32_t* __restrict__ cnt, const int32_t*
 __global__ void k_fill_bins(const int32_t* __restrict__ raw, const int32_t* __restrict__ cid, int32_t n,
                             int32_t* cursor, int32_t* __restrict__ node_bin, int32_t* __restrict__ bin_nodes) {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t c = cid[raw[i]];
-    node_bin[i] = c;
-    bin_nodes[atomicAdd(&cursor[c], 1)] = i;
+    const bool in = i < n;
+    const int32_t c = in ? cid[raw[i]] : -1;
+    if (in) node_bin[i] = c;
+    // one atomic per run of equal boxes among consecutive lanes (k_sort_bins orders every box afterwards)
+    int sl, len;
+    wave_run(c, in, sl, len);
+    const int lane = threadIdx.x & 63;
+    int32_t base = 0;
+    if (in && lane == sl) base = atomicAdd(&cursor[c], len);
+    base = __shfl(base, sl, 64);
+    if (in) bin_nodes[base + (lane - sl)] = i;
 }
 
 // one wave per bin: rank sort through LDS (the dofs of a bin are distinct; a lane per bin sorting in global memory by

@@ -74,6 +74,7 @@ enum fedd_timer {
  * Xpetra::DefaultPlatform, feddlib/problems/tests/laplace/main.cpp:60-62)
  * nccl_unique_id: NULL for a single rank; else the 128-byte ncclUniqueId shared by all ranks.
  * ---------------------------------------------------------------------------------------------- */
+/* (the environment variable FEDD_OPTIONS=key=value,... is applied to every new context through fedd_set_option) */
 int  fedd_ctx_create(fedd_ctx** out, int device, const void* nccl_unique_id, int rank, int nranks);
 void fedd_ctx_destroy(fedd_ctx* ctx);
 const char* fedd_last_error(void);
