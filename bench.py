@@ -891,6 +891,10 @@ def main():
         except BaseException as e:      # (never let the A/B change the exit status of a finished measurement)
             sys.stderr.write("[bench ab] rank %d: %r\n" % (rank, e))
             sys.stderr.flush()
+            sys.stdout.flush()
+            # the other ranks may be waiting in a collective this rank will never join: leave without the orderly shutdown of the
+            # process group (which would wait for them); their own watchdogs end them
+            os._exit(0)
         wd.cancel()
     if N > 1:
         dist.destroy_process_group()

@@ -1531,7 +1531,10 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     } ev_guard{ev};
     // column groups in flight per row block of the dot kernel: one when the vectors are long (every workgroup then
     // reads its rows of W once), more to fill the GPU when they are short
-    const int gy_dot = c->gmres_dot_gy > 0 ? c->gmres_dot_gy : (int)std::max<int64_t>(1, std::min<int64_t>(8, (2048 + nblkd - 1) / nblkd));
+    // (round 4, measured at 145 iterations: 1.26 M rows 1 / 2 / 3 / 4 groups 14.60 / 14.74 / 14.99 / 15.10 ms per solve, 1.03 M rows
+    // 15.54 / 15.64 / 15.77 / 15.97, 275 k rows 9.24 / 9.32 / 9.29 / 9.09; the old rule, 2048 workgroups in flight, took 2, 3 and 8)
+    const int gy_dot = c->gmres_dot_gy > 0 ? c->gmres_dot_gy
+                                           : (int)std::max<int64_t>(1, std::min<int64_t>(4, (1024 + nblkd / 2) / std::max(nblkd, 1)));
     double* hout = c->h_pinned + 16;                                  // host mirror of the block result
     double* hout_dev = c->h_pinned_dev ? c->h_pinned_dev + 16 : nullptr;
 

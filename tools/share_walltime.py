@@ -8,7 +8,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from feddlib_amd import capi  # noqa: E402
 
-M = 107
+M = int(os.environ.get("FEDD_SHARE_CELLS", "107"))
 m = capi.structured_mesh(3, 1, M)
 c = capi.Context(device=0)
 for kv in filter(None, (sys.argv[1] if len(sys.argv) > 1 else "").split(",")):
