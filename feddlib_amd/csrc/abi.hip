@@ -818,6 +818,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "spmv_exact_public") c->spmv_exact_public = (int)value;
     else if (k == "spmv_classes") { c->spmv_classes = (int)value; c->cs_valid = false; }
     else if (k == "spmv_keep_dictionary") c->spmv_keep_dict = (int)value;
+    else if (k == "spmv_classes_cover") { c->spmv_cls_cover = (int)value; c->cs_valid = false; }
     else if (k == "asm_tiles_host") { c->asm_tiles_host = (int)value; c->tl_state = 0; }
     else if (k == "asm_p2_elem") c->asm_p2_elem = (int)value;
     else if (k == "asm_zero_eps") {

@@ -225,7 +225,10 @@ struct fedd_ctx {
     int spmv_classes = 1;                       // option "spmv_classes": rows that repeat their column pattern AND their values bit for bit share a class (spmv.hip k_spmv_cls)
     int32_t cs_cls_tab_n = -1, cs_cls_tab_len = 0, cs_cls_tab_ncls = 0, cs_cls_tab_rows = 0;   // the class table and row words on the device: rows, stride, classes and classed rows of the build they come from (kept while the next matrix still matches them bit for bit)
     int32_t cs_pat_tab_n = -1, cs_pat_tab_npat = 0, cs_pat_tab_nexpl = 0, cs_pat_tab_len = 0;   // the column-pattern dictionary on the device: rows, patterns, explicit rows, longest pattern of the build it comes from (kept while the next matrix still matches it)
+    int spmv_cls_cover = 90;                    // option "spmv_classes_cover": the classes are used when they cover at least this percentage of the rows
     int spmv_keep_dict = 0;                     // option "spmv_keep_dictionary": 1 = the previous matrix' pattern dictionary and row classes are kept while the new stream matches them bit for bit (one verifying pass instead of the build: time loops that reassemble the same operator); 0 (default) = built per matrix
+    int32_t cs_nbnd = -1;                       // rows of the compacted stream that read ghost columns (-1: not listed)
+    fedd::DevBuf<int32_t> d_cs_bnd;             // flags / positions [n + 2] | the rows
     int cs_cls_len = 8;                         // stride of the class table (8, 16 or 48 values)
     int32_t cs_ncls = 0, cs_cls_rows = 0, cs_cls_rest = 0;   // classes in use (0: off), rows in a class, stream entries of the other rows
     fedd::DevBuf<uint32_t> d_cs_cls;            // per row: class << 8 | column pattern (0xffffffff: none)

@@ -927,6 +927,38 @@ __global__ __launch_bounds__(256) void k_spmv_cls(const int32_t* __restrict__ ro
     }
 }
 
+// Several ranks, option "halo_overlap": the rows that read ghost columns (a few node planes along the rank boundary) are
+// listed at setup (k_bnd_flag -> scan -> k_bnd_list); the SpMV on row classes then runs over ALL rows while the ghost import
+// travels on a second stream, and k_spmv_rows recomputes the listed rows when it has arrived -- the same entries in the same
+// order (the stream's values are the class's values bit for bit), so y is the y of the un-overlapped product.
+__global__ void k_bnd_flag(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int32_t n, int32_t* __restrict__ flag) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int f = 0;
+    for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) f |= col[p] >= n ? 1 : 0;
+    flag[r] = f;
+}
+__global__ void k_bnd_list(const int32_t* __restrict__ pos, int32_t n, int32_t* __restrict__ list) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && pos[r + 1] > pos[r]) list[pos[r]] = r;
+}
+__global__ void k_spmv_rows(const int32_t* __restrict__ list, int32_t nl, const int32_t* __restrict__ rowptr,
+                            const int32_t* __restrict__ col, const double* __restrict__ val, const double* __restrict__ x,
+                            double* __restrict__ y, SpmvEpi epi) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nl) return;
+    const int32_t r = list[i];
+    double s = 0.0;
+    {
+#pragma clang fp contract(off)
+        for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+            const double pr = val[p] * x[col[p]];
+            s = s + pr;
+        }
+    }
+    y[r] = epi_apply(epi, s, r);
+}
+
 // window -> first row table of the parity CSR (one-off per pattern)
 static int spmv_window_rows(fedd_ctx* c) {
     const int32_t nb = (int32_t)(c->nnz / SP_CHUNK + 1);
@@ -1097,7 +1129,7 @@ static int spmv_compact_build(fedd_ctx* c) {
             FEDD_HIP(hipStreamSynchronize(c->stream));
             if (getenv("FEDD_SPMV_DEBUG")) fprintf(stderr, "[spmv classes] n %d: slots claimed %d, classes %d, rows in classes %d, stream entries outside %d\n", n, hc[0], hc[1], hc[2], hc[3]);
             // worth it when nearly every row is in a class (the other rows go through a per-row loop)
-            if (hc[1] >= 1 && (int64_t)hc[2] * 10 >= (int64_t)n * 9) {
+            if (hc[1] >= 1 && (int64_t)hc[2] * 100 >= (int64_t)n * c->spmv_cls_cover) {
                 c->cs_ncls = std::min<int32_t>(hc[1], CLS_MAX);
                 c->cs_cls_rows = hc[2];
                 c->cs_cls_rest = hc[3];
@@ -1110,6 +1142,19 @@ static int spmv_compact_build(fedd_ctx* c) {
         }
         // (the dictionary was only tried for the classes' sake: a matrix in the Infinity Cache, or rows longer than k_spmv_pat unrolls)
         if ((!big || c->cs_pat_len > SPAT_LK) && c->cs_ncls == 0) c->cs_npat = 0;
+    }
+    // rows that read ghost columns (several ranks; for the overlapped import of the class SpMV, see k_bnd_flag)
+    c->cs_nbnd = -1;
+    if (c->cs_ncls > 0 && c->n_cols > c->n_rows && total > 0) {
+        FEDD_TRY(c->d_cs_bnd.ensure((size_t)2 * n + 4));
+        int32_t* bflag = c->d_cs_bnd.p;             // [n + 1] flags -> positions
+        int32_t* blist = bflag + n + 2;             // [<= n] the rows
+        const dim3 gq((unsigned)((n + 255) / 256));
+        hipLaunchKernelGGL(k_bnd_flag, gq, dim3(256), 0, c->stream, (const int32_t*)c->d_cs_rowptr.p, (const int32_t*)c->d_cs_col.p, n, bflag);
+        int64_t nb_rows = 0;
+        FEDD_TRY(exclusive_scan_i32(c, bflag, bflag, n, &nb_rows));
+        hipLaunchKernelGGL(k_bnd_list, gq, dim3(256), 0, c->stream, (const int32_t*)bflag, n, blist);
+        c->cs_nbnd = (int32_t)nb_rows;
     }
     // 16-bit columns for the per-entry window kernel (option "spmv_col16"; decided by the data: every window's column span)
     // (not for a stream that goes through the column patterns: k_spmv_pat reads no column of a row that has one)
@@ -1140,13 +1185,37 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
     const double* x = d_x_owned;
     const SpmvEpi epi{d_sub, theta};
     const bool compact = use_compact < 0 ? c->spmv_compact != 0 : use_compact != 0;
+    // (the solver's stream is built before the ghost import is issued: the overlapped import below needs its row list)
+    if (compact && c->spmv_kind == 0 && c->max_row_nnz <= 256 && c->nnz > 0 && !c->cs_valid) FEDD_TRY(spmv_compact_build(c));
+    bool overlapped = false;
     if (c->n_cols != c->n_rows || !c->halo.peers.empty()) {   // also a rank that only sends takes part
-        if (x_has_tail) {   // the caller's buffer takes the ghost values behind its owned entries
-            FEDD_TRY(halo_import(c, const_cast<double*>(d_x_owned), c->dofs));
-        } else {
+        double* xb = const_cast<double*>(d_x_owned);
+        if (!x_has_tail) {   // (else the caller's buffer takes the ghost values behind its owned entries)
             FEDD_HIP(hipMemcpyAsync(c->d_xcol.p, d_x_owned, (size_t)c->n_rows * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-            FEDD_TRY(halo_import(c, c->d_xcol.p, c->dofs));
+            xb = c->d_xcol.p;
             x = c->d_xcol.p;
+        }
+        // option "halo_overlap" with the class kernel (its build is current and lists the rows that read ghost columns): the
+        // import goes to a second stream, the product over all rows runs meanwhile, the listed rows are redone afterwards
+        const bool cls_path = compact && c->spmv_kind == 0 && c->max_row_nnz <= 256 && c->nnz > 0 && c->cs_valid && c->cs_npat > 0 &&
+                              c->spmv_pattern && c->cs_ncls > 0 && c->spmv_classes && c->cs_nnz > 0;
+        if (c->halo_overlap && c->nranks > 1 && cls_path && c->cs_nbnd >= 0) {
+            if (!c->stream2) {
+                FEDD_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+                FEDD_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                FEDD_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            hipStream_t main_stream = c->stream;
+            FEDD_HIP(hipEventRecord(c->ev_fork, main_stream));       // the owned part of x is complete here
+            FEDD_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            c->stream = c->stream2;
+            const int rc = halo_import(c, xb, c->dofs);
+            c->stream = main_stream;
+            if (rc) return rc;
+            FEDD_HIP(hipEventRecord(c->ev_join, c->stream2));
+            overlapped = true;
+        } else {
+            FEDD_TRY(halo_import(c, xb, c->dofs));
         }
     }
     const double avg = c->n_rows ? (double)c->nnz / (double)c->n_rows : 1.0;
@@ -1179,6 +1248,14 @@ int spmv_owned(fedd_ctx* c, const double* d_x_owned, double* d_y_owned, bool x_h
             else if (c->cs_cls_len <= 16) SPMV_CLS(4, 16);
             else SPMV_CLS(2, SPAT_L);
 #undef SPMV_CLS
+            if (overlapped) {   // the ghost values have arrived: the rows that read them, again
+                FEDD_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+                overlapped = false;
+                if (c->cs_nbnd > 0)
+                    hipLaunchKernelGGL(k_spmv_rows, dim3((unsigned)((c->cs_nbnd + 255) / 256)), dim3(256), 0, c->stream,
+                                       (const int32_t*)(c->d_cs_bnd.p + n + 2), c->cs_nbnd, (const int32_t*)c->d_cs_rowptr.p,
+                                       (const int32_t*)c->d_cs_col.p, (const double*)c->d_cs_val.p, x, d_y_owned, epi);
+            }
         } else if (c->cs_npat > 0 && c->spmv_pattern) {
             const int32_t* plen = c->d_cs_pati.p + n + 2 * SPAT_TS;
             const int32_t* pdelta = plen + SPAT_P;

@@ -393,7 +393,9 @@ int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_bloc
  * subdomain (the round-2 form; finds the same classes on the structured grids, four times slower);
  * "halo_overlap" 1 = several ranks, restricted combine: the subdomains that hold no dof of another rank are applied while the
  * ghost entries of r are imported on a second stream, the others after the import (same operator bit for bit); 0 (default) =
- * import, then all subdomains.  An A/B switch for multi-GPU runs: on one GPU there is nothing to hide;
+ * import, then all subdomains.  The SpMV on row classes does the same with its import of x: all rows while it travels, the
+ * rows that read ghost columns once more after it has arrived.  An A/B switch for multi-GPU runs: on one GPU there is
+ * nothing to hide;
  * "whole_boxes" 1 (default) = with row ghosts, a box that a rank boundary crosses is built whole (with its full
  * overlap) on every rank that owns a part of it wherever the stored rows reach, 0 = each rank takes its part;
  * "asm_zero_eps" eps > 0 = FE::doSetZeros(eps) (FE_def.hpp:74-79): element contributions of magnitude below eps are set to zero
@@ -433,7 +435,8 @@ int fedd_spmv_patterns(fedd_ctx* ctx, int64_t* n_patterns, int64_t* n_rows_expli
  * bit for bit.  n_classes = 0: not in use (fewer than 90 % of the rows repeat); n_rows_in_classes: rows served from the table;
  * nnz_streamed_rest: stream entries of the other rows.  Outputs may be NULL.  Option "spmv_keep_dictionary" 1: the pattern
  * dictionary and the classes of the previous matrix are kept while the new matrix still matches them bit for bit (one
- * verifying pass instead of the build -- for drivers that reassemble the same operator); default 0: built for every matrix. */
+ * verifying pass instead of the build -- for drivers that reassemble the same operator); default 0: built for every matrix.
+ * Option "spmv_classes_cover" (default 90): the percentage of the rows the classes must cover to be used. */
 int fedd_spmv_classes(fedd_ctx* ctx, int64_t* n_classes, int64_t* n_rows_in_classes, int64_t* nnz_streamed_rest);
 /* bytes per column index of the solver's SpMV stream: 0 = column patterns in use (above), 2 = 16-bit offsets from a base per
  * window of the stream (option "spmv_col16", default 1; 10 instead of 12 bytes per entry) in every window whose columns span less

@@ -668,16 +668,23 @@ def _thread_rank_overlap(capi, group, rank, dec, M, out, errs):
         c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
         rg = np.random.default_rng(5).standard_normal(m["n_global"])
         res = {}
-        for dedupe, kind in ((1, 4), (1, 0), (0, 0)):          # matrix-core kernel, flat kernel on shared slabs, flat kernel
+        for dedupe, kind in ((1, 4), (1, 0), (0, 0), (1, 40)):   # matrix-core kernel, flat kernel on shared slabs, flat kernel; the
+            # last: the matrix-core kernel with the SpMV on row classes (spmv_pattern 2 forces the dictionary on these small
+            # matrices) -- with halo_overlap the ghost import of the SpMV travels on the second stream as well and the rows
+            # that read ghost columns are redone when it has arrived (k_spmv_rows)
+            c.set_option("spmv_pattern", 2 if kind == 40 else 1)
+            c.set_option("spmv_classes_cover", 50 if kind == 40 else 90)     # (a fifth of these small blocks' rows read ghost columns)
             for ov in (0, 1):
                 c.set_option("schwarz_dedupe", dedupe)
-                c.set_option("apply_kind", kind)
+                c.set_option("apply_kind", kind % 10 if kind == 40 else kind)
                 c.set_option("halo_overlap", ov)
                 c.schwarz_set_target(27, 1.0)
                 c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
                 z = c.schwarz_apply(rg[m["gid_uni"]])
                 x, its, rel = c.gmres(None, rtol=1e-12, max_it=400, restart=100, use_prec=True)
                 res[(dedupe, kind, ov)] = (z, x, its)
+                if kind == 40:
+                    res[("spmv", ov)] = (c.spmv_info(), c.spmv(rg[m["gid_uni"]]))
         out[rank] = dict(gu=m["gid_uni"], res=res)
         c.close()
     except Exception as e:      # pragma: no cover
@@ -705,11 +712,14 @@ def test_interior_first_order_with_the_ghost_import_on_a_second_stream(fedd_lib)
     assert not errs, "\n".join(errs)
     for o in out:
         assert o is not None
-        for dedupe, kind in ((1, 4), (1, 0), (0, 0)):
+        for dedupe, kind in ((1, 4), (1, 0), (0, 0), (1, 40)):
             z0, x0, its0 = o["res"][(dedupe, kind, 0)]
             z1, x1, its1 = o["res"][(dedupe, kind, 1)]
             assert np.array_equal(z0, z1), (dedupe, kind)
             assert its0 == its1 and np.array_equal(x0, x1), (dedupe, kind)
+        # the class SpMV ran (every rank's rows repeat) and the solve on it is the solve on the per-entry stream, bit for bit
+        assert o["res"][("spmv", 1)][0]["row_classes"] >= 1
+        assert o["res"][(1, 40, 1)][2] == o["res"][(1, 4, 1)][2] and np.array_equal(o["res"][(1, 40, 1)][1], o["res"][(1, 4, 1)][1])
         # ... and the three kernels agree with each other to rounding
         za, zb = o["res"][(1, 4, 1)][0], o["res"][(0, 0, 1)][0]
         np.testing.assert_allclose(za, zb, rtol=0, atol=1e-11 * np.abs(zb).max())
