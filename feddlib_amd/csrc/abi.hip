@@ -833,6 +833,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "schwarz_fp_kind") { c->sw_fp_kind = (int)value; c->have_schwarz = false; }
     else if (k == "apply_span") c->apply_span = (int)value;
     else if (k == "gdsw_block") c->gdsw_block = value != 0.0;
+    else if (k == "gdsw_rotations") c->gdsw_rot = value != 0.0;
     else if (k == "multi_ch") c->multi_ch = (int)value;
     else if (k == "spmv_col16") { c->spmv_col16 = value != 0.0; c->cs_valid = false; }
     else if (k == "pat_hash") c->pat_hash = value != 0.0;

@@ -508,12 +508,143 @@ __global__ void k_gd_node_entity(CoarseGeom cg, const int32_t* __restrict__ conn
     val[i] = i;
 }
 
-// Phi <- Phi_Gamma (interface rows: 1 in the class of their own entity, component a; Dirichlet rows 0), interior
-// rows 0; imask = 1 on free interior dofs (the unknowns of the extension solves), 0 elsewhere
+// The coarse functions an interface node of entity e (class cls >= 0) takes part in: GDSW the functions of e itself; RGDSW,
+// option 1 (Dohrmann, Widlund 2017): those of every coarse node of C(e), the coarse nodes adjacent to e -- e_d odd stays, an
+// even e_d (direction with >= 2 cells) moves to e_d - 1 or e_d + 1 where that lies inside the lattice; all of them are
+// corners of the home cell -- each with the weight 1 / |C(e)|.  Returns their number; ai = active class index, E = coarse id,
+// ev = entity coordinates of the function's own entity (the centre of its rotations).
 template <int DIM>
-__global__ void k_gd_phi_init(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int64_t n_rows, int64_t ldp,
-                              const double* __restrict__ mask, double* __restrict__ phiT, double* __restrict__ imask) {
+__device__ __forceinline__ int gd_targets(const CoarseGeom& cg, const GdAct& act, const int e[3], int cls, int ai[8], int32_t E[8],
+                                          int ev[8][3]) {
     constexpr int NCLS = GdswCfg<DIM>::NCLS;
+    if (!cg.reduced) {
+        if (act.idx[cls] < 0) return 0;
+        ai[0] = act.idx[cls];
+        E[0] = gd_entity_id<DIM>(cg, e);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ev[0][d] = d < DIM ? e[d] : 0;
+        return 1;
+    }
+    int h[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) h[d] = e[d] >> 1;
+    int count = 0;
+    for (int c2 = 0; c2 < NCLS; ++c2) {
+        int v[3] = {0, 0, 0};
+        if (act.idx[c2] < 0 || !gd_entity_of<DIM>(cg, h, c2, v) || !gd_is_coarse_node<DIM>(cg, v)) continue;
+        bool adj = true;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) adj = adj && ((e[d] & 1) ? v[d] == e[d] : (cg.g[d] >= 2 ? (v[d] == e[d] - 1 || v[d] == e[d] + 1) : v[d] == e[d]));
+        if (!adj || count >= 8) continue;
+        ai[count] = act.idx[c2];
+        E[count] = gd_coarse_id<DIM>(cg, v);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ev[count][d] = v[d];
+        ++count;
+    }
+    return count;
+}
+
+// Null space of the operator restricted to an entity, function k of nns, component a at offset dd from the entity's centre:
+// k < dofs the translations (constant 1 in component k: all FROSch uses without node coordinates), k >= dofs the linearised
+// rotations FROSch adds with "Use node lists" and "Rotations" = true (steadyLinElas/parametersPrec.xml:6, 100): 2D (-y, x);
+// 3D about z (-y, x, 0), about x (0, -z, y), about y (z, 0, -x).  The centre is that of the entity in the lattice,
+// lo_d + (e_d + 1) H_d / 2: translations + rotations span the same space whatever the centre, this one keeps the rotations of
+// single-node vertices and the axial rotation of straight edges at zero, where the selection below drops them.
+template <int DIM>
+__device__ __forceinline__ double gd_null(int dofs, int k, int a, const double dd[3]) {
+    if (k < dofs) return k == a ? 1.0 : 0.0;
+    const int j = k - dofs;
+    if (DIM == 2) return a == 0 ? -dd[1] : dd[0];
+    if (j == 0) return a == 0 ? -dd[1] : (a == 1 ? dd[0] : 0.0);
+    if (j == 1) return a == 0 ? 0.0 : (a == 1 ? -dd[2] : dd[1]);
+    return a == 0 ? dd[2] : (a == 1 ? 0.0 : -dd[0]);
+}
+
+template <int DIM>
+__device__ __forceinline__ void gd_offset(const CoarseGeom& cg, const double* __restrict__ xyz, int32_t node, const int ev[3], double dd[3]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dd[d] = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) dd[d] = xyz[(int64_t)node * DIM + d] - (cg.lo[d] + (double)(ev[d] + 1) * (cg.L[d] / (double)cg.g[d]) * 0.5);
+}
+
+constexpr int GD_NNS_MAX = 6;                                   // 3 translations + 3 rotations
+constexpr int GD_NG = GD_NNS_MAX * (GD_NNS_MAX + 1) / 2;        // packed lower triangle of an entity's Gram matrix
+
+// Rotations: which of an entity's nns functions are linearly independent on its free interface dofs (FROSch drops the
+// dependent ones: no rotations on vertices and one-node edges, two on straight edges).  Step 1: the Gram matrix of the functions
+// per coarse id, G[E][k (k + 1) / 2 + l] = sum over interface nodes and free components of f_k f_l (atomics: the sums only
+// feed the thresholds of step 2).
+template <int DIM>
+__global__ void k_gd_gram(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int nns, int32_t n_own,
+                          const double* __restrict__ xyz, const double* __restrict__ mask, double* __restrict__ G) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_own) return;
+    int e[3];
+    gd_entity_coords<DIM>(cg, ent[i], e);
+    const int cls = gd_class<DIM>(e);
+    if (cls < 0) return;
+    int ai[8], ev[8][3];
+    int32_t E[8];
+    const int nt = gd_targets<DIM>(cg, act, e, cls, ai, E, ev);
+    for (int t = 0; t < nt; ++t) {
+        double dd[3];
+        gd_offset<DIM>(cg, xyz, i, ev[t], dd);
+        const double w = 1.0 / (double)nt;
+        for (int k = 0; k < nns; ++k)
+            for (int l = 0; l <= k; ++l) {
+                double sum = 0.0;
+                for (int a = 0; a < dofs; ++a) {
+                    const double m = mask[(int64_t)i * dofs + a];
+                    sum += (w * gd_null<DIM>(dofs, k, a, dd) * m) * (w * gd_null<DIM>(dofs, l, a, dd) * m);
+                }
+                if (sum != 0.0) atomicAdd(&G[(int64_t)E[t] * GD_NG + k * (k + 1) / 2 + l], sum);
+            }
+    }
+}
+
+// Step 2: a Cholesky sweep over the functions in their order (translations first): function k stays if what is left of it after
+// the kept ones before it exceeds 1e-8 x (its scale) x (the largest translation's sum): scale 1 for a translation, Hmax^2 for a
+// rotation.  keep[E] = bit mask of the functions kept.
+__global__ void k_gd_select(const double* __restrict__ G, int64_t n_coarse, int dofs, int nns, double hmax2, int32_t* __restrict__ keep) {
+    const int64_t E = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (E >= n_coarse) return;
+    double g[GD_NNS_MAX][GD_NNS_MAX], L[GD_NNS_MAX][GD_NNS_MAX];
+    for (int k = 0; k < nns; ++k)
+        for (int l = 0; l <= k; ++l) {
+            g[k][l] = G[E * GD_NG + k * (k + 1) / 2 + l];
+            L[k][l] = 0.0;
+        }
+    double tmax = 0.0;
+    for (int t = 0; t < dofs; ++t) tmax = fmax(tmax, g[t][t]);
+    int32_t bits = 0;
+    for (int k = 0; k < nns; ++k) {
+        double r = g[k][k];
+        for (int j = 0; j < k; ++j) {
+            if (!((bits >> j) & 1)) continue;
+            double v = g[k][j];
+            for (int q = 0; q < j; ++q)
+                if ((bits >> q) & 1) v -= L[k][q] * L[j][q];
+            L[k][j] = v / L[j][j];
+            r -= L[k][j] * L[k][j];
+        }
+        if (tmax > 0.0 && r > 1e-8 * (k < dofs ? 1.0 : hmax2) * tmax) {
+            bits |= 1 << k;
+            L[k][k] = sqrt(r);
+        }
+    }
+    keep[E] = bits;
+}
+
+// Phi <- Phi_Gamma (interface rows: the null-space functions of their own entity -- RGDSW: of the adjacent coarse nodes, weighted --
+// in the class of that entity; Dirichlet rows 0), interior rows 0; imask = 1 on free interior dofs (the unknowns of the
+// extension solves), 0 elsewhere.  nns functions per entity (dofs translations, then the rotations if any); keep: the bit
+// masks of k_gd_select, nullptr = all kept.
+template <int DIM>
+__global__ void k_gd_phi_init(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int nns, int64_t n_rows, int64_t ldp,
+                              const double* __restrict__ xyz, const int32_t* __restrict__ keep,
+                              const double* __restrict__ mask, double* __restrict__ phiT, double* __restrict__ imask) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     const int32_t node = (int32_t)(r / dofs);
@@ -521,28 +652,19 @@ __global__ void k_gd_phi_init(CoarseGeom cg, GdAct act, const int32_t* __restric
     int e[3];
     gd_entity_coords<DIM>(cg, ent[node], e);
     const int cls = gd_class<DIM>(e);
-    const int nsa = act.n * dofs;
+    const int nsa = act.n * nns;
     for (int s = 0; s < nsa; ++s) phiT[(int64_t)s * ldp + r] = 0.0;
-    if (cls >= 0 && !cg.reduced && act.idx[cls] >= 0) phiT[(int64_t)(act.idx[cls] * dofs + a) * ldp + r] = mask[r];
-    if (cls >= 0 && cg.reduced) {
-        // RGDSW, option 1 (Dohrmann, Widlund 2017): an interface node of entity e gets the value 1 / |C(e)| for every
-        // coarse node of C(e), the coarse nodes adjacent to e: e_d odd stays, an even e_d (direction with >= 2 cells)
-        // moves to e_d - 1 or e_d + 1 where that lies inside the lattice.  All of them are corners of the home cell.
-        int h[3] = {0, 0, 0};
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) h[d] = e[d] >> 1;
-        int count = 0;
-        for (int pass = 0; pass < 2; ++pass)
-            for (int c2 = 0; c2 < NCLS; ++c2) {
-                int v[3] = {0, 0, 0};
-                if (act.idx[c2] < 0 || !gd_entity_of<DIM>(cg, h, c2, v) || !gd_is_coarse_node<DIM>(cg, v)) continue;
-                bool adj = true;
-#pragma unroll
-                for (int d = 0; d < DIM; ++d) adj = adj && ((e[d] & 1) ? v[d] == e[d] : (cg.g[d] >= 2 ? (v[d] == e[d] - 1 || v[d] == e[d] + 1) : v[d] == e[d]));
-                if (!adj) continue;
-                if (pass == 0) ++count;
-                else phiT[(int64_t)(act.idx[c2] * dofs + a) * ldp + r] = mask[r] / (double)count;
-            }
+    if (cls >= 0) {
+        int ai[8], ev[8][3];
+        int32_t E[8];
+        const int nt = gd_targets<DIM>(cg, act, e, cls, ai, E, ev);
+        for (int t = 0; t < nt; ++t) {
+            double dd[3] = {0.0, 0.0, 0.0};
+            if (nns > dofs) gd_offset<DIM>(cg, xyz, node, ev[t], dd);
+            const int32_t bits = keep ? keep[E[t]] : -1;
+            for (int k = 0; k < nns; ++k)
+                if ((bits >> k) & 1) phiT[(int64_t)(ai[t] * nns + k) * ldp + r] = gd_null<DIM>(dofs, k, a, dd) * mask[r] / (double)nt;
+        }
     }
     imask[r] = cls < 0 ? mask[r] : 0.0;
 }
@@ -692,12 +814,12 @@ __global__ __launch_bounds__(256) void k_gd_restrict_cells(const int32_t* __rest
 
 // restriction, step 2: r0[(E, k)] = sum over the cells that see E (fixed order) of their class(E) partial sum
 template <int DIM>
-__global__ void k_gd_restrict_ent(CoarseGeom cg, GdAct act, int dofs, int64_t n_ent, const double* __restrict__ part,
+__global__ void k_gd_restrict_ent(CoarseGeom cg, GdAct act, int nns, int64_t n_ent, const double* __restrict__ part,
                                   double* __restrict__ r0) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_ent * dofs) return;
-    const int32_t E = (int32_t)(t / dofs);
-    const int k = (int)(t - (int64_t)E * dofs);
+    if (t >= n_ent * nns) return;
+    const int32_t E = (int32_t)(t / nns);
+    const int k = (int)(t - (int64_t)E * nns);
     int e[3];
     gd_coarse_coords<DIM>(cg, E, e);
     const int cls = gd_class<DIM>(e);
@@ -717,7 +839,7 @@ __global__ void k_gd_restrict_ent(CoarseGeom cg, GdAct act, int dofs, int64_t n_
                 }
                 ok = ok && h[d] >= 0 && h[d] < cg.g[d];
             }
-            if (ok) sum += part[(int64_t)cell_of<DIM>(cg, h) * (act.n * dofs) + act.idx[cls] * dofs + k];
+            if (ok) sum += part[(int64_t)cell_of<DIM>(cg, h) * (act.n * nns) + act.idx[cls] * nns + k];
         }
     }
     r0[t] = sum;
@@ -725,7 +847,7 @@ __global__ void k_gd_restrict_ent(CoarseGeom cg, GdAct act, int dofs, int64_t n_
 
 // prolongation: z[r] (+)= mask[r] * sum_slots Phi[slot][r] * z0[entity(home(r), class)][k]
 template <int DIM, bool ADD>
-__global__ void k_gd_prolong(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int64_t n_rows, int64_t ldp,
+__global__ void k_gd_prolong(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int nns, int64_t n_rows, int64_t ldp,
                              const double* __restrict__ phiT, const double* __restrict__ mask,
                              const double* __restrict__ z0, double* __restrict__ z) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -741,7 +863,7 @@ __global__ void k_gd_prolong(CoarseGeom cg, GdAct act, const int32_t* __restrict
         if (!gd_entity_of<DIM>(cg, h, act.cls[ai], ee)) continue;
         const int64_t E = gd_coarse_id<DIM>(cg, ee);
         if (E < 0) continue;
-        for (int k = 0; k < dofs; ++k) sum = fma(phiT[(int64_t)(ai * dofs + k) * ldp + r], z0[E * dofs + k], sum);
+        for (int k = 0; k < nns; ++k) sum = fma(phiT[(int64_t)(ai * nns + k) * ldp + r], z0[E * nns + k], sum);
     }
     if (ADD) z[r] += sum * mask[r];
     else z[r] = sum * mask[r];
@@ -760,7 +882,7 @@ __host__ __device__ __forceinline__ int gd_period(const CoarseGeom& cg) { return
 // a cell sees three consecutive entity coordinates per direction, so at most one entity of the colour, i.e. a row reads at
 // most ONE entry of Phi (the generic prolongation read all of them, 375 times per setup)
 template <int DIM>
-__global__ void k_gd_prolong_colour(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int64_t n_rows, int64_t ldp,
+__global__ void k_gd_prolong_colour(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int nns, int64_t n_rows, int64_t ldp,
                                     const double* __restrict__ phiT, const double* __restrict__ mask, int k, GdCol col,
                                     double* __restrict__ v) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -777,18 +899,18 @@ __global__ void k_gd_prolong_colour(CoarseGeom cg, GdAct act, const int32_t* __r
         bool on = gd_coarse_id<DIM>(cg, ee) >= 0;
 #pragma unroll
         for (int d = 0; d < DIM; ++d) on = on && (ee[d] % gd_period(cg)) == col.c[d];
-        if (on) val = phiT[(int64_t)(ai * dofs + k) * ldp + r];
+        if (on) val = phiT[(int64_t)(ai * nns + k) * ldp + r];
     }
     v[r] = val * mask[r];
 }
 
 // K0[(E, a)][(E', k)] = r0[(E, a)] with E' the entity of the colour within two lattice steps of E
 template <int DIM>
-__global__ void k_gd_scatter_col(CoarseGeom cg, int dofs, int64_t n_ent, int k, GdCol col, const double* __restrict__ r0,
+__global__ void k_gd_scatter_col(CoarseGeom cg, int nns, int64_t n_ent, int k, GdCol col, const double* __restrict__ r0,
                                  double* __restrict__ K, int64_t ld) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_ent * dofs) return;
-    const int32_t E = (int32_t)(t / dofs);
+    if (t >= n_ent * nns) return;
+    const int32_t E = (int32_t)(t / nns);
     int e[3], ep[3] = {0, 0, 0};
     gd_coarse_coords<DIM>(cg, E, e);
     if (gd_class<DIM>(e) < 0) return;
@@ -804,7 +926,7 @@ __global__ void k_gd_scatter_col(CoarseGeom cg, int dofs, int64_t n_ent, int k, 
     if (!ok || gd_class<DIM>(ep) < 0) return;
     const int64_t Ep = gd_coarse_id<DIM>(cg, ep);
     if (Ep < 0) return;
-    K[t * ld + Ep * dofs + k] = r0[t];
+    K[t * ld + Ep * nns + k] = r0[t];
 }
 
 // ---- the Galerkin product MULTI_NR columns at a time (stacked vectors X[r * MULTI_NR + j], multi.hip) ----
@@ -818,7 +940,7 @@ struct GdCols {
 // A thread per row: the entities its home cell sees are worked out once, each column then only compares colours (a thread per
 // (row, column) repeated the entity arithmetic sixteen times: 1.97 ms per launch with the 26 classes of GDSW).
 template <int DIM>
-__global__ void k_gd_prolong_colours(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int64_t n_rows, int64_t ldp,
+__global__ void k_gd_prolong_colours(CoarseGeom cg, GdAct act, const int32_t* __restrict__ ent, int dofs, int nns, int64_t n_rows, int64_t ldp,
                                      const double* __restrict__ phiT, const double* __restrict__ mask, GdCols cols,
                                      double* __restrict__ V) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -851,7 +973,7 @@ __global__ void k_gd_prolong_colours(CoarseGeom cg, GdAct act, const int32_t* __
 #pragma unroll
     for (int j = 0; j < MULTI_NR; ++j) {
         double val = 0.0;
-        if (j < cols.nb && sel[j] >= 0) val = phiT[(int64_t)(sel[j] * dofs + cols.k[j]) * ldp + r] * m;
+        if (j < cols.nb && sel[j] >= 0) val = phiT[(int64_t)(sel[j] * nns + cols.k[j]) * ldp + r] * m;
         V[r * MULTI_NR + j] = val;
     }
 }
@@ -895,20 +1017,20 @@ __global__ __launch_bounds__(256) void k_gd_restrict_cells_cols(const int32_t* _
 
 // step 2: r0[(E, a)][j] = sum over the cells that see E and their chunks (fixed order) of the class(E) partial sums
 template <int DIM>
-__global__ void k_gd_restrict_ent_cols(CoarseGeom cg, GdAct act, int dofs, int64_t n_ent, int nch, const double* __restrict__ part,
+__global__ void k_gd_restrict_ent_cols(CoarseGeom cg, GdAct act, int nns, int64_t n_ent, int nch, const double* __restrict__ part,
                                        double* __restrict__ r0) {
     const int64_t tt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tt >= n_ent * dofs * MULTI_NR) return;
+    if (tt >= n_ent * nns * MULTI_NR) return;
     const int j = (int)(tt % MULTI_NR);
     const int64_t t = tt / MULTI_NR;
-    const int32_t E = (int32_t)(t / dofs);
-    const int k = (int)(t - (int64_t)E * dofs);
+    const int32_t E = (int32_t)(t / nns);
+    const int k = (int)(t - (int64_t)E * nns);
     int e[3];
     gd_coarse_coords<DIM>(cg, E, e);
     const int cls = gd_class<DIM>(e);
     double sum = 0.0;
     if (cls >= 0 && act.idx[cls] >= 0) {
-        const int nsd = act.n * dofs;
+        const int nsd = act.n * nns;
         for (int a = 0; a < (1 << DIM); ++a) {
             int h[3] = {0, 0, 0};
             bool ok = true;
@@ -924,7 +1046,7 @@ __global__ void k_gd_restrict_ent_cols(CoarseGeom cg, GdAct act, int dofs, int64
             }
             if (ok) {
                 const int64_t cell = cell_of<DIM>(cg, h);
-                for (int ch = 0; ch < nch; ++ch) sum += part[((cell * nch + ch) * nsd + act.idx[cls] * dofs + k) * MULTI_NR + j];
+                for (int ch = 0; ch < nch; ++ch) sum += part[((cell * nch + ch) * nsd + act.idx[cls] * nns + k) * MULTI_NR + j];
             }
         }
     }
@@ -933,14 +1055,14 @@ __global__ void k_gd_restrict_ent_cols(CoarseGeom cg, GdAct act, int dofs, int64
 
 // K0[(E, a)][(E', k_j)] = r0[(E, a)][j] with E' the entity of column j's colour within two lattice steps of E
 template <int DIM>
-__global__ void k_gd_scatter_cols(CoarseGeom cg, int dofs, int64_t n_ent, GdCols cols, const double* __restrict__ r0,
+__global__ void k_gd_scatter_cols(CoarseGeom cg, int nns, int64_t n_ent, GdCols cols, const double* __restrict__ r0,
                                   double* __restrict__ K, int64_t ld) {
     const int64_t tt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tt >= n_ent * dofs * MULTI_NR) return;
+    if (tt >= n_ent * nns * MULTI_NR) return;
     const int j = (int)(tt % MULTI_NR);
     if (j >= cols.nb) return;
     const int64_t t = tt / MULTI_NR;
-    const int32_t E = (int32_t)(t / dofs);
+    const int32_t E = (int32_t)(t / nns);
     int e[3], ep[3] = {0, 0, 0};
     gd_coarse_coords<DIM>(cg, E, e);
     if (gd_class<DIM>(e) < 0) return;
@@ -956,7 +1078,7 @@ __global__ void k_gd_scatter_cols(CoarseGeom cg, int dofs, int64_t n_ent, GdCols
     if (!ok || gd_class<DIM>(ep) < 0) return;
     const int64_t Ep = gd_coarse_id<DIM>(cg, ep);
     if (Ep < 0) return;
-    K[t * ld + Ep * dofs + cols.k[j]] = r0[tt];
+    K[t * ld + Ep * nns + cols.k[j]] = r0[tt];
 }
 
 // ---- apply ----
@@ -1122,18 +1244,18 @@ static GdAct gdsw_active(const CoarseGeom& cg) {
 static int64_t gdsw_ldp(const fedd_ctx* c) { return (c->n_rows + 15) & ~(int64_t)15; }
 
 static int gdsw_restrict(fedd_ctx* c, const double* d_rv, double* d_r0) {
-    const int dim = c->dim, dofs = c->dofs;
+    const int dim = c->dim, dofs = c->dofs, nns = c->co_nns;
     const CoarseGeom cg = c->co_geom;
     const GdAct act = gdsw_active(cg);
-    const int nsa = act.n * dofs;
+    const int nsa = act.n * nns;
     const int64_t ncell = c->co_ncell, n_ent = c->co_nlat;
     if (nsa > 0)   // (RGDSW on a lattice without coarse nodes has no functions: r0 = 0 below)
         hipLaunchKernelGGL(k_gd_restrict_cells, dim3((unsigned)ncell, (unsigned)((nsa + 7) / 8)), dim3(256), 0, c->stream,
                        (const int32_t*)c->d_co_cell_ptr.p, (const int32_t*)c->d_co_val[c->co_sorted].p, dofs, nsa, gdsw_ldp(c),
                        (const double*)c->d_gd_phi.p, d_rv, c->d_co_part.p);
-    const dim3 ge((unsigned)((n_ent * dofs + 255) / 256)), blk(256);
-    if (dim == 3) hipLaunchKernelGGL(k_gd_restrict_ent<3>, ge, blk, 0, c->stream, cg, act, dofs, n_ent, (const double*)c->d_co_part.p, d_r0);
-    else hipLaunchKernelGGL(k_gd_restrict_ent<2>, ge, blk, 0, c->stream, cg, act, dofs, n_ent, (const double*)c->d_co_part.p, d_r0);
+    const dim3 ge((unsigned)((n_ent * nns + 255) / 256)), blk(256);
+    if (dim == 3) hipLaunchKernelGGL(k_gd_restrict_ent<3>, ge, blk, 0, c->stream, cg, act, nns, n_ent, (const double*)c->d_co_part.p, d_r0);
+    else hipLaunchKernelGGL(k_gd_restrict_ent<2>, ge, blk, 0, c->stream, cg, act, nns, n_ent, (const double*)c->d_co_part.p, d_r0);
     return 0;
 }
 
@@ -1143,10 +1265,10 @@ static int gdsw_prolong(fedd_ctx* c, const double* d_z0, double* d_z) {
     const GdAct act = gdsw_active(cg);
     const dim3 gr((unsigned)((c->n_rows + 255) / 256)), blk(256);
     if (c->dim == 3)
-        hipLaunchKernelGGL((k_gd_prolong<3, ADD>), gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, c->dofs, c->n_rows,
+        hipLaunchKernelGGL((k_gd_prolong<3, ADD>), gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, c->dofs, c->co_nns, c->n_rows,
                            gdsw_ldp(c), (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, d_z0, d_z);
     else
-        hipLaunchKernelGGL((k_gd_prolong<2, ADD>), gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, c->dofs, c->n_rows,
+        hipLaunchKernelGGL((k_gd_prolong<2, ADD>), gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, c->dofs, c->co_nns, c->n_rows,
                            gdsw_ldp(c), (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, d_z0, d_z);
     return 0;
 }
@@ -1167,16 +1289,20 @@ static int gdsw_setup(fedd_ctx* c) {
     // 5^3 cells 1199 + 294 ms (224 iterations), 6^3 900 + 246 (190), 7^3 869 + 215 (162): smaller interiors take fewer
     // extension iterations, and the Galerkin product no longer costs a sweep per coarse column
     const bool reduced = c->co_kind == FEDD_COARSE_RGDSW;
+    // functions per entity: the translations, and with option "gdsw_rotations" on a vector problem (dofs = dim) the rotations
+    const bool rot = c->gdsw_rot && dofs == dim && dim >= 2;
+    const int nns = rot ? dofs + (dim == 3 ? 3 : 1) : dofs;
+    c->co_nns = nns;
     double target = c->co_cells_target;
     // RGDSW has (g - 1)^dim * dofs coarse dofs only: one cell per 400 nodes, as many as the dense coarse solver takes
     // (vector problems in 3D: 13^3 cells = 5184 coarse dofs; cfg 5's share: 123 outer iterations against 186 with 9^3 cells,
     // setup 1.6 against 1.7 s -- profiles/r02_gdsw_tol_sweep.txt)
     if (!(target > 0)) {
         if (reduced) {
-            const int gmax = (int)std::floor(std::pow((double)COARSE_MAX_DOFS / dofs, 1.0 / dim)) + 1;
+            const int gmax = (int)std::floor(std::pow((double)COARSE_MAX_DOFS / nns, 1.0 / dim)) + 1;
             target = std::min(std::pow((double)std::min(gmax, 20), (double)dim), std::max(1.0, std::floor(n_global / 400.0)));
         } else {
-            const int gmax = std::max(1, ((int)std::floor(std::pow((double)COARSE_MAX_DOFS / dofs, 1.0 / dim)) + 1) / 2);
+            const int gmax = std::max(1, ((int)std::floor(std::pow((double)COARSE_MAX_DOFS / nns, 1.0 / dim)) + 1) / 2);
             target = std::min(std::pow((double)gmax, (double)dim), std::max(1.0, std::floor(n_global / 1000.0)));
         }
     }
@@ -1203,9 +1329,9 @@ static int gdsw_setup(fedd_ctx* c) {
         ncell *= g;
         n_ent *= reduced ? (g >= 2 ? g - 1 : 1) : 2 * g - 1;
     }
-    const int64_t n0 = n_ent * dofs;
+    const int64_t n0 = n_ent * nns;
     FEDD_CHECK(n0 <= COARSE_MAX_DOFS, "GDSW setup: %lld coarse dofs ((2g - 1)^dim entities, RGDSW: (g - 1)^dim coarse nodes, x %d), the dense coarse solver takes at "
-               "most %d; lower fedd_schwarz_set_coarse (now %g cells)", (long long)n0, dofs, COARSE_MAX_DOFS, target);
+               "most %d; lower fedd_schwarz_set_coarse (now %g cells)", (long long)n0, nns, COARSE_MAX_DOFS, target);
     const int64_t ld = (n0 + NB - 1) / NB * NB;
     c->co_geom = cg;
     c->co_ncell = ncell;
@@ -1213,7 +1339,7 @@ static int gdsw_setup(fedd_ctx* c) {
     c->co_n0 = n0;
     c->co_ld = ld;
     const GdAct act = gdsw_active(cg);
-    const int nsd = act.n * dofs;           // active slots (compact)
+    const int nsd = act.n * nns;            // active slots (compact)
     const int64_t ldp = gdsw_ldp(c);
     const dim3 blk(256), gn((n_own + 255) / 256), gr((unsigned)((n_rows + 255) / 256));
     // ---- entity and home cell of every owned node; nodes grouped by home cell (stable radix split) ----
@@ -1251,8 +1377,23 @@ static int gdsw_setup(fedd_ctx* c) {
     double* w = v + nc;
     double* b = w + n_rows;
     double* x = b + n_rows;
-    if (dim == 3) hipLaunchKernelGGL(k_gd_phi_init<3>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_co_mask.p, c->d_gd_phi.p, c->d_gd_imask.p);
-    else hipLaunchKernelGGL(k_gd_phi_init<2>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_co_mask.p, c->d_gd_phi.p, c->d_gd_imask.p);
+    const int32_t* d_keep = nullptr;
+    if (rot) {
+        // which functions of every entity are independent on its free interface dofs: Gram matrices (summed over the ranks), selection
+        double hmax2 = 0.0;
+        for (int d = 0; d < dim; ++d) hmax2 = std::max(hmax2, (cg.L[d] / cg.g[d]) * (cg.L[d] / cg.g[d]));
+        FEDD_CHECK(n_ent * GD_NG < ((int64_t)1 << 31), "GDSW setup: %lld entities", (long long)n_ent);
+        FEDD_TRY(c->d_gd_gram.ensure((size_t)n_ent * GD_NG));
+        FEDD_TRY(c->d_gd_keep.ensure((size_t)n_ent));
+        FEDD_HIP(hipMemsetAsync(c->d_gd_gram.p, 0, (size_t)n_ent * GD_NG * sizeof(double), c->stream));
+        if (dim == 3) hipLaunchKernelGGL(k_gd_gram<3>, gn, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, nns, n_own, (const double*)c->d_xyz.p, (const double*)c->d_co_mask.p, c->d_gd_gram.p);
+        else hipLaunchKernelGGL(k_gd_gram<2>, gn, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, nns, n_own, (const double*)c->d_xyz.p, (const double*)c->d_co_mask.p, c->d_gd_gram.p);
+        if (c->nranks > 1) FEDD_TRY(allreduce_sum(c, c->d_gd_gram.p, (int)(n_ent * GD_NG)));
+        hipLaunchKernelGGL(k_gd_select, dim3((unsigned)((n_ent + 255) / 256)), blk, 0, c->stream, (const double*)c->d_gd_gram.p, n_ent, dofs, nns, hmax2, c->d_gd_keep.p);
+        d_keep = c->d_gd_keep.p;
+    }
+    if (dim == 3) hipLaunchKernelGGL(k_gd_phi_init<3>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, nns, n_rows, ldp, (const double*)c->d_xyz.p, d_keep, (const double*)c->d_co_mask.p, c->d_gd_phi.p, c->d_gd_imask.p);
+    else hipLaunchKernelGGL(k_gd_phi_init<2>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, nns, n_rows, ldp, (const double*)c->d_xyz.p, d_keep, (const double*)c->d_co_mask.p, c->d_gd_phi.p, c->d_gd_imask.p);
     FEDD_TRY(c->d_co_part.ensure((size_t)ncell * std::max(nsd, 1)));
     FEDD_TRY(c->d_co_r0.ensure(std::max<size_t>((size_t)ld, c->d_co_r0.cap)));
     FEDD_TRY(c->d_co_z0.ensure((size_t)ld));
@@ -1360,40 +1501,40 @@ static int gdsw_setup(fedd_ctx* c) {
         FEDD_TRY(c->d_co_r0.ensure(std::max<size_t>((size_t)n0 * MULTI_NR, c->d_co_r0.cap)));
         FEDD_CHECK(n0 * MULTI_NR < ((int64_t)1 << 31), "GDSW setup: coarse space too large for the stacked Galerkin product");
         const dim3 gs((unsigned)((n_rows + 255) / 256)), ges((unsigned)((n0 * MULTI_NR + 255) / 256));
-        const int64_t npairs = (int64_t)colours.size() * dofs;
+        const int64_t npairs = (int64_t)colours.size() * nns;
         for (int64_t p0 = 0; p0 < npairs; p0 += MULTI_NR) {
             GdCols cols;
             cols.nb = (int)std::min<int64_t>(MULTI_NR, npairs - p0);
             for (int j = 0; j < MULTI_NR; ++j) {
                 const int64_t pj = std::min(p0 + j, npairs - 1);
-                for (int d = 0; d < 3; ++d) cols.c[j][d] = (int8_t)colours[(size_t)(pj / dofs)].c[d];
-                cols.k[j] = (int8_t)(pj % dofs);
+                for (int d = 0; d < 3; ++d) cols.c[j][d] = (int8_t)colours[(size_t)(pj / nns)].c[d];
+                cols.k[j] = (int8_t)(pj % nns);
             }
-            if (dim == 3) hipLaunchKernelGGL(k_gd_prolong_colours<3>, gs, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, cols, Vs);
-            else hipLaunchKernelGGL(k_gd_prolong_colours<2>, gs, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, cols, Vs);
+            if (dim == 3) hipLaunchKernelGGL(k_gd_prolong_colours<3>, gs, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, nns, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, cols, Vs);
+            else hipLaunchKernelGGL(k_gd_prolong_colours<2>, gs, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, nns, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, cols, Vs);
             FEDD_TRY(spmm_owned(c, Vs, Ws, nullptr, nullptr));
             hipLaunchKernelGGL(k_gd_restrict_cells_cols, dim3((unsigned)ncell, (unsigned)((nsd + 15) / 16), (unsigned)nch), blk, 0, c->stream,
                                (const int32_t*)c->d_co_cell_ptr.p, (const int32_t*)c->d_co_val[c->co_sorted].p, dofs, nsd, nch, ldp,
                                (const double*)c->d_gd_phi.p, (const double*)Ws, c->d_co_part.p);
-            if (dim == 3) hipLaunchKernelGGL(k_gd_restrict_ent_cols<3>, ges, blk, 0, c->stream, cg, act, dofs, n_ent, nch, (const double*)c->d_co_part.p, c->d_co_r0.p);
-            else hipLaunchKernelGGL(k_gd_restrict_ent_cols<2>, ges, blk, 0, c->stream, cg, act, dofs, n_ent, nch, (const double*)c->d_co_part.p, c->d_co_r0.p);
+            if (dim == 3) hipLaunchKernelGGL(k_gd_restrict_ent_cols<3>, ges, blk, 0, c->stream, cg, act, nns, n_ent, nch, (const double*)c->d_co_part.p, c->d_co_r0.p);
+            else hipLaunchKernelGGL(k_gd_restrict_ent_cols<2>, ges, blk, 0, c->stream, cg, act, nns, n_ent, nch, (const double*)c->d_co_part.p, c->d_co_r0.p);
             if (c->nranks > 1) FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, (int)(n0 * MULTI_NR)));
-            if (dim == 3) hipLaunchKernelGGL(k_gd_scatter_cols<3>, ges, blk, 0, c->stream, cg, dofs, n_ent, cols, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
-            else hipLaunchKernelGGL(k_gd_scatter_cols<2>, ges, blk, 0, c->stream, cg, dofs, n_ent, cols, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
+            if (dim == 3) hipLaunchKernelGGL(k_gd_scatter_cols<3>, ges, blk, 0, c->stream, cg, nns, n_ent, cols, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
+            else hipLaunchKernelGGL(k_gd_scatter_cols<2>, ges, blk, 0, c->stream, cg, nns, n_ent, cols, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
         }
         // (the per-column restriction of the apply takes its own layout of the partial sums)
         FEDD_TRY(c->d_co_part.ensure((size_t)ncell * std::max(nsd, 1)));
     }
     for (size_t ci = 0; ci < (stacked ? 0 : colours.size()); ++ci)
-                for (int k = 0; k < dofs; ++k) {
+                for (int k = 0; k < nns; ++k) {
                     const GdCol col = colours[ci];
-                    if (dim == 3) hipLaunchKernelGGL(k_gd_prolong_colour<3>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, k, col, v);
-                    else hipLaunchKernelGGL(k_gd_prolong_colour<2>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, k, col, v);
+                    if (dim == 3) hipLaunchKernelGGL(k_gd_prolong_colour<3>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, nns, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, k, col, v);
+                    else hipLaunchKernelGGL(k_gd_prolong_colour<2>, gr, blk, 0, c->stream, cg, act, (const int32_t*)c->d_gd_ent.p, dofs, nns, n_rows, ldp, (const double*)c->d_gd_phi.p, (const double*)c->d_co_mask.p, k, col, v);
                     FEDD_TRY(spmv_owned(c, v, w, true));
                     FEDD_TRY(gdsw_restrict(c, w, c->d_co_r0.p));
                     if (c->nranks > 1) FEDD_TRY(allreduce_sum(c, c->d_co_r0.p, (int)n0));
-                    if (dim == 3) hipLaunchKernelGGL(k_gd_scatter_col<3>, ge, blk, 0, c->stream, cg, dofs, n_ent, k, col, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
-                    else hipLaunchKernelGGL(k_gd_scatter_col<2>, ge, blk, 0, c->stream, cg, dofs, n_ent, k, col, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
+                    if (dim == 3) hipLaunchKernelGGL(k_gd_scatter_col<3>, ge, blk, 0, c->stream, cg, nns, n_ent, k, col, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
+                    else hipLaunchKernelGGL(k_gd_scatter_col<2>, ge, blk, 0, c->stream, cg, nns, n_ent, k, col, (const double*)c->d_co_r0.p, c->d_co_K.p, ld);
                 }
     hipLaunchKernelGGL(k_fix_diag, dim3((unsigned)((ld + 3) / 4)), blk, 0, c->stream, c->d_co_K.p, ld, n0);
     FEDD_TRY(dense_invert_batched(c, c->d_co_K.p, ld, 1, ld * ld, nullptr, (int)(ld / NB), 1, d_bad + 1));

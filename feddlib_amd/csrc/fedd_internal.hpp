@@ -332,6 +332,10 @@ struct fedd_ctx {
     int gm_nr = 0;                              // > 1: GMRES runs on stacked vectors X[row * gm_nr + j] (multi.hip; the GDSW extension solves)
     int multi_ch = 4;                           // option "multi_ch": matrix-core steps per flight of gathers in k_apply_multi (4, 8, 16)
     int pat_hash = 1;                           // option "pat_hash": 1 = hashed node-pattern merge for vertex-only elements (symbolic.hip)
+    int gdsw_rot = 0;                           // option "gdsw_rotations": rotations in the null space of vector problems (dofs = dim)
+    int co_nns = 1;                             // coarse functions per entity of the last GDSW setup (dofs, or dofs + rotations)
+    fedd::DevBuf<double> d_gd_gram;             // [entities * 21] Gram matrices of the entities' functions (selection of the independent ones)
+    fedd::DevBuf<int32_t> d_gd_keep;            // [entities] bit masks of the functions kept
     int gdsw_block = 1;                         // option "gdsw_block": 1 = extension solves sixteen columns at a time, 0 = one by one
     const double* gm_mask = nullptr;            // != nullptr: GMRES solves the constrained system (dofs with mask 0 held), see gmres.hip
 

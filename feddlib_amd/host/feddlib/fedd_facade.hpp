@@ -1140,6 +1140,15 @@ int LinearSolver<SC, LO, GO, NO>::solve(Problem_Type* problem, BlockMultiVectorP
         if (blocks && twoLevel && problem->getVerbose())
             std::cout << "-- note: the coarse level is not built for merged block systems; running one level --" << std::endl;
         const bool two = twoLevel && !blocks;
+        // rotations in the null space of the coarse space: "Rotations" of the coarse operator's block 1
+        // (steadyLinElas/parametersPrec.xml:100), which FROSch can only build from the node coordinates the reference hands over
+        // with "Use node lists" (Preconditioner_def.hpp:266, 353-381; default true).  The library ignores the switch for
+        // scalar problems (a rotation needs dofs = dim).
+        if (two && coarseKind != FEDD_COARSE_Q1) {
+            const bool nodeLists = pl->get("Use node lists", true);
+            const bool rotations = frosch.sublist(coarseType).sublist("Blocks").sublist("1").get("Rotations", false);
+            feddCheck(fedd_set_option(ctx, "gdsw_rotations", nodeLists && rotations ? 1.0 : 0.0), "fedd_set_option(gdsw_rotations)");
+        }
         feddCheck(fedd_schwarz_setup(ctx, overlap, cmb, two ? 1 : 0, two ? coarseKind : 0), "fedd_schwarz_setup");
     }
     auto b = rhs.is_null() ? problem->getRhs() : rhs;

@@ -275,7 +275,14 @@ int fedd_spmv_info(fedd_ctx* ctx, int64_t* nnz_pattern, int64_t* nnz_streamed);
  * profiles/r02_gdsw_tol_sweep.txt and r03_gdsw_tol_sweep_stacked.txt; the parity tests ask for 1e-13; option "gdsw_block" 1 (default) = sixteen columns at a
  * time as one stacked system over an SpMM and a matrix-core Schwarz apply, multi.hip, 0 = column by column; "multi_ch" 4 / 8 / 16 = matrix-core
  * steps per flight of gathers of that apply), K0 = Phi^T A Phi inverted on the
- * matrix cores.  (2g - 1)^dim * dofs coarse dofs for g cells per direction. */
+ * matrix cores.  (2g - 1)^dim * dofs coarse dofs for g cells per direction.
+ * Option "gdsw_rotations" 1 (default 0; GDSW and RGDSW, vector problems with dofs = dim): what FROSch builds with "Use node
+ * lists" = true and "Rotations" = true (steadyLinElas/parametersPrec.xml:6, 100) -- every interface component carries the
+ * linearised rotations about its centre next to the translations (3 + 3 functions in 3D, 2 + 1 in 2D; the coarse space then
+ * holds the rigid-body modes of every cell).  Functions that are linearly dependent on a component's free dofs are dropped
+ * (a Cholesky sweep over the component's Gram matrix: a one-node vertex keeps its translations, a straight edge 5 of 6);
+ * (2g - 1)^dim * (dofs + rotations) coarse dofs, the dropped ones with a unit diagonal in K0.  Normative definition:
+ * oracle/fedd_oracle.py CoarseGDSW(rotations=True). */
 #define FEDD_COARSE_GDSW 2
 /* FEDD_COARSE_RGDSW: the reduced GDSW space (FROSch RGDSWCoarseOperator, the one steadyLinElas_Perf/parametersPrec.xml:18
  * names; Dohrmann & Widlund 2017, option 1): coarse functions only for the coarse nodes of the same decomposition (its

@@ -1054,10 +1054,18 @@ class CoarseGDSW:
       * Phi_Gamma[(node, a), (entity, a)] = 1 for free interface dofs (null space = constants per component);
       * Phi_I = -A_II^-1 A_IGamma Phi_Gamma on the free interior dofs (exact sparse solve here);
       * K0 = Phi^T A Phi over ALL (2g - 1)^dim entities x dofs (cell interiors and empty entities: unit diagonal, the
-        rest a relative diagonal shift of 1e-12); the level adds Phi K0^-1 Phi^T."""
+        rest a relative diagonal shift of 1e-12); the level adds Phi K0^-1 Phi^T.
+    rotations = True (FROSch with "Use node lists" and "Rotations" = true, steadyLinElas/parametersPrec.xml:6, 100; vector
+    problems with dofs = dim): every entity carries nns = dofs + (1 in 2D, 3 in 3D) functions, the translations and the
+    linearised rotations about the entity's centre in the lattice, c_d = lo_d + (e_d + 1) H_d / 2, H_d = L_d / g_d:
+    2D (-y, x); 3D about z (-y, x, 0), about x (0, -z, y), about y (z, 0, -x).  Functions that are linearly dependent on the
+    entity's free interface dofs are dropped (FROSch: no rotations on vertices, two on straight edges): with G the Gram
+    matrix of the entity's functions, a Cholesky sweep in the order of the functions keeps function k when the remainder
+    r_k = G_kk - sum_{j kept} L_kj^2 exceeds 1e-8 * s_k * max_t G_tt (t over the translations; s_k = 1 for a translation,
+    max_d H_d^2 for a rotation); dropped functions are zero columns (unit diagonal in K0)."""
 
     def __init__(self, A: sp.csr_matrix, conn: np.ndarray, xyz: np.ndarray, is_dir: np.ndarray, dofs: int = 1,
-                 cells_target: float = 8.0, lo=None, L=None, reduced: bool = False):
+                 cells_target: float = 8.0, lo=None, L=None, reduced: bool = False, rotations: bool = False):
         """reduced = True: RGDSW, option 1 (FEDD_COARSE_RGDSW): coarse dofs only on the coarse nodes -- entities with
         an odd coordinate in every direction that has >= 2 cells --, numbered compactly ((e_d - 1) / 2 per such
         direction); an interface node of entity e carries 1 / |C(e)| for every coarse node of C(e) (odd e_d kept, even
@@ -1093,9 +1101,82 @@ class CoarseGDSW:
         comp = np.tile(np.arange(dofs), n_nodes)
         col = np.repeat(ent, dofs) * dofs + comp
         sel = gamma_dof & free
-        self.n0 = n_ent * dofs
-        if not reduced:
+        rotations = bool(rotations) and dofs == dim and dim >= 2
+        nns = dofs + ((3 if dim == 3 else 1) if rotations else 0)
+        self.nns = nns
+        Hd = Lpos / g
+
+        def null_vec(k, dd):
+            v = np.zeros(dofs)
+            if k < dofs:
+                v[k] = 1.0
+            elif dim == 2:
+                v[:] = (-dd[1], dd[0])
+            else:
+                v[:] = ((-dd[1], dd[0], 0.0), (0.0, -dd[2], dd[1]), (dd[2], 0.0, -dd[0]))[k - dofs]
+            return v
+
+        self.n0 = n_ent * nns
+        if not reduced and not rotations:
             PhiG = sp.csr_matrix((np.ones(sel.sum()), (np.nonzero(sel)[0], col[sel])), shape=(n, self.n0))
+        elif rotations:
+            # (node, coarse id, entity coordinates of the function, weight) for every interface node
+            multi = g >= 2
+            cstride = np.ones(dim, dtype=np.int64)
+            ncoarse = 1
+            for d in range(dim):
+                cstride[d] = ncoarse
+                ncoarse *= (g[d] - 1) if multi[d] else 1
+            if reduced:
+                self.n0 = ncoarse * nns
+            rows, cols, vals = [], [], []
+            for node in np.nonzero(on_gamma)[0]:
+                if not reduced:
+                    targets = [(int(ent[node]), e[node])]
+                else:
+                    opts = []
+                    for d in range(dim):
+                        if not multi[d]:
+                            opts.append([0])
+                        elif e[node, d] % 2 == 1:
+                            opts.append([e[node, d]])
+                        else:
+                            opts.append([v for v in (e[node, d] - 1, e[node, d] + 1) if 1 <= v <= 2 * g[d] - 3])
+                    targets = [(int(sum(cstride[d] * ((v[d] - 1) // 2) for d in range(dim) if multi[d])), np.asarray(v))
+                               for v in itertools.product(*opts)]
+                for cid, ev in targets:
+                    dd = xyz[node] - (lo + (np.asarray(ev) + 1) * Hd * 0.5)
+                    for k in range(nns):
+                        f = null_vec(k, dd) / len(targets)
+                        for a in range(dofs):
+                            if free[node * dofs + a] and f[a] != 0.0:
+                                rows.append(node * dofs + a)
+                                cols.append(cid * nns + k)
+                                vals.append(f[a])
+            PhiG = sp.csr_matrix((vals, (rows, cols)), shape=(n, self.n0))
+            # independent functions per coarse id
+            G = (PhiG.T @ PhiG).toarray() if self.n0 <= 4096 else None
+            hmax2 = float((Hd[:dim] ** 2).max())
+            keep = np.zeros(self.n0, dtype=bool)
+            for E in range(self.n0 // nns):
+                sl = slice(E * nns, (E + 1) * nns)
+                Ge = G[sl, sl] if G is not None else (PhiG[:, sl].T @ PhiG[:, sl]).toarray()
+                tmax = max(Ge[t, t] for t in range(dofs))
+                Lc = np.zeros((nns, nns))
+                kept = []
+                for k in range(nns):
+                    r = Ge[k, k]
+                    for j in kept:
+                        v = Ge[k, j] - sum(Lc[k, q] * Lc[j, q] for q in kept if q < j)
+                        Lc[k, j] = v / Lc[j, j]
+                        r -= Lc[k, j] ** 2
+                    if tmax > 0.0 and r > 1e-8 * (1.0 if k < dofs else hmax2) * tmax:
+                        kept.append(k)
+                        Lc[k, k] = math.sqrt(r)
+                        keep[E * nns + k] = True
+            self.kept = keep
+            PhiG = (PhiG @ sp.diags(keep.astype(float))).tocsr()
+            PhiG.eliminate_zeros()
         else:
             multi = g >= 2
             cstride = np.ones(dim, dtype=np.int64)

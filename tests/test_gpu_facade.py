@@ -296,6 +296,37 @@ def test_linelas_two_level_tight_tolerance(linelas_driver, tmp_path):
     assert "is not built" not in log          # that file names RGDSWCoarseOperator: FEDD_COARSE_RGDSW runs
 
 
+def test_linelas_rotations_from_the_parameter_file(linelas_driver, tmp_path):
+    """"Rotations" = true in the coarse operator's block (steadyLinElas/parametersPrec.xml:100) with node lists on
+    (Preconditioner_def.hpp:266: the default) reaches the library as option gdsw_rotations: same solution, fewer iterations
+    than with the translations alone; "Use node lists" = false switches them off again, as FROSch has no coordinates then."""
+    prob = tmp_path / "p.xml"
+    prob.write_text(open(os.path.join(LINELAS_XML, "parametersProblem.xml")).read()
+                    .replace('name="H/h"							    	type="int"   	value="4"', 'name="H/h" type="int" value="8"'))
+    sol = tmp_path / "s.xml"
+    sol.write_text(open(os.path.join(LINELAS_XML, "parametersSolver.xml")).read()
+                   .replace('"Convergence Tolerance" type="double" value="1e-6"', '"Convergence Tolerance" type="double" value="1e-10"')
+                   .replace('"Maximum Iterations" type="int" value="100"', '"Maximum Iterations" type="int" value="500"'))
+    base = (open(os.path.join(LINELAS_XML, "parametersPrec.xml")).read()
+            .replace('name="TwoLevel"                                          type="bool"     value="false"',
+                     'name="TwoLevel" type="bool" value="true"/>\n<Parameter name="Coarse Cells" type="double" value="8"'))
+    assert 'name="TwoLevel" type="bool" value="true"' in base        # (Coarse Cells: this library's lattice; 729 nodes default to one cell)
+    rot_off = 'name="Rotations"                             type="bool"     value="false"'
+    assert base.count(rot_off) >= 2
+    its = {}
+    xs = {}
+    for key, text in (("translations", base), ("rotations", base.replace(rot_off, 'name="Rotations" type="bool" value="true"')),
+                      ("rotations, no node lists", base.replace(rot_off, 'name="Rotations" type="bool" value="true"')
+                       .replace('<Parameter name="Number of blocks" type="int" value="1"/>',
+                                '<Parameter name="Number of blocks" type="int" value="1"/>\n    <Parameter name="Use node lists" type="bool" value="false"/>', 1))):
+        prec = tmp_path / "c.xml"
+        prec.write_text(text)
+        xs[key], its[key], rel, log = run_driver(linelas_driver, tmp_path, prob, prec, sol)
+        assert rel <= 1e-9
+    assert its["rotations"] < its["translations"] and its["rotations, no node lists"] == its["translations"], its
+    np.testing.assert_allclose(xs["rotations"], xs["translations"], rtol=0, atol=1e-7 * np.abs(xs["translations"]).max())
+
+
 STOKES_XML = os.path.join(ROOT, "tests", "golden", "stokes_xml")
 
 

@@ -509,7 +509,12 @@ def _thread_rank_gdsw(capi, group, rank, dec, M, out, errs):
         c.schwarz_setup(1, capi.COMBINE_RESTRICTED, two_level=1, coarse_kind=capi.COARSE_GDSW)
         g, Kinv = c.schwarz_coarse()
         x, its, rel = c.gmres(None, rtol=1e-12, max_it=600, restart=100, use_prec=True)
-        out[rank] = dict(gu=m["gid_uni"], g=g, Kinv=Kinv, x=x, its=its, rel=rel)
+        # ... and with the rotations in the null space (their Gram matrices are summed over the ranks before the selection)
+        c.set_option("gdsw_rotations", 1)
+        c.schwarz_setup(1, capi.COMBINE_RESTRICTED, two_level=1, coarse_kind=capi.COARSE_GDSW)
+        _, Kinv_rot = c.schwarz_coarse()
+        x_rot, its_rot, rel_rot = c.gmres(None, rtol=1e-12, max_it=600, restart=100, use_prec=True)
+        out[rank] = dict(gu=m["gid_uni"], g=g, Kinv=Kinv, x=x, its=its, rel=rel, Kinv_rot=Kinv_rot, x_rot=x_rot, its_rot=its_rot)
         c.close()
     except Exception as e:      # pragma: no cover
         import traceback
@@ -555,6 +560,14 @@ def test_cfg5_miniature_gdsw_on_eight_ranks(fedd_lib):
         assert o["rel"] <= 1e-12
     assert len({o["its"] for o in out}) == 1
     np.testing.assert_allclose(x, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
+    co_rot = fo.CoarseGDSW(A_bc, ref["conn"], ref["xyz"], is_dir, 3, cells_target=8, rotations=True)
+    assert co_rot.n0 == 27 * 6 and int(co_rot.kept.sum()) == 1 * 3 + 6 * 5 + 12 * 6     # the vertex, 6 straight edges, 12 faces
+    x_rot = np.zeros_like(xd)
+    for o in out:
+        np.testing.assert_allclose(o["Kinv_rot"], co_rot.K0inv, rtol=0, atol=1e-8 * np.abs(co_rot.K0inv).max())
+        x_rot[(3 * o["gu"][:, None] + np.arange(3)[None, :]).ravel()] = o["x_rot"]
+    assert len({o["its_rot"] for o in out}) == 1 and out[0]["its_rot"] < out[0]["its"]
+    np.testing.assert_allclose(x_rot, xd, rtol=0, atol=1e-9 * np.abs(xd).max())
     # one rank, same problem, same coarse decomposition: the same preconditioner (whole boxes + row ghosts make the first
     # level independent of the number of ranks; the coarse level is defined on the global lattice)
     c = fedd_lib.Context(device=0)

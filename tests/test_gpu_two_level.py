@@ -224,6 +224,69 @@ def test_gdsw_elasticity_and_iteration_counts(fedd_lib):
         c.close()
 
 
+@pytest.mark.parametrize("dim,M,cells,kind", [(3, 8, 8, "gdsw"), (3, 12, 27, "gdsw"), (3, 8, 8, "rgdsw"), (3, 12, 27, "rgdsw"),
+                                              (2, 16, 16, "gdsw"), (2, 16, 16, "rgdsw"), (3, 9, 12, "gdsw")])
+def test_gdsw_rotations_in_the_null_space(fedd_lib, dim, M, cells, kind):
+    """Option "gdsw_rotations" (FROSch with node lists and "Rotations" = true, steadyLinElas/parametersPrec.xml:6, 100):
+    elasticity, every entity carries the translations AND the linearised rotations about its centre, the dependent ones
+    dropped (vertices keep 3 functions, straight edges 5, faces 6 in 3D) -- against the oracle's
+    CoarseGDSW(rotations=True): size and inverse of K0, the operator, the solve, and fewer iterations than with translations
+    alone.  ((3, 9, 12): a 3 x 2 x 2 lattice whose planes do not all lie on mesh planes.)"""
+    c = fedd_lib.Context(device=0)
+    try:
+        mu, nu = 2.0e6, 0.4
+        lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
+        m = fedd_lib.structured_mesh(dim, 1, M)
+        c.mesh_set_dict(m)
+        c.pattern_build(dim, fedd_lib.BLOCK_FULL)
+        c.assemble(fedd_lib.FORM_LINELAS, [lam, mu])
+        f = [0.0, 1.0, 0.0][:dim]
+        c.assemble_rhs(f)
+        c.dirichlet([2], [0.0] * dim)
+        om = oracle_mesh(m)
+        A_bc, rhs_bc, _, _, flags = fo.linelas_problem(om, mu, nu, f=tuple(f))
+        is_dir = fo.dirichlet_rows(flags, (2,), dofs=dim)
+        reduced = kind == "rgdsw"
+        ck = fedd_lib.COARSE_RGDSW if reduced else fedd_lib.COARSE_GDSW
+        tgt = 8 if dim == 3 else 9
+        c.schwarz_set_target(tgt, 1.0)
+        c.schwarz_set_coarse(cells)
+        c.set_option("gdsw_tol", 1e-13)
+        its = {}
+        for rot in (0, 1):
+            c.set_option("gdsw_rotations", rot)
+            c.schwarz_setup(1, fedd_lib.COMBINE_RESTRICTED, two_level=1, coarse_kind=ck)
+            g, Kinv = c.schwarz_coarse()
+            co = fo.CoarseGDSW(A_bc, m["conn"], m["xyz"], is_dir, dim, cells_target=cells, reduced=reduced, rotations=bool(rot))
+            nns = dim + ((3 if dim == 3 else 1) if rot else 0)
+            assert co.nns == nns and Kinv.shape == (co.n0, co.n0)
+            assert co.n0 == nns * (int(np.prod(np.where(co.g >= 2, co.g - 1, 1))) if reduced else int(np.prod(2 * co.g - 1)))
+            np.testing.assert_allclose(Kinv, co.K0inv, rtol=0, atol=1e-10 * np.abs(co.K0inv).max())
+            if rot and not reduced:
+                # the functions the device dropped are the oracle's: unit rows of K0^-1 exactly where the oracle keeps none
+                # although the entity has free interface dofs
+                unit = np.abs(Kinv - np.eye(co.n0)).sum(axis=1) < 1e-14
+                assert np.array_equal(unit, ~co.kept)
+                if dim == 3 and M % int(co.g[0]) == 0 and co.g.min() >= 2:
+                    per_entity = co.kept.reshape(-1, nns).sum(axis=1)
+                    assert set(per_entity.tolist()) <= {0, 3, 5, 6}
+            node_bin, nb, _ = fo.schwarz_bins(m["xyz"], tgt)
+            ras = fo.RAS(A_bc, node_bin, nb, dofs=dim)
+            r = np.random.default_rng(5).standard_normal(A_bc.shape[0])
+            zc = c.schwarz_coarse_apply(r)
+            np.testing.assert_allclose(zc, co.apply(r), rtol=0, atol=1e-10 * np.abs(zc).max(), err_msg="coarse level, rotations %d" % rot)
+            z = c.schwarz_apply(r)
+            zo = ras.apply(r) + co.apply(r)
+            np.testing.assert_allclose(z, zo, rtol=0, atol=1e-10 * np.abs(zo).max(), err_msg="both levels, rotations %d" % rot)
+            x, its[rot], rel = c.gmres(None, rtol=1e-12, max_it=400, restart=100, use_prec=True)
+            xd = fo.direct_solve(A_bc, rhs_bc)
+            np.testing.assert_allclose(x, xd, rtol=0, atol=1e-10 * np.abs(xd).max())
+        print("iterations without / with rotations:", its)
+        assert its[1] < its[0]
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("problem,kind", [("laplace", "gdsw"), ("laplace", "rgdsw"), ("elasticity", "gdsw"), ("elasticity", "rgdsw"),
                                           ("cylinder", "gdsw"), ("cylinder", "rgdsw")])
 def test_extension_solves_sixteen_columns_at_a_time(fedd_lib, problem, kind):

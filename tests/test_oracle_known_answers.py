@@ -266,6 +266,52 @@ def test_coarse_level_invariants():
     assert abs(co3.K0[0::3, 1::3]).max() == 0
 
 
+@pytest.mark.parametrize("dim,M,cells,reduced", [(3, 8, 8, False), (3, 8, 8, True), (2, 16, 16, False), (2, 12, 9, True)])
+def test_gdsw_rotations_hold_the_rigid_body_modes(dim, M, cells, reduced):
+    """CoarseGDSW(rotations=True): without Dirichlet rows every rigid-body mode of the body lies in the range of Phi (on an
+    entity a global rotation is the entity's own rotation plus a translation, and the harmonic extension of a rigid-body mode is
+    the mode, K u = 0); the dropped functions are the dependent ones -- on a lattice whose planes are mesh planes a vertex keeps
+    its translations, a straight edge 5 of 6 functions, a face all 6; and the level takes iterations off the solve."""
+    m = fo.build_mesh_structured(dim, 1, M)
+    f = (0.0, 1.0, 0.0)[:dim]
+    A_bc, rhs_bc, A, _, flags = fo.linelas_problem(m, 2.0e6, 0.4, f=f)
+    n = A.shape[0]
+    co = fo.CoarseGDSW(A, m.conn, m.xyz_uni, np.zeros(n, dtype=bool), dim, cells_target=cells, reduced=reduced, rotations=True)
+    assert co.nns == (6 if dim == 3 else 3)
+    xyz = m.xyz_uni
+    modes = []
+    for k in range(dim):
+        u = np.zeros((xyz.shape[0], dim))
+        u[:, k] = 1.0
+        modes.append(u.ravel())
+    for a, b in (((0, 1), (1, 2), (2, 0)) if dim == 3 else ((0, 1),)):
+        u = np.zeros((xyz.shape[0], dim))
+        u[:, a] = -xyz[:, b]
+        u[:, b] = xyz[:, a]
+        modes.append(u.ravel())
+    Phi = co.Phi.toarray()
+    for u in modes:
+        assert np.abs(A @ u).max() <= 1e-12 * np.abs(A).max()
+        cf = np.linalg.lstsq(Phi, u, rcond=None)[0]
+        assert np.abs(Phi @ cf - u).max() <= 1e-11 * np.abs(u).max()
+    if not reduced:
+        per_entity = co.kept.reshape(-1, co.nns).sum(axis=1)
+        if dim == 3:     # 2 x 2 x 2 cells: 8 interiors, 12 faces, 6 straight edges, 1 vertex
+            assert sorted(per_entity.tolist()) == [0] * 8 + [3] + [5] * 6 + [6] * 12
+        else:            # 4 x 4 cells: 16 interiors, 24 straight edges (2 + 1 functions), 9 vertices (2)
+            assert sorted(per_entity.tolist()) == [0] * 16 + [2] * 9 + [3] * 24
+    else:
+        assert co.kept.all()
+    is_dir = fo.dirichlet_rows(flags, (2,), dofs=dim)
+    nb_, nb, _ = fo.schwarz_bins(m.xyz_uni, 8 if dim == 3 else 9)
+    ras = fo.RAS(A_bc, nb_, nb, dofs=dim)
+    its = {}
+    for rot in (False, True):
+        c2 = fo.CoarseGDSW(A_bc, m.conn, m.xyz_uni, is_dir, dim, cells_target=cells, reduced=reduced, rotations=rot)
+        x, its[rot], _ = fo.gmres_right(A_bc, rhs_bc, lambda r: ras.apply(r) + c2.apply(r), rtol=1e-8, max_it=300, restart=100)
+    assert its[True] < its[False], its
+
+
 def test_bd_stabilization_on_the_reference_tet():
     """FE::assemblyBDStabilization (FE_def.hpp:2151-2220) on meshes/tetrahedron.mesh: P1 mass (1 + delta_ij) / 120 minus
     |K| / 16 = 1 / 96 per entry: 1/60 - 1/96 = 1/160 on the diagonal, 1/120 - 1/96 = -1/480 off it; rows sum to zero."""
