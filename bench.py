@@ -223,6 +223,21 @@ def phases(tm, steps):
     return {k: round(v[0] / steps, 4) for k, v in tm.items() if not k.startswith("_")}
 
 
+def spmv_bytes_model(si, nr):
+    """bytes one solver SpMV streams: values (8) and column ids (4) per entry + row pointer, x and y per row; with the
+    column patterns (fedd_spmv_patterns) a 2-byte pattern id per row replaces the column ids of the rows that have one"""
+    if si.get("row_classes"):
+        # row classes (k_spmv_cls): a classed row reads its 4-byte (class, pattern) word and x (8) and writes y (8) -- its values come
+        # from the class table (66 bytes per class, cache resident); the other rows stream their entries as before
+        nc, rest = si["rows_in_classes"], si["nnz_streamed_outside_classes"]
+        return 20.0 * nc + 12.0 * rest + 22.0 * (nr - nc) + 66.0 * si["row_classes"]
+    if si.get("column_patterns"):
+        return 8.0 * si["nnz_streamed"] + 22.0 * nr + 4.0 * si["nnz_streamed"] * si["rows_with_explicit_columns"] / max(nr, 1)
+    # (16-bit column offsets: 10 B per entry, 12 for the entries of the windows that keep 32-bit indices)
+    wide = si.get("entries_with_32bit_columns", 0) if si.get("column_index_bytes", 4) == 2 else 0
+    return (8.0 + si.get("column_index_bytes", 4)) * si["nnz_streamed"] + 2.0 * wide + 20.0 * nr
+
+
 def extra_per_gpu_share(capi, dev, a, its_headline):
     """The share of ONE GPU of the 8-GPU run (BASELINE cfg 3: 2 x 2 x 2 blocks of 107^3 cells), on one GPU: the same step on a
     107^3-cell cube (1 259 712 dofs) held to the iteration count of the full grid (rtol off, max_it = that count), because at
@@ -262,7 +277,7 @@ def extra_per_gpu_share(capi, dev, a, its_headline):
     return out
 
 
-def extra_cfg5_share(capi, dev, a):
+def extra_cfg5_share(capi, dev, a, only=None):
     """BASELINE cfg 5 (3D P1 linear elasticity, 189^3 nodes on 8 GPUs, two-level Schwarz) as the share of one GPU: a
     94^3-cell cube, 2 571 375 dofs, steadyLinElas_Perf parameters (mu 2e6, nu 0.4, f = (0, 1, 0), Dirichlet on flag 2, rtol 1e-6,
     restart 100; parametersProblem.xml:5-11, parametersSolver.xml), 8-node boxes; coarse level RGDSW as the XML names it, the Q1
@@ -278,8 +293,14 @@ def extra_cfg5_share(capi, dev, a):
     n = 3 * m["n_global"]
     out = {"workload": "3D P1 linear elasticity, 94^3 cells, %d dofs (one GPU's share of cfg 5), rtol 1e-6, 8-node boxes" % n}
     # (the one-level operator alone needs > 2000 iterations on this problem with 8-node boxes: not a configuration anyone runs)
-    kinds = (("q1", capi.COARSE_Q1), ("rgdsw", capi.COARSE_RGDSW), ("gdsw", capi.COARSE_GDSW))
+    # rgdsw_rotations: option gdsw_rotations, what FROSch builds from steadyLinElas/parametersPrec.xml:6, 100 (node lists and
+    # "Rotations" = true; the Perf file's coarse block has "Rotations" = false)
+    kinds = (("q1", capi.COARSE_Q1), ("rgdsw", capi.COARSE_RGDSW), ("rgdsw_rotations", capi.COARSE_RGDSW), ("gdsw", capi.COARSE_GDSW))
     for name, kind in kinds:
+        if only is not None and name not in only:
+            continue
+        c.set_option("gdsw_rotations", 1 if name.endswith("_rotations") else 0)
+
         def step():
             c.pattern_build(3, capi.BLOCK_FULL)
             c.assemble(capi.FORM_LINELAS, [lam, mu])
@@ -303,11 +324,31 @@ def extra_cfg5_share(capi, dev, a):
             nr, _, nnz = c.csr_sizes()
             si = c.spmv_info()
             ms, nl = tm["spmv"]
-            byt = (8.0 + si.get("column_index_bytes", 4)) * si["nnz_streamed"] + 20.0 * nr if not si.get("column_patterns") else \
-                8.0 * si["nnz_streamed"] + 22.0 * nr + 4.0 * si["nnz_streamed"] * si["rows_with_explicit_columns"] / max(nr, 1)
+            byt = spmv_bytes_model(si, nr)
             e["spmv"] = {"ms_per_launch": ms / max(nl, 1), "bytes_streamed": byt, "GBs": byt / (ms / max(nl, 1)) / 1e6,
                          "frac_hbm_peak": byt / (ms / max(nl, 1)) / 1e6 / HBM_PEAK_GBS, "nnz": si,
-                         "parity_csr_bytes": 12.0 * nnz + 20.0 * nr}
+                         "parity_csr_bytes": 12.0 * nnz + 20.0 * nr,
+                         "note": "the solver's kernel; on this structured grid the rows repeat (row classes): it streams a word per row "
+                                 "and is bound by the gathers of x, not by HBM -- the general kernels on the same matrix are below"}
+            # the same matrix through the kernel a mesh WITHOUT repeated rows gets (an unstructured elasticity matrix of this size):
+            # row classes off -- the 45-entry rows are longer than the pattern kernel takes, so this is the per-entry stream, values +
+            # 16-bit column offsets --, 50 launches back to back; y is the same bit for bit (tests/test_gpu_edge_cases.py)
+            c.set_option("spmv_classes", 0)
+            c.timing_enable(1)
+            c.spmv_device(5)
+            c.timing_reset()
+            c.spmv_device(50)
+            c.sync()
+            msg, nlg = c.timing_get()["spmv"]
+            c.timing_enable(0)
+            sig = c.spmv_info()
+            bg = spmv_bytes_model(sig, nr)
+            c.set_option("spmv_classes", 1)
+            e["spmv_general_kernel_back_to_back"] = {
+                "ms_per_launch": msg / max(nlg, 1), "bytes_streamed": bg, "GBs": bg / (msg / max(nlg, 1)) / 1e6,
+                "frac_hbm_peak": bg / (msg / max(nlg, 1)) / 1e6 / HBM_PEAK_GBS, "column_patterns": sig.get("column_patterns", 0),
+                "row_classes": sig.get("row_classes", 0), "column_index_bytes": sig.get("column_index_bytes", 4),
+                "note": "option spmv_classes 0: the HBM-sized, value-free case (what an unstructured mesh of this size runs)"}
             ms, nl = tm["assemble"]
             ab = 4.0 * m["conn"].size + 8.0 * 3 * m["xyz"].shape[0] + 12.0 * nnz + 4.0 * (nr + 1)
             e["assemble"] = {"ms_per_launch": ms / max(nl, 1), "bytes": ab, "frac_hbm_peak": ab / (ms / max(nl, 1)) / 1e6 / HBM_PEAK_GBS}
@@ -522,20 +563,6 @@ def main():
         return tr
 
     TIMING_STRIDE = 8       # the per-iteration kernel classes are timed every 8th launch (measure() below)
-
-    def spmv_bytes_model(si, nr):
-        """bytes one solver SpMV streams: values (8) and column ids (4) per entry + row pointer, x and y per row; with the
-        column patterns (fedd_spmv_patterns) a 2-byte pattern id per row replaces the column ids of the rows that have one"""
-        if si.get("row_classes"):
-            # row classes (k_spmv_cls): a classed row reads its 4-byte (class, pattern) word and x (8) and writes y (8) -- its values come
-            # from the class table (66 bytes per class, cache resident); the other rows stream their entries as before
-            nc, rest = si["rows_in_classes"], si["nnz_streamed_outside_classes"]
-            return 20.0 * nc + 12.0 * rest + 22.0 * (nr - nc) + 66.0 * si["row_classes"]
-        if si.get("column_patterns"):
-            return 8.0 * si["nnz_streamed"] + 22.0 * nr + 4.0 * si["nnz_streamed"] * si["rows_with_explicit_columns"] / max(nr, 1)
-        # (16-bit column offsets: 10 B per entry, 12 for the entries of the windows that keep 32-bit indices)
-        wide = si.get("entries_with_32bit_columns", 0) if si.get("column_index_bytes", 4) == 2 else 0
-        return (8.0 + si.get("column_index_bytes", 4)) * si["nnz_streamed"] + 2.0 * wide + 20.0 * nr
 
     def kernel_table(tm, m, nr, nnz, info):
         # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md section 6), this rank's share
