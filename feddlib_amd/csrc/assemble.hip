@@ -972,6 +972,7 @@ constexpr int TL_BLOBMAX = 4096;  // words of the largest blob this path takes (
 
 template <int DIM, int FORM, int BS, bool ZE = false /* doSetZeros thresholding compiled in (asm_zero_eps > 0) */>
 __global__ __launch_bounds__(BS) void k_assemble_tiles(AsmArgs a, const TileHdr* __restrict__ hdr, const uint32_t* __restrict__ blob,
+                                                        const uint32_t* __restrict__ shape_off,
                                                         int32_t ntile, int tiles_per_wg, int block_mode, int lds_el, int lds_blob, int dbg) {
     constexpr int NEN = DIM + 1, TL_PFW = (TL_BLOBMAX + BS - 1) / BS;
     constexpr int PARK = FORM == F_LAPLACE ? NEN * NEN : NEN * DIM + 1;     // element matrix | transformed gradients and |det B|
@@ -982,6 +983,7 @@ __global__ __launch_bounds__(BS) void k_assemble_tiles(AsmArgs a, const TileHdr*
     double* park = sm + ntab + (ntab & 1);                      // [lds_el][PARK]
     uint32_t* sb = reinterpret_cast<uint32_t*>(park + (size_t)lds_el * PARK);    // [lds_blob] the tile's blob (8-byte aligned)
     int32_t* pre = reinterpret_cast<int32_t*>(sb + lds_blob);   // [TL_RMAX + 1] prefix of the nodes' slot counts
+    int32_t* heavy = pre + TL_RMAX + 2;                         // [TL_RMAX] slot with the longest gather list of every node
     const int tid = threadIdx.x;
     for (int i = tid; i < ntab; i += BS) sm[i] = a.tab[i];
     // park index of value c of element e: Laplace (16 values: a 128-byte element stride would put all lanes of a store on one
@@ -996,11 +998,21 @@ __global__ __launch_bounds__(BS) void k_assemble_tiles(AsmArgs a, const TileHdr*
     auto blob_words = [&](const TileHdr& q) {
         return 2 * DIM * (int)q.NE + (int)q.NE + (int)q.R + (int)q.EL + 2 * ((int)q.R + 1) + (((int)q.NS + 1) >> 1) + (int)((q.GN + 1) >> 1);
     };
+    // words of the blob that belong to this tile alone (coordinates and ids of its extended nodes, row starts); the rest -- element
+    // records and gather lists in tile-local numbering, its SHAPE -- is read from the first tile of the same shape (shape_off,
+    // build_tile_shapes) and stays in LDS while consecutive tiles share it
+    auto own_words = [&](const TileHdr& q) { return 2 * DIM * (int)q.NE + (int)q.NE + (int)q.R; };
+    uint32_t so = shape_off[t_begin];                       // first word of the current tile's shape
+    uint32_t so_next = t_begin + 1 < t_end ? shape_off[t_begin + 1] : so;
+    uint32_t so_lds = 0xffffffffu;                          // the shape whose words are in LDS
     uint32_t pf[TL_PFW];
     {
-        const int nw = blob_words(h);
+        const int nw = blob_words(h), w0 = own_words(h);
 #pragma unroll
-        for (int u = 0; u < TL_PFW; ++u) pf[u] = tid + BS * u < nw ? blob[(size_t)h.off + tid + BS * u] : 0u;
+        for (int u = 0; u < TL_PFW; ++u) {
+            const int i = tid + BS * u;
+            pf[u] = i < nw ? blob[i < w0 ? (size_t)h.off + i : (size_t)so + (i - w0)] : 0u;
+        }
     }
     const int dofs = a.dofs;
     const bool full = block_mode == FEDD_BLOCK_FULL;
@@ -1009,17 +1021,28 @@ __global__ __launch_bounds__(BS) void k_assemble_tiles(AsmArgs a, const TileHdr*
     for (int32_t tile = t_begin; tile < t_end; ++tile) {
         const int R = h.R, NE = h.NE, EL = h.EL;
         __syncthreads();        // the previous tile is done with sb / park / pre
+        {
+            const int keep_from = so == so_lds ? own_words(h) : lds_blob;     // (uniform) the shape words in LDS are this tile's
 #pragma unroll
-        for (int u = 0; u < TL_PFW; ++u)
-            if (tid + BS * u < lds_blob) sb[tid + BS * u] = pf[u];
-        // request the next tile's blob, and the header of the one after it
+            for (int u = 0; u < TL_PFW; ++u)
+                if (tid + BS * u < keep_from) sb[tid + BS * u] = pf[u];
+            so_lds = so;
+        }
+        // request the next tile's blob (its shape only if it is another one), and the header of the tile after it
         const bool more = tile + 1 < t_end;
         const TileHdr hn = h_next;
+        const uint32_t son = so_next;
         if (more) {
-            const int nw = blob_words(hn);
+            const int w0 = own_words(hn), nw = son == so ? w0 : blob_words(hn);
 #pragma unroll
-            for (int u = 0; u < TL_PFW; ++u) pf[u] = tid + BS * u < nw ? blob[(size_t)hn.off + tid + BS * u] : 0u;
-            if (tile + 2 < t_end) h_next = hdr[tile + 2];
+            for (int u = 0; u < TL_PFW; ++u) {
+                const int i = tid + BS * u;
+                pf[u] = i < nw ? blob[i < w0 ? (size_t)hn.off + i : (size_t)son + (i - w0)] : 0u;
+            }
+            if (tile + 2 < t_end) {
+                h_next = hdr[tile + 2];
+                so_next = shape_off[tile + 2];
+            }
         }
         const double* xs = reinterpret_cast<const double*>(sb);                  // [NE][DIM] coordinates of the extended nodes
         const int32_t* nbv = reinterpret_cast<const int32_t*>(sb) + 2 * DIM * NE + NE;
@@ -1031,6 +1054,18 @@ __global__ __launch_bounds__(BS) void k_assemble_tiles(AsmArgs a, const TileHdr*
         __syncthreads();
         // slots before node p: sp[p] counts nslot + 1 offsets per node, so pre[p] = sp[p] - p (no prefix sum in the kernel)
         if (tid <= R) pre[tid] = (int)sp[tid] - tid;
+        // the slot of every node with the longest gather list (the diagonal: all 24 elements of a Kuhn-cube node against 4 - 6
+        // of an edge): phase 2 hands these to its first lanes, so that one wave walks the long lists and the others the short
+        // ones (a node's sixteen slots on sixteen consecutive lanes made EVERY wave wait for its diagonals: 3 rounds of 8 each)
+        if (h.MAXS <= 16)       // (sixteen lanes per node: one list length each, the longest by four exchanges; ties: lowest slot)
+            for (int q = tid; q < ((R * 16 + 63) & ~63); q += BS) {
+                const int p = min(q >> 4, R - 1), sl = q & 15;
+                const int s0 = (int)sp[p], ns = (int)sp[p + 1] - s0 - 1;
+                int key = sl < ns ? (((int)gslot[s0 + sl + 1] - (int)gslot[s0 + sl]) << 4) + (15 - sl) : -1;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) key = max(key, __shfl_xor(key, off, 64));
+                if (sl == 0 && (q >> 4) < R) heavy[p] = key < 0 ? 0 : 15 - (key & 15);
+            }
         // ---- phase 1: the elements of the tile, once each ----
         for (int e = tid; e < ((dbg & 1) ? 0 : EL); e += BS) {
             const uint32_t rec = el[e];
@@ -1082,9 +1117,17 @@ __global__ __launch_bounds__(BS) void k_assemble_tiles(AsmArgs a, const TileHdr*
             const int q = item / ncomp, ab = item - q * ncomp;
             int p, sl;
             if (direct) {
-                p = q >> 4;
-                sl = q & 15;
-                if (sl >= pre[p + 1] - pre[p]) continue;
+                if (q < R) {            // the nodes' longest lists first
+                    p = q;
+                    sl = heavy[p];
+                    if (pre[p + 1] - pre[p] <= 0) continue;
+                } else {                // then the other slots, fifteen places per node
+                    const int q2 = q - R;
+                    p = q2 / 15;
+                    const int s2 = q2 - p * 15, hv = heavy[p];
+                    sl = s2 + (s2 >= hv ? 1 : 0);
+                    if (sl >= pre[p + 1] - pre[p]) continue;
+                }
             } else {
                 int lo = 0, hi = R - 1;
                 while (lo < hi) {
@@ -1134,7 +1177,115 @@ __global__ __launch_bounds__(BS) void k_assemble_tiles(AsmArgs a, const TileHdr*
             a.val[start + (full ? sl * dofs + cb : sl)] = acc;
         }
         h = hn;
+        so = son;
     }
+}
+
+// ---- shapes: tiles whose element records and gather lists agree word for word (all interior tiles of a structured grid) share them ----
+// shape_off[t] = first word of tile t's shape part: its own (hdr[t].off + own words), or that of the first tile with the same
+// header counts and the same shape words.  k_tile_shape_hash: one wave per tile hashes counts and words, the tile with the
+// smallest id claims the hash; k_tile_shape_pick: every tile compares itself word by word with the claimant (a hash collision
+// or a tile of another shape keeps its own).  The kernel above then streams 3.6 instead of 10.5 KB per tile of the Kuhn cube.
+__device__ __forceinline__ uint64_t tl_mix(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+__device__ __forceinline__ int tl_own_words(const TileHdr& q, int dim) { return 2 * dim * (int)q.NE + (int)q.NE + (int)q.R; }
+__device__ __forceinline__ int tl_all_words(const TileHdr& q, int dim) {
+    return tl_own_words(q, dim) + (int)q.EL + 2 * ((int)q.R + 1) + (((int)q.NS + 1) >> 1) + (int)((q.GN + 1) >> 1);
+}
+__global__ __launch_bounds__(256) void k_tile_shape_hash(const TileHdr* __restrict__ hdr, const uint32_t* __restrict__ blob, int32_t ntile, int dim,
+                                                         unsigned long long* __restrict__ tkey, int32_t* __restrict__ trep, uint32_t tmask,
+                                                         unsigned long long* __restrict__ hash) {
+    const int32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= ntile) return;
+    const TileHdr h = hdr[t];
+    const int w0 = tl_own_words(h, dim), w1 = tl_all_words(h, dim);
+    uint64_t acc = 0;
+    for (int i = w0 + lane; i < w1; i += 64) acc += tl_mix(((uint64_t)(i - w0 + 1) << 32) ^ blob[(size_t)h.off + i]);      // order-free sum of position-keyed words
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down((unsigned long long)acc, off, 64);
+    if (lane != 0) return;
+    uint64_t key = tl_mix(acc ^ ((uint64_t)h.R << 48) ^ ((uint64_t)h.NE << 32) ^ ((uint64_t)h.EL << 16) ^ (uint64_t)h.NS ^ ((uint64_t)h.GN << 24) ^ ((uint64_t)h.MAXS << 56));
+    if (key == 0) key = 1;
+    hash[t] = key;
+    uint32_t slot = (uint32_t)(key >> 20) & tmask;
+    for (uint32_t probe = 0; probe <= tmask; ++probe) {
+        const unsigned long long prev = atomicCAS(&tkey[slot], 0ull, (unsigned long long)key);
+        if (prev == 0ull || prev == key) {
+            atomicMin(&trep[slot], t);
+            return;
+        }
+        slot = (slot + 1) & tmask;
+    }
+}
+__global__ __launch_bounds__(256) void k_tile_shape_pick(const TileHdr* __restrict__ hdr, const uint32_t* __restrict__ blob, int32_t ntile, int dim,
+                                                         const unsigned long long* __restrict__ tkey, const int32_t* __restrict__ trep, uint32_t tmask,
+                                                         const unsigned long long* __restrict__ hash, uint32_t* __restrict__ shape_off,
+                                                         int32_t* __restrict__ n_shared) {
+    const int32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= ntile) return;
+    const TileHdr h = hdr[t];
+    const int w0 = tl_own_words(h, dim), w1 = tl_all_words(h, dim);
+    const unsigned long long key = hash[t];
+    uint32_t slot = (uint32_t)(key >> 20) & tmask;
+    int32_t r = t;
+    for (uint32_t probe = 0; probe <= tmask; ++probe) {
+        const unsigned long long k2 = tkey[slot];
+        if (k2 == key) {
+            r = trep[slot];
+            break;
+        }
+        if (k2 == 0ull) break;
+        slot = (slot + 1) & tmask;
+    }
+    bool same = r != t;
+    TileHdr hr = h;
+    if (same) {
+        hr = hdr[r];
+        same = hr.R == h.R && hr.NE == h.NE && hr.EL == h.EL && hr.NS == h.NS && hr.GN == h.GN && hr.MAXS == h.MAXS;
+    }
+    if (same) {
+        uint32_t diff = 0;
+        for (int i = w0 + lane; i < w1; i += 64) diff |= blob[(size_t)h.off + i] ^ blob[(size_t)hr.off + i];
+        same = __ballot(diff != 0) == 0ull;
+    }
+    if (lane == 0) {
+        shape_off[t] = (same ? hr.off : h.off) + (uint32_t)w0;
+        if (same) atomicAdd(n_shared, 1);
+    }
+}
+
+static int build_tile_shapes(fedd_ctx* c) {
+    const int32_t nt = (int32_t)c->tl_ntile;
+    FEDD_TRY(c->tl_shape.ensure((size_t)nt));
+    uint32_t tsize = 1024;
+    while (tsize < 2u * (uint32_t)nt) tsize <<= 1;
+    // scratch: hashes [nt] | table keys [tsize] (64-bit), claimants [tsize] + counter (32-bit)
+    FEDD_TRY(c->d_cs_hash.ensure((size_t)nt + tsize));
+    FEDD_TRY(c->d_itmp0.ensure((size_t)tsize + 1));
+    unsigned long long* hash = (unsigned long long*)c->d_cs_hash.p;
+    unsigned long long* tkey = hash + nt;
+    int32_t* trep = c->d_itmp0.p;
+    FEDD_HIP(hipMemsetAsync(tkey, 0, (size_t)tsize * sizeof(unsigned long long), c->stream));
+    FEDD_HIP(hipMemsetAsync(trep, 0x7f, (size_t)tsize * sizeof(int32_t), c->stream));
+    FEDD_HIP(hipMemsetAsync(trep + tsize, 0, sizeof(int32_t), c->stream));
+    const dim3 g((unsigned)((nt + 3) / 4)), b(256);
+    hipLaunchKernelGGL(k_tile_shape_hash, g, b, 0, c->stream, (const TileHdr*)c->tl_hdr.p, (const uint32_t*)c->tl_blob.p, nt, c->dim, tkey, trep, tsize - 1, hash);
+    hipLaunchKernelGGL(k_tile_shape_pick, g, b, 0, c->stream, (const TileHdr*)c->tl_hdr.p, (const uint32_t*)c->tl_blob.p, nt, c->dim,
+                       (const unsigned long long*)tkey, (const int32_t*)trep, tsize - 1, (const unsigned long long*)hash, c->tl_shape.p, trep + tsize);
+    int32_t ns = 0;
+    FEDD_HIP(hipMemcpyAsync(&ns, trep + tsize, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    FEDD_HIP(hipStreamSynchronize(c->stream));
+    c->tl_nshared = ns;
+    FEDD_HIP(hipGetLastError());
+    return 0;
 }
 
 // the tile structures of the current mesh (host; threads over tiles).  c->tl_state = -1 when the mesh does not fit.
@@ -1867,6 +2018,7 @@ int launch_tiles(fedd_ctx* c, const AsmArgs& a, int ntab) {
         const auto t0 = std::chrono::steady_clock::now();
         if (c->asm_tiles_host) FEDD_TRY(build_tiles(c));
         else FEDD_TRY(build_tiles_device(c));
+        if (c->tl_state == 1) FEDD_TRY(build_tile_shapes(c));
         FEDD_HIP(hipStreamSynchronize(c->stream));
         c->tl_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -1874,7 +2026,7 @@ int launch_tiles(fedd_ctx* c, const AsmArgs& a, int ntab) {
     constexpr int NEN = DIM + 1, PARK = FORM == F_LAPLACE ? NEN * NEN : NEN * DIM + 1;
     static_assert(sizeof(TileHdr) == 16, "tile header");
     const int lds_el = c->tl_max_el, lds_blob = (c->tl_max_blob + 1) & ~1;
-    const size_t lds = ((size_t)ntab + 1 + (size_t)lds_el * PARK) * sizeof(double) + ((size_t)lds_blob + TL_RMAX + 2) * sizeof(uint32_t);
+    const size_t lds = ((size_t)ntab + 1 + (size_t)lds_el * PARK) * sizeof(double) + ((size_t)lds_blob + 2 * TL_RMAX + 2) * sizeof(uint32_t);
     if (lds > 96 * 1024 || lds_blob > TL_BLOBMAX) return -1;
     // Laplace: 448 lanes, the 324 elements and the 405 slots of a 3^3-node tile of the Kuhn cube each take one pass (4.27 -> 4.12 ms
     // at cfg 3); elasticity (9 items per slot: several passes anyway) is faster with 256 (94^3 cells: 2.86 against 3.34 ms)
@@ -1890,9 +2042,9 @@ int launch_tiles(fedd_ctx* c, const AsmArgs& a, int ntab) {
     const int64_t grid = (c->tl_ntile + tiles_per_wg - 1) / tiles_per_wg;
     ScopedTimer tm(c, FEDD_T_ASSEMBLE);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BS), lds, c->stream, a, (const TileHdr*)c->tl_hdr.p,
-                       (const uint32_t*)c->tl_blob.p, (int32_t)c->tl_ntile, tiles_per_wg, c->block_mode, lds_el, lds_blob, c->asm_dbg);
+                       (const uint32_t*)c->tl_blob.p, (const uint32_t*)c->tl_shape.p, (int32_t)c->tl_ntile, tiles_per_wg, c->block_mode, lds_el, lds_blob, c->asm_dbg);
     tm.stop();
-    if (c->asm_dbg & 64) fprintf(stderr, "[tiles] %lld tiles, max elements %d, blob words %d, LDS %zu bytes, %lld workgroups x %d tiles\n", (long long)c->tl_ntile, lds_el, lds_blob, lds, (long long)grid, tiles_per_wg);
+    if (c->asm_dbg & 64) fprintf(stderr, "[tiles] %lld tiles (%d read the shape of an earlier one), max elements %d, blob words %d, LDS %zu bytes, %lld workgroups x %d tiles\n", (long long)c->tl_ntile, c->tl_nshared, lds_el, lds_blob, lds, (long long)grid, tiles_per_wg);
     FEDD_HIP(hipGetLastError());
     return 0;
 }

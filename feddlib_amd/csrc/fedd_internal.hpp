@@ -192,6 +192,8 @@ struct fedd_ctx {
     int64_t tl_ntile = 0;
     int tl_max_el = 0, tl_max_ext = 0, tl_max_blob = 0;
     fedd::DevBuf<uint32_t> tl_hdr, tl_blob;     // per-tile headers (16 bytes each) and blobs (assemble.hip TileHdr)
+    fedd::DevBuf<uint32_t> tl_shape;            // [tl_ntile] first word of the shape part every tile reads (its own or an earlier tile's)
+    int tl_nshared = 0;                         // tiles that read the shape of an earlier tile
     fedd::DevBuf<int32_t> d_pat_stash;          // pattern build: merged node lists of the count pass, [k][node]
     fedd::DevBuf<int32_t> d_spmv_rows;          // CSR-stream: first row of every nnz window
     bool spmv_rows_ready = false;
