@@ -17,7 +17,7 @@ COMBINE_RESTRICTED, COMBINE_AVERAGING, COMBINE_FULL = range(3)
 (T_SYMBOLIC, T_ASSEMBLE, T_RHS, T_DIRICHLET, T_SPMV, T_SCHWARZ_SETUP, T_SCHWARZ_APPLY, T_ORTHO, T_COARSE_SETUP,
  T_COARSE_APPLY, T_HALO, T_ALLREDUCE, T_SPMV_SETUP) = range(13)
 TIMER_NAMES = ["symbolic", "assemble", "rhs", "dirichlet", "spmv", "schwarz_setup", "schwarz_apply", "ortho",
-               "coarse_setup", "coarse_apply", "halo", "allreduce", "spmv_setup", "gs_dot", "gs_update"]
+               "coarse_setup", "coarse_apply", "halo", "allreduce", "spmv_setup", "gs_dot", "gs_update", "gs_fused"]
 COARSE_Q1 = 1
 COARSE_GDSW = 2
 COARSE_RGDSW = 3
@@ -95,6 +95,7 @@ SIGNATURES = {
     "fedd_timing_get": [C.c_void_p, C.c_int, _f64p, _i64p],
     "fedd_timing_get_sampled": [C.c_void_p, C.c_int, _f64p, _i64p, _f64p],
     "fedd_gmres_info": [C.c_void_p, _ip, _ip, _ip, _ip],
+    "fedd_gmres_fused_blocks": [C.c_void_p, C.POINTER(C.c_int)],
     "fedd_gmres_x0": [C.c_void_p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int, _ip, _f64p],
     "fedd_gmres_status": [C.c_void_p, _ip, _f64p],
     "fedd_mesh_setup_info": [C.c_void_p, _f64p, _f64p, _ip, _i64p],
@@ -601,9 +602,10 @@ class Context:
         return out
 
     def gmres_info(self):
-        k, s, nb, nc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        k, s, nb, nc, nf = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _chk(self._L.fedd_gmres_info(self._h, C.byref(k), C.byref(s), C.byref(nb), C.byref(nc)))
-        return {"kind": k.value, "s": s.value, "blocks": nb.value, "cut_blocks": nc.value}
+        _chk(self._L.fedd_gmres_fused_blocks(self._h, C.byref(nf)))
+        return {"kind": k.value, "s": s.value, "blocks": nb.value, "cut_blocks": nc.value, "fused_blocks": nf.value}
 
     def read_bandwidth(self, nbytes=2 << 30, reps=10):
         """GB/s of a read-only stream on this GPU (roofline calibration)."""

@@ -834,6 +834,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     else if (k == "apply_span") c->apply_span = (int)value;
     else if (k == "gdsw_block") c->gdsw_block = value != 0.0;
     else if (k == "gdsw_rotations") c->gdsw_rot = value != 0.0;
+    else if (k == "gmres_fuse") c->gmres_fuse = (int)value;
     else if (k == "multi_ch") c->multi_ch = (int)value;
     else if (k == "spmv_col16") { c->spmv_col16 = value != 0.0; c->cs_valid = false; }
     else if (k == "pat_hash") c->pat_hash = value != 0.0;
@@ -940,6 +941,12 @@ extern "C" int fedd_gmres_info(fedd_ctx* c, int* kind, int* s, int* blocks, int*
     if (s) *s = c->gmres_s > 0 ? c->gmres_s : c->gmres_s_used;
     if (blocks) *blocks = c->gmres_blocks;
     if (cut_blocks) *cut_blocks = c->gmres_cut_blocks;
+    return 0;
+}
+
+extern "C" int fedd_gmres_fused_blocks(fedd_ctx* c, int* blocks) {
+    FEDD_CHECK(c && blocks, "fedd_gmres_fused_blocks: null argument");
+    *blocks = c->gmres_fused_blocks;
     return 0;
 }
 

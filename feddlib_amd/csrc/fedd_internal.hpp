@@ -334,6 +334,8 @@ struct fedd_ctx {
     int gm_nr = 0;                              // > 1: GMRES runs on stacked vectors X[row * gm_nr + j] (multi.hip; the GDSW extension solves)
     int multi_ch = 4;                           // option "multi_ch": matrix-core steps per flight of gathers in k_apply_multi (4, 8, 16)
     int pat_hash = 1;                           // option "pat_hash": 1 = hashed node-pattern merge for vertex-only elements (symbolic.hip)
+    int gmres_fused_blocks = 0;                 // blocks of the last s-step solve whose first update and second dot ran as one sweep
+    int gmres_fuse = -1;                        // option "gmres_fuse": s-step solver, first update and second dot of a block in one sweep (k_blockfuse); -1 = from 4 M rows on
     int gdsw_rot = 0;                           // option "gdsw_rotations": rotations in the null space of vector problems (dofs = dim)
     int co_nns = 1;                             // coarse functions per entity of the last GDSW setup (dofs, or dofs + rotations)
     fedd::DevBuf<double> d_gd_gram;             // [entities * 21] Gram matrices of the entities' functions (selection of the independent ones)
@@ -372,9 +374,9 @@ struct ScopedTimer {
             const bool per_iteration = timer == FEDD_T_SPMV || timer == FEDD_T_SCHWARZ_APPLY ||
                                        timer == FEDD_T_ORTHO || timer == FEDD_T_COARSE_APPLY ||
                                        timer == FEDD_T_HALO || timer == FEDD_T_ALLREDUCE || timer == FEDD_T_GS_DOT ||
-                                       timer == FEDD_T_GS_UPDATE;
+                                       timer == FEDD_T_GS_UPDATE || timer == FEDD_T_GS_FUSED;
             // (the s-step solver launches its sweeps once per block, each over a different number of columns: all timed)
-            const bool block_sweeps = c->gmres_kind == 2 && (timer == FEDD_T_ORTHO || timer == FEDD_T_GS_DOT || timer == FEDD_T_GS_UPDATE);
+            const bool block_sweeps = c->gmres_kind == 2 && (timer == FEDD_T_ORTHO || timer == FEDD_T_GS_DOT || timer == FEDD_T_GS_UPDATE || timer == FEDD_T_GS_FUSED);
             const int64_t k = c->timers[id].seen++;
             if (per_iteration && !block_sweeps && c->timing_stride > 1 && k % c->timing_stride != 0) return;
             sampled = true;

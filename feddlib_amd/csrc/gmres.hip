@@ -1040,6 +1040,119 @@ __global__ __launch_bounds__(256) void k_blockaxpy(double* __restrict__ V, int64
     }
 }
 
+// First update and second dot of the block Gram-Schmidt in ONE sweep (option "gmres_fuse"): a lane takes a row pair, forms
+//   W' = (W - V_k C1) R1^-1   (k_blockaxpy: all k basis columns read once, W' stored)
+// and then, with W' still in registers, the second pass' products  [V_k W']^T W'  (k_blockdot) over the same rows: the
+// basis columns are read a second time -- from the Infinity Cache, where the first read of the workgroup's rows left them
+// (tools/microbench/reread.hip: two passes over the same rows of 64 columns 1.43 ms against 2 x 0.84 for two sweeps).
+// partial[(col * S + j) * nblk + blk] as k_blockdot writes it, nblk = gridDim.x (512 rows per workgroup).
+template <int S>
+__global__ __launch_bounds__(256) void k_blockfuse(double* __restrict__ V, int64_t ldv, int64_t n, int k, int sa_req,
+                                                   const int32_t* __restrict__ d_sa, const double* __restrict__ cf,
+                                                   const double* __restrict__ rinv, double* __restrict__ partial, int nblk) {
+    constexpr int SS_CG = 2, NV = SS_CG * S;
+    static_assert(NV == 32, "block size");
+    __shared__ double sh[SS_LDS_GROUPS][4][NV];
+    const int sa = min(*d_sa, sa_req);
+    if (sa <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r = (int64_t)blockIdx.x * AX_ROWS + 2 * tid;
+    const RowPair rp = row_pair(r, n);
+    double2 w[S];
+    {
+        double2 acc[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) acc[j] = double2{0.0, 0.0};
+        int c = 0;
+        for (; c + 8 <= k; c += 8) {
+            double2 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = ldp<false>(V + (int64_t)(c + u) * ldv, rp);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < S; ++j) {
+                    const double cc = cf[(c + u) * S + j];   // wave-uniform: scalar loads
+                    acc[j].x += cc * q[u].x;
+                    acc[j].y += cc * q[u].y;
+                }
+        }
+        for (; c < k; ++c) {
+            const double2 q = ldp<false>(V + (int64_t)c * ldv, rp);
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const double cc = cf[c * S + j];
+                acc[j].x += cc * q.x;
+                acc[j].y += cc * q.y;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const double2 wv = ldp<false>(V + (int64_t)(k + (j < sa ? j : 0)) * ldv, rp);
+            acc[j].x = j < sa ? wv.x - acc[j].x : 0.0;
+            acc[j].y = j < sa ? wv.y - acc[j].y : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            double2 o = double2{0.0, 0.0};
+            if (j < sa) {
+#pragma unroll
+                for (int i = 0; i <= j; ++i) {
+                    const double ri = rinv[i * S + j];
+                    o.x += ri * acc[i].x;
+                    o.y += ri * acc[i].y;
+                }
+                double* wj = V + (int64_t)(k + j) * ldv;
+                if (rp.v1) *reinterpret_cast<double2*>(wj + r) = o;
+                else if (rp.v0) wj[r] = o.x;
+            }
+            // (rows past n: every value above came through ldp's zeros, so o is 0 there)
+            w[j] = o;
+        }
+    }
+    // ---- second pass' dot products over the same rows ----
+    const int ncol = k + sa;
+    const int ncg = (ncol + SS_CG - 1) / SS_CG;
+    int parked = 0, first_cg = 0;
+    constexpr int GRP = 64 / NV;
+    auto flush = [&](int count) {
+        __syncthreads();
+        for (int e = tid; e < count * NV; e += 256) {
+            const int g = e / NV, idx = e % NV;
+            const int col = (first_cg + g) * SS_CG + idx / S;
+            if (col < ncol) partial[((int64_t)col * S + (idx % S)) * nblk + blockIdx.x] = ((sh[g][0][idx] + sh[g][1][idx]) + sh[g][2][idx]) + sh[g][3][idx];
+        }
+        __syncthreads();
+    };
+    double2 v[SS_CG];
+    auto load_group = [&](int cg) {
+#pragma unroll
+        for (int cc = 0; cc < SS_CG; ++cc) {
+            const int col = cg * SS_CG + cc;
+            const double* __restrict__ a = V + (int64_t)(col < ncol ? col : 0) * ldv;
+            // basis columns: second and last read of this sweep (non-temporal); the block's own columns were stored above by this lane
+            v[cc] = col < k ? ldraw<true>(a, rp) : ldp<false>(a, rp);
+        }
+    };
+    load_group(0);
+    for (int cg = 0; cg < ncg; ++cg) {
+        double acc[NV];
+#pragma unroll
+        for (int cc = 0; cc < SS_CG; ++cc)
+#pragma unroll
+            for (int j = 0; j < S; ++j) acc[cc * S + j] = v[cc].x * w[j].x + v[cc].y * w[j].y;
+        if (cg + 1 < ncg) load_group(cg + 1);
+        const double tot = wave_reduce_transpose<NV>(acc, lane);
+        if ((lane & (GRP - 1)) == 0) sh[parked][wave][lane / GRP] = tot;
+        if (++parked == SS_LDS_GROUPS) {
+            flush(parked);
+            parked = 0;
+            first_cg = cg + 1;
+        }
+    }
+    if (parked) flush(parked);
+}
+
 struct Off3 {
     int Hraw, P, C1, R1, R1i, Cc, cf1, ri1, cf2, ri2, th, res;
 };
@@ -1430,7 +1543,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     const bool ghosts = c->n_cols != c->n_rows || !c->halo.peers.empty();
     FEDD_TRY(c->d_w.ensure(std::max<size_t>((size_t)2 * nc, c->d_w.cap)));   // x trial | A x trial
     FEDD_TRY(c->d_Z.ensure((size_t)nc * (nr > 1 && ghosts ? 3 : 2)));      // (stacked, several ranks: + a copy with a ghost tail)
-    FEDD_TRY(c->d_part.ensure(std::max((size_t)(m + 1 + S) * S * nblkd, (size_t)std::max(nblk, nblk2))));
+    FEDD_TRY(c->d_part.ensure(std::max((size_t)(m + 1 + S) * S * (c->gmres_fuse != 0 ? std::max(nblkd, nblk2) : nblkd), (size_t)std::max(nblk, nblk2))));
     FEDD_TRY(c->d_flags.ensure(16));
     Off o;
     Off3 o3;
@@ -1601,6 +1714,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     bool done = false;
     c->gmres_blocks = 0;
     c->gmres_cut_blocks = 0;
+    c->gmres_fused_blocks = 0;
     while (!done && its < max_it) {
         hipLaunchKernelGGL(k_ss_cycle_init, dim3(1), dim3(256), 0, st, Sx, o, o3, m, S, (const double*)(Sx + o.nrm + 3));
         hipLaunchKernelGGL(k_scale_to, gn, blk, 0, st, (const double*)r, (const double*)(Sx + o.misc + 1), V, n);
@@ -1645,18 +1759,34 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
                                    (const int32_t*)nullptr);
                 FEDD_TRY(allreduce_sum(c, Sx + o3.P, (k + sa) * S));
                 hipLaunchKernelGGL(k_ss_pass1<S>, dim3(1), blk, 0, st, Sx, o3, k, sa, chol_tol, d_sa);
-                {
-                    ScopedTimer tu(c, FEDD_T_GS_UPDATE);
-                    tu.bytes(upd_bytes);
-                    hipLaunchKernelGGL(k_blockaxpy<S>, dim3(nblk2), blk, 0, st, V, ldv, n, k, sa, (const int32_t*)d_sa,
-                                       (const double*)(Sx + o3.cf1), (const double*)(Sx + o3.ri1));
+                bool fused = false;
+                // (auto: long vectors only -- at 9.9 M rows the step gains 1.1 ms, at the 1.26 M rows of the N = 8 share the two
+                //  separate kernels are 0.15 ms ahead: their second read finds much of the basis in the Infinity Cache anyway)
+                if constexpr (S == 16) fused = c->gmres_fuse > 0 || (c->gmres_fuse < 0 && n >= 4000000);
+                if (fused) {
+                    ++c->gmres_fused_blocks;
+                    // first update + second dot in one sweep (k_blockfuse), its own class; algorithmic bytes: what the two operations
+                    // together must move once -- the basis and the block read, the block written: those of the update alone
+                    if constexpr (S == 16) {
+                        ScopedTimer tu(c, FEDD_T_GS_FUSED);
+                        tu.bytes(upd_bytes);
+                        hipLaunchKernelGGL(k_blockfuse<S>, dim3(nblk2), blk, 0, st, V, ldv, n, k, sa, (const int32_t*)d_sa,
+                                           (const double*)(Sx + o3.cf1), (const double*)(Sx + o3.ri1), c->d_part.p, nblk2);
+                    }
+                } else {
+                    {
+                        ScopedTimer tu(c, FEDD_T_GS_UPDATE);
+                        tu.bytes(upd_bytes);
+                        hipLaunchKernelGGL(k_blockaxpy<S>, dim3(nblk2), blk, 0, st, V, ldv, n, k, sa, (const int32_t*)d_sa,
+                                           (const double*)(Sx + o3.cf1), (const double*)(Sx + o3.ri1));
+                    }
+                    {
+                        ScopedTimer td(c, FEDD_T_GS_DOT);
+                        td.bytes(dot_bytes);
+                        launch_dot(gd, (const int32_t*)d_sa);
+                    }
                 }
-                {
-                    ScopedTimer td(c, FEDD_T_GS_DOT);
-                    td.bytes(dot_bytes);
-                    launch_dot(gd, (const int32_t*)d_sa);
-                }
-                hipLaunchKernelGGL(k_reduce_cols, dim3((k + sa) * S), blk, 0, st, (const double*)c->d_part.p, Sx + o3.P, nblkd,
+                hipLaunchKernelGGL(k_reduce_cols, dim3((k + sa) * S), blk, 0, st, (const double*)c->d_part.p, Sx + o3.P, fused ? nblk2 : nblkd,
                                    (const int32_t*)nullptr);
                 FEDD_TRY(allreduce_sum(c, Sx + o3.P, (k + sa) * S));
                 hipLaunchKernelGGL(k_ss_pass2<S>, dim3(1), blk, pass2_lds, st, Sx, o, o3, k, sa, m,

@@ -66,7 +66,8 @@ enum fedd_timer {
     FEDD_T_SPMV_SETUP = 12, /* compaction of the solver's SpMV stream (once per assembled matrix) */
     FEDD_T_GS_DOT   = 13, /* Gram-Schmidt sweep 1 alone: the multi-dot kernel over the Krylov basis (inside ORTHO)   */
     FEDD_T_GS_UPDATE= 14, /* Gram-Schmidt sweep 2 alone: the multi-axpy kernel over the Krylov basis (inside ORTHO)  */
-    FEDD_T_COUNT    = 15
+    FEDD_T_GS_FUSED = 15, /* s-step solver: first update and second dot of a block in one sweep, k_blockfuse (inside ORTHO) */
+    FEDD_T_COUNT    = 16
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -347,6 +348,8 @@ int fedd_schwarz_coarse_apply(fedd_ctx* ctx, const double* r_owned, double* z_ow
 /* the orthogonalisation in use ("gmres_kind") and, for the s-step form, its block length and the blocks of the last solve
  * (all, and those that were cut short because the block basis became numerically dependent); outputs may be NULL */
 int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_blocks);
+/* blocks of the last s-step solve orthogonalised with three sweeps instead of four (option "gmres_fuse": k_blockfuse) */
+int fedd_gmres_fused_blocks(fedd_ctx* ctx, int* blocks);
 
 /* tuning knobs (A/B tests), 0 is the default of each: "spmv_kind" 0 = CSR-window (CSR-stream when a row has more than 256 entries), 1 = row-per-lane-group, 2 = CSR-stream;
  * "pat_hash" 1 (default) = node pattern of vertex-only elements merged through a hash table of list positions (symbolic.hip), 0 = ordered insertion;
@@ -375,7 +378,9 @@ int fedd_gmres_info(fedd_ctx* ctx, int* kind, int* s, int* blocks, int* cut_bloc
  * to "gmres_chol_tol", default 1e-13; the convergence claim is checked against the true residual and the residual returned is
  * the true one; tolerances below 1e-9 / 1e-11 take blocks of at most 5 / 3 vectors, because the recurrence of a longer block
  * loses touch with the true residual there ("gmres_tol_blocks" 0 lifts that cap: measurements held to an iteration count
- * instead of a tolerance); "gmres_spec" n > 0: n operator applications of the next block are put into the
+ * instead of a tolerance); "gmres_fuse" 1 = blocks of 16: the first pass' update and the second pass' dot products run as one
+ * sweep (k_blockfuse: three sweeps per block; the second read of a workgroup's rows comes from the Infinity Cache), 0 = four
+ * sweeps, -1 (default) = one sweep from 4 million rows per rank on; "gmres_spec" n > 0: n operator applications of the next block are put into the
  * stream before the host reads a block's outcome, so that the GPU works through that round trip -- default 0: on one GPU the
  * round trip is not what the step waits for (tools/share_n8.py), an A/B switch for multi-GPU runs), see fedd_gmres_info;
  * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank;

@@ -16,7 +16,7 @@ fe = load(sys.argv[1], "FETCH_SIZE"); wr = load(sys.argv[2], "WRITE_SIZE")
 # (spmv: the solver's kernel -- k_spmv_cls on row classes since round 4; k_spmv_win<true, 8, false> is then the parity-CSR
 #  product of the acceptance residual and is listed on its own)
 classes = {"spmv": ("k_spmv_cls<", "k_spmv_pat<"), "spmv_parity_csr": "k_spmv_win<", "schwarz_apply": "k_apply", "assemble": ("k_assemble_pairs<", "k_assemble_tiles<"), "multidot": "k_multidot(",
-           "multiaxpy": "k_multiaxpy(", "gs_dot": ("k_multidot2", "k_blockdot<"), "gs_update": ("k_axpy2", "k_blockaxpy<"), "invert": "k_invert_reg<7"}
+           "multiaxpy": "k_multiaxpy(", "gs_dot": ("k_multidot2", "k_blockdot<"), "gs_update": ("k_axpy2", "k_blockaxpy<"), "gs_fused": "k_blockfuse<", "invert": "k_invert_reg<7"}
 # (gs_dot / gs_update: the basis grows from launch to launch; the figure is the mean over all launches of the solve, like
 # bench.py's byte model.  schwarz_apply with shared inverses is a gather kernel: the doubling of FETCH_SIZE is calibrated
 # on streaming reads and may overstate its traffic)
@@ -31,7 +31,7 @@ for key, pat in classes.items():
     wk2 = wk[:len(wk)]
     rd = 2.0 * 1024 * sum(fk2) / len(fk2)
     wrt = 1024 * sum(wk2) / max(1, len(wk2))
-    names = sorted({k.split("(")[0] for k in fe if any(p in k for p in pats)})
+    names = sorted({k.replace("(anonymous namespace)::", "").split("(")[0] for k in fe if any(p in k for p in pats)})
     out[key] = {"kernel": ", ".join(names), "read_bytes_per_launch": rd, "write_bytes_per_launch": wrt, "hbm_bytes_per_launch": rd + wrt,
                 "launches_sampled": len(fk2), "note": "FETCH_SIZE doubled (gfx950 128-B request correction), WRITE_SIZE as reported"}
 flat = {k: v["hbm_bytes_per_launch"] for k, v in out.items()}
