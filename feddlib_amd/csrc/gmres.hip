@@ -981,15 +981,20 @@ __global__ __launch_bounds__(256) void k_blockdot(const double* __restrict__ V, 
 }
 
 // W <- (W - V_k C) Rinv : cf = C [k][S] row-wise, rinv [S][S] row-wise upper triangular; columns >= sa untouched
-template <int S>
+// COMB (the block that fills a restart cycle, second update): the sweep also forms  comb = sum_{c < k + sa - 1} y_c V_c  with
+// the finished columns of the block -- the combination k_combine would read the whole basis for right afterwards (y from
+// k_backsolve over all k - 1 + sa Hessenberg columns; only valid if the block is not cut, which the host knows later)
+template <int S, bool COMB = false>
 __global__ __launch_bounds__(256) void k_blockaxpy(double* __restrict__ V, int64_t ldv, int64_t n, int k, int sa_req,
                                                    const int32_t* __restrict__ d_sa, const double* __restrict__ cf,
-                                                   const double* __restrict__ rinv) {
+                                                   const double* __restrict__ rinv, const double* __restrict__ yv = nullptr,
+                                                   double* __restrict__ comb = nullptr) {
     const int sa = min(*d_sa, sa_req);
     if (sa <= 0) return;
     const int tid = threadIdx.x;
     const int64_t r = (int64_t)blockIdx.x * AX_ROWS + 2 * tid;
     const RowPair rp = row_pair(r, n);
+    double2 cb = double2{0.0, 0.0};
     double2 acc[S];
 #pragma unroll
     for (int j = 0; j < S; ++j) acc[j] = double2{0.0, 0.0};
@@ -999,13 +1004,19 @@ __global__ __launch_bounds__(256) void k_blockaxpy(double* __restrict__ V, int64
 #pragma unroll
         for (int u = 0; u < 8; ++u) q[u] = ldp<true>(V + (int64_t)(c + u) * ldv, rp);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 8; ++u) {
 #pragma unroll
             for (int j = 0; j < S; ++j) {
                 const double cc = cf[(c + u) * S + j];   // wave-uniform: scalar loads
                 acc[j].x += cc * q[u].x;
                 acc[j].y += cc * q[u].y;
             }
+            if constexpr (COMB) {
+                const double yc = yv[c + u];
+                cb.x += yc * q[u].x;
+                cb.y += yc * q[u].y;
+            }
+        }
     }
     for (; c < k; ++c) {
         const double2 q = ldp<true>(V + (int64_t)c * ldv, rp);
@@ -1014,6 +1025,11 @@ __global__ __launch_bounds__(256) void k_blockaxpy(double* __restrict__ V, int64
             const double cc = cf[c * S + j];
             acc[j].x += cc * q.x;
             acc[j].y += cc * q.y;
+        }
+        if constexpr (COMB) {
+            const double yc = yv[c];
+            cb.x += yc * q.x;
+            cb.y += yc * q.y;
         }
     }
     double2 t[S];
@@ -1036,7 +1052,18 @@ __global__ __launch_bounds__(256) void k_blockaxpy(double* __restrict__ V, int64
             double* wj = V + (int64_t)(k + j) * ldv;
             if (rp.v1) *reinterpret_cast<double2*>(wj + r) = o;
             else if (rp.v0) wj[r] = o.x;
+            if constexpr (COMB) {
+                if (j < sa - 1) {       // (the last basis vector takes no part in the solution update)
+                    const double yc = yv[k + j];
+                    cb.x += yc * o.x;
+                    cb.y += yc * o.y;
+                }
+            }
         }
+    }
+    if constexpr (COMB) {
+        if (rp.v1) *reinterpret_cast<double2*>(comb + r) = cb;
+        else if (rp.v0) comb[r] = cb.x;
     }
 }
 
@@ -1652,10 +1679,16 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
     double* hout_dev = c->h_pinned_dev ? c->h_pinned_dev + 16 : nullptr;
 
     // xt = x + M^-1 V(:, 0:cols) y, r = b - A xt, ||r||^2 to the host: the true residual with `cols` columns of this cycle
+    // columns whose combination sum_c y_c V_c is already in r: written by the second update of a block that filled its restart
+    // cycle (k_blockaxpy<S, true>), -1: none
+    int precomb_cols = -1;
     auto trial = [&](int cols, double* true_abs) -> int {
         if (cols > 0) {
-            hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(cols + 1) * sizeof(double), st, Sx, o, cols, m);
-            hipLaunchKernelGGL(k_combine, dim3((unsigned)((n + AX_ROWS - 1) / AX_ROWS)), blk, 0, st, (const double*)V, ldv, n, cols, (const double*)(Sx + o.y), r);
+            if (cols != precomb_cols) {
+                hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(cols + 1) * sizeof(double), st, Sx, o, cols, m);
+                hipLaunchKernelGGL(k_combine, dim3((unsigned)((n + AX_ROWS - 1) / AX_ROWS)), blk, 0, st, (const double*)V, ldv, n, cols, (const double*)(Sx + o.y), r);
+            }
+            precomb_cols = -1;      // (r becomes the residual below)
             if (nr > 1) {
                 FEDD_TRY(schwarz_apply_multi(c, r, z, mk));
                 hipLaunchKernelGGL(k_axpby, gn, blk, 0, st, 1.0, (const double*)d_x, 1.0, (const double*)z, xt, n);
@@ -1796,7 +1829,21 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
                 if (!hout_dev)
                     FEDD_HIP(hipMemcpyAsync(hout + 2, Sx + o3.res, S * sizeof(double), hipMemcpyDeviceToHost, st));
                 FEDD_HIP(hipEventRecord(ev, st));
-                {
+                // a block that fills the restart cycle is followed by the solution update over all its columns: the second
+                // update forms that combination while it has the basis in hand (one read of the basis less per cycle)
+                bool comb = false;
+                if constexpr (S == 16) comb = c->gmres_fuse != 0 && nr == 1 && k - 1 + sa == m && sa >= 2;
+                precomb_cols = -1;
+                if (comb) {
+                    if constexpr (S == 16) {
+                        hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(256), (size_t)(k + sa) * sizeof(double), st, Sx, o, k - 1 + sa, m);
+                        ScopedTimer tu(c, FEDD_T_GS_UPDATE);
+                        tu.bytes(upd_bytes + 8.0 * (double)n);
+                        hipLaunchKernelGGL((k_blockaxpy<S, true>), dim3(nblk2), blk, 0, st, V, ldv, n, k, sa, (const int32_t*)d_sa,
+                                           (const double*)(Sx + o3.cf2), (const double*)(Sx + o3.ri2), (const double*)(Sx + o.y), r);
+                        precomb_cols = k - 1 + sa;
+                    }
+                } else {
                     ScopedTimer tu(c, FEDD_T_GS_UPDATE);
                     tu.bytes(upd_bytes);
                     hipLaunchKernelGGL(k_blockaxpy<S>, dim3(nblk2), blk, 0, st, V, ldv, n, k, sa, (const int32_t*)d_sa,
@@ -1824,6 +1871,7 @@ static int gmres_solve_sstep(fedd_ctx* c, const double* d_b, double* d_x, double
             const int ncolH = brk ? 1 : sa_eff;
             ++c->gmres_blocks;
             if (sa_eff < sa) ++c->gmres_cut_blocks;
+            if (sa_eff < sa || brk) precomb_cols = -1;      // (the columns behind a cut are not what y was solved for)
             FEDD_CHECK(ncolH >= 1 && ncolH <= S, "gmres (s-step): block result %d", ncolH);
             for (int i = 0; i < ncolH && !done && !restart_now; ++i) {
                 relres = hout[2 + i] / beta0;

@@ -380,7 +380,8 @@ int fedd_gmres_fused_blocks(fedd_ctx* ctx, int* blocks);
  * loses touch with the true residual there ("gmres_tol_blocks" 0 lifts that cap: measurements held to an iteration count
  * instead of a tolerance); "gmres_fuse" 1 = blocks of 16: the first pass' update and the second pass' dot products run as one
  * sweep (k_blockfuse: three sweeps per block; the second read of a workgroup's rows comes from the Infinity Cache), 0 = four
- * sweeps, -1 (default) = one sweep from 4 million rows per rank on; "gmres_spec" n > 0: n operator applications of the next block are put into the
+ * sweeps, -1 (default) = one sweep from 4 million rows per rank on; unless 0 the last update of a block that fills a restart cycle
+ * also forms the solution update sum_c y_c V_c (one read of the basis less per cycle); "gmres_spec" n > 0: n operator applications of the next block are put into the
  * stream before the host reads a block's outcome, so that the GPU works through that round trip -- default 0: on one GPU the
  * round trip is not what the step waits for (tools/share_n8.py), an A/B switch for multi-GPU runs), see fedd_gmres_info;
  * "box_kind" 0 = Schwarz boxes from one lattice over the nodes of all ranks, 1 = a lattice per rank;
