@@ -180,3 +180,28 @@ def test_elasticity_and_two_level(fedd_lib, ctx):
         b = ctx.rhs_get()
         assert np.linalg.norm(b - ctx.spmv(x2)) <= 1e-8 * np.linalg.norm(b)
         np.testing.assert_allclose(x2, x0, rtol=0, atol=1e-6 * np.abs(x0).max())
+
+
+@pytest.mark.parametrize("restart", [24, 20, 100])
+def test_three_sweeps_per_block_and_the_folded_solution_update(fedd_lib, ctx, restart):
+    """Option "gmres_fuse" (blocks of 16): the first update and the second dot of a block as one sweep (k_blockfuse), and the
+    solution update of a restart cycle formed by the last update of the block that fills the cycle (k_blockaxpy<16, true>;
+    restart 24 = 8 + 8 + 8 columns, 20: a last block of 4, 100: no cycle fills).  Same iterations as the four-sweep
+    form, same solution to rounding, true residual below the tolerance, and the direct solve at 1e-10."""
+    m, om, A_bc, rhs_bc = _setup_laplace(fedd_lib, ctx, 3, 20)
+    ctx.set_option("gmres_kind", 2)
+    ctx.set_option("gmres_s", 16)
+    res = {}
+    for fuse in (0, 1):
+        ctx.set_option("gmres_fuse", fuse)
+        x, its, rel = ctx.gmres(None, rtol=1e-9, max_it=600, restart=restart, use_prec=False)
+        info = ctx.gmres_info()
+        res[fuse] = (x, its, rel, info)
+        assert _true_relres(A_bc, rhs_bc, x) <= 1e-9
+    ctx.set_option("gmres_fuse", -1)
+    (x0, its0, _, info0), (x1, its1, _, info1) = res[0], res[1]
+    assert info0["fused_blocks"] == 0 and info1["fused_blocks"] == info1["blocks"] >= 2
+    assert abs(its0 - its1) <= 1 and (its1 > restart or restart == 100)
+    np.testing.assert_allclose(x1, x0, rtol=0, atol=1e-9 * np.abs(x0).max())
+    xd = fo.direct_solve(A_bc, rhs_bc)
+    np.testing.assert_allclose(x1, xd, rtol=0, atol=1e-7 * np.abs(xd).max())      # tolerance-limited (1e-9 residual)
