@@ -373,7 +373,7 @@ int fedd_gmres_fused_blocks(fedd_ctx* ctx, int* blocks);
  * basis grows "gmres_s" (1 ... 16; 0, the default: 16 from 1.2 million rows per rank, else 8) vectors at a time -- blocks longer than 8 on the Newton block basis ("gmres_newton" 1, the
  * default: shifts = Leja-ordered Ritz values of the first gmres_s Arnoldi steps, which run in monomial blocks of at most 8; 0 =
  * monomial basis, blocks of at most 8) -- and each block is orthogonalised by block Gram-Schmidt with two
- * passes (four sweeps over the basis and two reductions per block instead of two sweeps and one reduction per iteration; same
+ * passes (four sweeps over the basis -- three with "gmres_fuse" -- and two reductions per block instead of two sweeps and one reduction per iteration; same
  * iterates as 0 / 1 in exact arithmetic; a block is cut where the squared sine of a new vector against its predecessors falls
  * to "gmres_chol_tol", default 1e-13; the convergence claim is checked against the true residual and the residual returned is
  * the true one; tolerances below 1e-9 / 1e-11 take blocks of at most 5 / 3 vectors, because the recurrence of a longer block
