@@ -827,7 +827,7 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     }
     else if (k == "whole_boxes") c->whole_boxes = (int)value;
     else if (k == "gdsw_tol") {
-        FEDD_CHECK(value > 0.0 && value < 1.0, "fedd_set_option: gdsw_tol %g", value);
+        FEDD_CHECK(value >= 0.0 && value < 1.0, "fedd_set_option: gdsw_tol %g (0 = by coarse space)", value);
         c->gdsw_tol = value;
     } else if (k == "schwarz_dedupe") c->sw_dedupe = (int)value;
     else if (k == "schwarz_fp_kind") { c->sw_fp_kind = (int)value; c->have_schwarz = false; }

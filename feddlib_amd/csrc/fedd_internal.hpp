@@ -312,7 +312,7 @@ struct fedd_ctx {
     fedd::DevBuf<double> d_co_part, d_co_r0, d_co_z0;
     bool have_coarse = false;
     int co_kind = FEDD_COARSE_Q1;               // FEDD_COARSE_Q1 (lattice hat functions) / FEDD_COARSE_GDSW
-    double gdsw_tol = 1e-4;                     // option "gdsw_tol": relative residual of the interior extension solves
+    double gdsw_tol = 0.0;                      // option "gdsw_tol": relative residual of the interior extension solves; 0 = GDSW 1e-4, RGDSW 1e-3
     int gdsw_ext_its = 0;                       // most iterations / largest final residual of the last setup's extension solves
     double gdsw_ext_rel = 0.0;
     fedd::DevBuf<int32_t> d_gd_ent;             // [n_own] interface entity (doubled-lattice id) of every owned node

@@ -272,7 +272,7 @@ int fedd_spmv_info(fedd_ctx* ctx, int64_t* nnz_pattern, int64_t* nnz_streamed);
  * interface nodes are classified into the faces / edges / vertices between the cells, the coarse basis is the null space
  * (constants per dof component: what FROSch has without node coordinates, parametersPrec.xml:5 "Use node lists" = false)
  * restricted to each interface component and extended discrete-harmonically into the cell interiors (device GMRES +
- * one-level Schwarz on the constrained operator, option "gdsw_tol", default 1e-4: the outer iteration count is that of exact extensions down to there, see
+ * one-level Schwarz on the constrained operator, option "gdsw_tol", default 1e-4 for GDSW and 1e-3 for RGDSW: the outer iteration count is that of exact extensions down to there, see
  * profiles/r02_gdsw_tol_sweep.txt and r03_gdsw_tol_sweep_stacked.txt; the parity tests ask for 1e-13; option "gdsw_block" 1 (default) = sixteen columns at a
  * time as one stacked system over an SpMM and a matrix-core Schwarz apply, multi.hip, 0 = column by column; "multi_ch" 4 / 8 / 16 = matrix-core
  * steps per flight of gathers of that apply), K0 = Phi^T A Phi inverted on the
