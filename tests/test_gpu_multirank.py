@@ -881,17 +881,21 @@ def _thread_rank_cut(capi, group, rank, dec, M, out, errs):
         c.schwarz_set_target(27, 1.0)
         c.schwarz_setup(1, capi.COMBINE_RESTRICTED)
         res = {}
-        for name, opts, rtol in (("cut", {"gmres_s": 8, "gmres_chol_tol": 0.5}, 1e-10),
-                                 ("claims", {"gmres_s": 16, "gmres_tol_blocks": 0}, 1e-13),
-                                 ("spec", {"gmres_s": 8, "gmres_spec": 2}, 1e-10)):
+        # fused: three sweeps per block (k_blockfuse) and the solution update folded into the last update of every restart
+        # cycle (restart 20 = 8 + 8 + 4 columns, no preconditioner: several cycles), the reductions between them all-reduced
+        for name, opts, rtol, restart, prec in (("cut", {"gmres_s": 8, "gmres_chol_tol": 0.5}, 1e-10, 50, True),
+                                                ("claims", {"gmres_s": 16, "gmres_tol_blocks": 0}, 1e-13, 50, True),
+                                                ("spec", {"gmres_s": 8, "gmres_spec": 2}, 1e-10, 50, True),
+                                                ("fused", {"gmres_s": 16, "gmres_fuse": 1}, 1e-10, 20, False)):
             for k, v in opts.items():
                 c.set_option(k, v)
-            x, its, rel = c.gmres(None, rtol=rtol, max_it=600, restart=50, use_prec=True)
+            x, its, rel = c.gmres(None, rtol=rtol, max_it=600, restart=restart, use_prec=prec)
             res[name] = dict(x=x, its=its, rel=rel, info=c.gmres_info(), status=c.gmres_status())
             c.set_option("gmres_chol_tol", 1e-13)
             c.set_option("gmres_tol_blocks", 1)
             c.set_option("gmres_spec", 0)
             c.set_option("gmres_s", 0)
+            c.set_option("gmres_fuse", -1)
         out[rank] = dict(gu=m["gid_uni"], res=res, selftest=selftest)
         c.close()
     except Exception as e:      # pragma: no cover
@@ -926,7 +930,7 @@ def test_cut_blocks_and_failed_claims_keep_the_ranks_in_step(fedd_lib):
     A_bc, rhs_bc, _, _, _ = fo.laplace_problem(om)
     xd = fo.direct_solve(A_bc, rhs_bc)
     assert max(o["selftest"] for o in out) <= 1e-9
-    for name, tol in (("cut", 1e-7), ("claims", 1e-10), ("spec", 1e-7)):
+    for name, tol in (("cut", 1e-7), ("claims", 1e-10), ("spec", 1e-7), ("fused", 1e-7)):
         assert len({o["res"][name]["its"] for o in out}) == 1, name
         assert len({o["res"][name]["rel"] for o in out}) == 1, name
         assert len({(o["res"][name]["info"]["blocks"], o["res"][name]["info"]["cut_blocks"]) for o in out}) == 1, name
@@ -937,3 +941,5 @@ def test_cut_blocks_and_failed_claims_keep_the_ranks_in_step(fedd_lib):
         assert abs(out[0]["res"][name]["rel"] - tr) <= 0.05 * tr + 1e-16, (name, out[0]["res"][name]["rel"], tr)
         np.testing.assert_allclose(x, xd, rtol=0, atol=tol * np.abs(xd).max())
     assert out[0]["res"]["cut"]["info"]["cut_blocks"] >= 1
+    fi = out[0]["res"]["fused"]
+    assert fi["info"]["fused_blocks"] == fi["info"]["blocks"] >= 4 and fi["its"] > 40, fi["info"]
