@@ -10,7 +10,9 @@ PARITY STATUS
     NO golden numbers (every test passes on exit code only) and cannot be
     built here (Trilinos/Boost/METIS absent), so this half is pinned by analytic known-answer
     tests only (tests/test_oracle_known_answers.py): reference-tet stiffness/mass/rhs,
-    quadrature exactness, partition of unity, Kuhn-cube 7-point stencil, rigid-body modes.
+    quadrature exactness, partition of unity, Kuhn-cube 7-point stencil, rigid-body modes, and the
+    whole chain generator -> assembly -> Dirichlet rows -> solve against the Fourier-series value of
+    -Laplace u = 1 at the centre of the unit cube (second-order convergence).
     => "parity unpinned" in the sense of the task statement: no reference-produced vector exists.
   * solve half (GMRES + one-level overlapping Schwarz): the arithmetic lives in Trilinos
     (Belos / ShyLU_DDFROSch / Amesos2-KLU), an un-vendored and un-pinned dependency of the
