@@ -539,3 +539,52 @@ def test_p2_path_converges_to_the_analytic_solution_at_fourth_order(fedd_lib):
         c.close()
     assert err[16] < 1e-6
     assert 12.0 <= err[4] / err[8] <= 20.0 and 12.0 <= err[8] / err[16] <= 20.0, err
+
+
+@pytest.mark.parametrize("dim,M,p2", [(3, 10, False), (2, 24, False), (3, 6, True)])
+def test_assembled_forms_hold_their_integral_identities(fedd_lib, dim, M, p2):
+    """Identities of the forms themselves, no oracle involved: the mass matrix sums to the volume of the unit box (1), the
+    load vector of f = 1 too, constants lie in the kernel of the stiffness matrix (row sums 0), x^T K x of a linear function x is
+    the integral of |grad|^2 (= 1 for u = x_0), and elasticity annihilates the rigid-body modes."""
+    c = fedd_lib.Context(device=0)
+    try:
+        m = fedd_lib.structured_mesh(dim, 1, M)
+        if p2:
+            m = fedd_lib.p2_of_p1(m, volume_id=0)
+        n = m["n_global"]
+        c.mesh_set_dict(m)
+        c.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+        c.assemble(fedd_lib.FORM_MASS)
+        Mm, _ = csr_global(c, n)
+        assert abs(Mm.sum() - 1.0) <= 1e-12
+        c.assemble(fedd_lib.FORM_LAPLACE)
+        K, _ = csr_global(c, n)
+        assert np.abs(K @ np.ones(n)).max() <= 1e-12 * np.abs(K).max()
+        xyz = np.zeros((n, dim))
+        xyz[m["gid_rep"]] = m["xyz"]
+        u = xyz[:, 0]
+        assert abs(u @ (K @ u) - 1.0) <= 1e-12
+        c.assemble_rhs([1.0])
+        b = np.zeros(n)
+        b[m["gid_uni"]] = c.rhs_get()
+        assert abs(b.sum() - 1.0) <= 1e-12
+        if not p2:
+            mu, nu = 2.0e6, 0.4
+            lam = 2.0 * mu * nu / (1.0 - 2.0 * nu)
+            c.pattern_build(dim, fedd_lib.BLOCK_FULL)
+            c.assemble(fedd_lib.FORM_LINELAS, [lam, mu])
+            E, _ = csr_global(c, dim * n)
+            modes = []
+            for k in range(dim):
+                v = np.zeros((n, dim))
+                v[:, k] = 1.0
+                modes.append(v.ravel())
+            for a, b2 in (((0, 1), (1, 2), (2, 0)) if dim == 3 else ((0, 1),)):
+                v = np.zeros((n, dim))
+                v[:, a] = -xyz[:, b2]
+                v[:, b2] = xyz[:, a]
+                modes.append(v.ravel())
+            for v in modes:
+                assert np.abs(E @ v).max() <= 1e-11 * np.abs(E).max()
+    finally:
+        c.close()
