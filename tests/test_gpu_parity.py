@@ -588,3 +588,32 @@ def test_assembled_forms_hold_their_integral_identities(fedd_lib, dim, M, p2):
                 assert np.abs(E @ v).max() <= 1e-11 * np.abs(E).max()
     finally:
         c.close()
+
+
+def test_analytic_solution_at_the_centre_of_the_square(fedd_lib):
+    """The 2D generator and assembly against the same kind of known answer: -Laplace u = 1 on the unit square, u = 0 on its
+    boundary, u(1/2, 1/2) = sum over odd i, j of 16 (-1)^((i + j - 2) / 2) / (pi^4 i j (i^2 + j^2)) = 0.0736713533...; second order."""
+    u_exact = 0.07367135328
+    err = {}
+    c = fedd_lib.Context(device=0)
+    try:
+        for M in (16, 32, 64, 128):
+            m = fedd_lib.structured_mesh(2, 1, M)
+            c.mesh_set_dict(m)
+            c.pattern_build(1, fedd_lib.BLOCK_SCALAR)
+            c.assemble(fedd_lib.FORM_LAPLACE)
+            c.assemble_rhs([1.0])
+            c.dirichlet([1, 2, 3], [0.0, 0.0, 0.0])
+            c.schwarz_set_target(9, 1.0)
+            c.schwarz_setup(overlap=1, combine=fedd_lib.COMBINE_RESTRICTED)
+            x, its, rel = c.gmres(None, rtol=1e-12, max_it=3000, restart=200, use_prec=True)
+            assert rel <= 1e-11
+            centre = np.nonzero(np.all(np.abs(m["xyz"] - 0.5) < 1e-12, axis=1))[0]
+            assert centre.shape[0] == 1
+            pos = np.nonzero(m["gid_uni"] == m["gid_rep"][centre[0]])[0][0]
+            err[M] = abs(x[pos] - u_exact)
+    finally:
+        c.close()
+    assert err[128] < 2e-5, err
+    for M in (32, 64, 128):
+        assert 3.0 <= err[M // 2] / err[M] <= 5.0, err
