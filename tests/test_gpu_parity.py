@@ -586,6 +586,15 @@ def test_assembled_forms_hold_their_integral_identities(fedd_lib, dim, M, p2):
                 modes.append(v.ravel())
             for v in modes:
                 assert np.abs(E @ v).max() <= 1e-11 * np.abs(E).max()
+            # a linear displacement u = G x: constant strain eps = sym(G), so the interior nodal forces vanish and the energy is
+            # the integral of 2 mu eps : eps + lam tr(eps)^2 over the unit box -- this pins both Lame coefficients
+            G = np.random.default_rng(3).standard_normal((dim, dim))
+            v = (xyz @ G.T).ravel()
+            eps = 0.5 * (G + G.T)
+            energy = 2.0 * mu * np.sum(eps * eps) + lam * np.trace(eps) ** 2
+            assert abs(v @ (E @ v) - energy) <= 1e-11 * energy
+            interior = np.repeat(np.all((xyz > 1e-9) & (xyz < 1.0 - 1e-9), axis=1), dim)
+            assert np.abs((E @ v)[interior]).max() <= 1e-10 * np.abs(E).max() * np.abs(v).max()
     finally:
         c.close()
 
