@@ -591,7 +591,9 @@ def main():
                 kern[k] = dict(ms_per_launch=ms / nl, launches=nl, total_ms=ms, GBs=b / (ms / nl) / 1e6, bytes=b)
         if "schwarz_apply" in kern:
             kern["schwarz_apply"]["distinct_inverses"] = info["n_unique"]
-            kern["schwarz_apply"]["kernel"] = "k_apply_mfma (shared inverses)" if shared and info["n_subdomains"] >= 4096 else "k_apply_flat"
+            bt = info.get("n_conforming") == info["n_subdomains"]     # every box conforms: the batch-table kernel runs
+            kern["schwarz_apply"]["kernel"] = (("k_apply_bt (batch table, shared inverses)" if bt else "k_apply_mfma (shared inverses)")
+                                               if shared and info["n_subdomains"] >= 4096 else "k_apply_flat")
         # the sweeps of the Gram-Schmidt process over the Krylov basis (gmres.hip): the launch sites state their algorithmic
         # bytes -- DCGS2 (gmres_kind 0): sweep 1 reads the k final columns, u and B u, sweep 2 reads them again and writes
         # v_{k+1} and the next u; s-step (gmres_kind 2): a dot sweep reads the k final columns and the s block columns, an

@@ -832,6 +832,8 @@ extern "C" int fedd_set_option(fedd_ctx* c, const char* key, double value) {
     } else if (k == "schwarz_dedupe") c->sw_dedupe = (int)value;
     else if (k == "schwarz_fp_kind") { c->sw_fp_kind = (int)value; c->have_schwarz = false; }
     else if (k == "apply_span") c->apply_span = (int)value;
+    else if (k == "apply_dbg") c->apply_dbg = (int)value;
+    else if (k == "apply_bt") c->apply_bt = (int)value;
     else if (k == "gdsw_block") c->gdsw_block = value != 0.0;
     else if (k == "gdsw_rotations") c->gdsw_rot = value != 0.0;
     else if (k == "gmres_fuse") c->gmres_fuse = (int)value;

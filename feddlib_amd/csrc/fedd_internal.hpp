@@ -280,6 +280,7 @@ struct fedd_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int64_t sw_nconf = 0;                       // subdomains whose dof list is their representative's list shifted (ids computed in the apply)
     int64_t sw_nint = -1;                       // subdomains without ghost dofs at the front of d_sw_order (-1: not split)
+    int apply_dbg = 0;                          // ablation bits of k_apply_mfma<4, 12> (development; wrong results by design)
     int apply_span = 0;                         // grouped apply: subdomains per workgroup (0 = 64)
     int sw_dedupe = 1;                          // option "schwarz_dedupe": subdomains with the same local matrix share one slab
     int sw_fp_kind = 0;                         // option "schwarz_fp_kind": fingerprints from row hashes (0) or entry by entry (1)
@@ -288,6 +289,11 @@ struct fedd_ctx {
     fedd::DevBuf<uint64_t> d_sw_fp;             // fingerprints [2 nsub] | hash table keys [2 tsize]
     fedd::DevBuf<int32_t> d_sw_order;           // subdomains sorted by representative [nsub] | sort scratch [2 nsub] | pad | records int4[nsub]
     int64_t sw_order_off = 0;                   // where the records start (in int32 units, 16-byte aligned)
+    fedd::DevBuf<int32_t> d_sw_bt;              // batch table of k_apply_bt: BT_W ints per batch (schwarz.hip)
+    fedd::DevBuf<int32_t> d_sw_btw;             // ... its build scratch
+    int64_t sw_nbatch = 0;                      // batches in the table (0: no table, the chunk-record kernel runs)
+    int64_t sw_nbatch_int = 0;                  // ... of which belong to the subdomains without ghost dofs (split order)
+    int apply_bt = 1;                           // build and use the batch table (option "apply_bt")
     fedd::DevBuf<int32_t> d_sw_replist;         // the representatives (the subdomains that are inverted)
     fedd::DevBuf<int32_t> d_sw_rep;             // representative [nsub] | sizes for the inversion [nsub] | slot [nsub] | table min [tsize]
     int sw_big = -1;                            // large-subdomain path: -1 = for merged block systems, 0 = never, 1 = always

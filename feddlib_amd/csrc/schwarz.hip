@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_apply_flat(const int32_t* __restrict__ 
 // Without the sharing the slabs stream from HBM once per apply and the flat kernel above is the right one.
 typedef double ap_d4 __attribute__((ext_vector_type(4)));
 constexpr int AM_MB = 16;
-template <int RT, int KW>   // owned rows <= 16 RT, columns <= 16 KW
+template <int RT, int KW, int ABL = 0>   // owned rows <= 16 RT, columns <= 16 KW; ABL: ablation bits of tools/ab_apply.py (1 no gathers of r, 2 no stores of z, 4 no exchange of the partial tiles, 8 no products)
 __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <= 12) ? 2 : 1)) void k_apply_mfma(const int4* __restrict__ order, const int32_t* __restrict__ sub_dofs,
                                                     const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
                                                     const double* __restrict__ r, double* __restrict__ z, int32_t nsub, int span) {
@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
 #pragma unroll
             for (int kk = 0; kk < KW; ++kk) {
                 const int c = 4 * (w + 4 * kk) + lk;
-                bv[kk] = (lj < mb && c < n) ? r[ids[buf][lj][c]] : 0.0;
+                bv[kk] = (ABL & 1) ? (double)(c + lj) : ((lj < mb && c < n) ? r[ids[buf][lj][c]] : 0.0);
             }
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
@@ -1188,9 +1188,12 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         for (int t = 0; t < RT; ++t) acc[t] = ap_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk)
-            if (4 * (w + 4 * kk) < n) {     // (uniform over the wave)
+            if ((ABL & 32) || 4 * (w + 4 * kk) < n) {     // (uniform over the wave)
 #pragma unroll
-                for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][kk], bv[kk], acc[t], 0, 0, 0);
+                for (int t = 0; t < RT; ++t) {
+                    if (ABL & 8) acc[t][kk & 3] += a[t][kk] * bv[kk];
+                    else acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][kk], bv[kk], acc[t], 0, 0, 0);
+                }
             }
         // (uniform) the next batch's entries of r and its output rows (first dof + offset): the fragments of this batch are
         // spent, the gathers fly while the partial tiles are exchanged, added and stored
@@ -1201,7 +1204,7 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
 #pragma unroll
             for (int kk = 0; kk < KW; ++kk) {
                 const int c = 4 * (w + 4 * kk) + lk;
-                bv[kk] = (lj < mb_n && c < n_n) ? r[a0n + soff[c]] : 0.0;
+                bv[kk] = (ABL & 1) ? (double)(c + a0n) : ((lj < mb_n && c < n_n) ? r[a0n + soff[c]] : 0.0);
             }
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
@@ -1209,14 +1212,19 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
                 od_p[t] = (lj < mb_n && i < nrow_n) ? a0n + soff[i] : -1;
             }
         }
+        if (!(ABL & 4)) {
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
+            for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) part[w][t][q][lane] = acc[t][q];
-        __syncthreads();
+                for (int q = 0; q < 4; ++q) part[w][t][q][lane] = acc[t][q];
+        }
+        if (!(ABL & 16)) __syncthreads();
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
-            if (od[t] >= 0) z[od[t]] = ((part[0][t][w][lane] + part[1][t][w][lane]) + part[2][t][w][lane]) + part[3][t][w][lane];
+        for (int t = 0; t < RT; ++t) {
+            const double sum = (ABL & 4) ? ((acc[t][0] + acc[t][1]) + acc[t][2]) + acc[t][3]
+                                         : ((part[0][t][w][lane] + part[1][t][w][lane]) + part[2][t][w][lane]) + part[3][t][w][lane];
+            if (od[t] >= 0 && (!(ABL & 2) || sum == 1.2345e300)) z[od[t]] = sum;
+        }
         if (last) break;
         if (!direct_n) park_ids(buf ^ 1, v);
         if (cross) {        // (uniform) next chunk: its records were requested a chunk ago; request the one after it
@@ -1224,7 +1232,7 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
             hdr = hdr_n;
             hdr_n = p_chunk + 64 + lane < p_end ? order[p_chunk + 64 + lane] : none;
         }
-        __syncthreads();    // part and ids[buf] are rewritten by the next batch; ids[buf ^ 1] is complete
+        if (!(ABL & 16)) __syncthreads();    // part and ids[buf] are rewritten by the next batch; ids[buf ^ 1] is complete
         buf ^= 1;
         direct = direct_n;
         pos = pos_n;
@@ -1234,6 +1242,217 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
     }
 }
 
+
+// The same batched product on a BATCH TABLE (round 4, the default when every subdomain conforms).  What bounds k_apply_mfma is
+// neither its gathers nor the matrix cores: with the gathers of r, the stores of z and the exchange of the partial tiles
+// taken out it still runs 103 of its 127 us at 214^3 cells, while its 48 matrix instructions per wave and batch alone
+// sustain 69-74 TFLOP/s on this chip (tools/microbench/mfma_f64.hip: 57 us for the same products).  The rest is the
+// instruction stream around them -- chunk records, ballots and bit scans to find the batch boundaries, predicated loads
+// compiled to one exec-mask branch each, the list path woven through the loop --, some 3 000 cycles per wave and batch,
+// which the two waves of a SIMD run through together instead of one under the other's matrix instructions.
+// Here the batches are cut at setup (k_bt_*: one descriptor of 20 ints per batch: representative, sizes, subdomains in
+// the batch, subdomain of the inverse, the sixteen first dofs -- absent ones repeat the first), the control values of a
+// batch are wave-uniform scalars, every gather is unconditional (columns beyond the list read the first dof: their entries
+// of A are zero), and the entry of r the NEXT batch needs in a fragment register is requested as soon as the last product
+// of this batch that reads the register has been issued -- between the matrix instructions, not behind them.  Products
+// and summation order are those of k_apply_mfma: the same bits.
+constexpr int BT_W = 20;    // ints per batch descriptor: rep | n + (nrow << 10) | subdomains | subdomain of the inverse | first dofs [16]
+template <int RT, int KW, bool DBG = false>   // owned rows <= 16 RT, columns <= 16 KW; DBG: phase clocks of one wave (development)
+__global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <= 12) ? 2 : 1)) void k_apply_bt(const int32_t* __restrict__ bt, const int32_t* __restrict__ sub_dofs,
+                                                    const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
+                                                    const double* __restrict__ r, double* __restrict__ z, int32_t nbatch, int bspan) {
+    __shared__ double part[4][RT][4][64];
+    __shared__ int32_t soff[16 * KW];       // dof offsets of a representative's list (entries beyond the list: 0)
+    long long t_begin = 0, t_loop = 0;
+    int n_reload = 0;
+    if (DBG) t_begin = __builtin_readcyclecounter();
+    const int tid = threadIdx.x, lane = tid & 63, lj = lane & 15, lk = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-contiguous ranges (neighbouring boxes gather overlapping parts of r: one L2)
+    const int nwg = gridDim.x, q_ = nwg >> 3, rem_ = nwg & 7, xcd_ = blockIdx.x & 7, within_ = blockIdx.x >> 3;
+    const int wg = (xcd_ < rem_ ? xcd_ * (q_ + 1) : rem_ * (q_ + 1) + (xcd_ - rem_) * q_) + within_;
+    int32_t b = wg * bspan;
+    const int32_t b_end = min(nbatch, b + bspan);
+    if (b >= b_end) return;
+    const int4* __restrict__ bt4 = reinterpret_cast<const int4*>(bt);
+    int4 h = bt4[(int64_t)b * (BT_W / 4)];
+    int32_t a0 = bt[(int64_t)b * BT_W + 4 + lj];
+    int4 hn = make_int4(-1, 0, 0, 0);
+    int32_t a0n = 0;
+    if (b + 1 < b_end) {
+        hn = bt4[(int64_t)(b + 1) * (BT_W / 4)];
+        a0n = bt[(int64_t)(b + 1) * BT_W + 4 + lj];
+    }
+    int32_t so_rep = -1, cur = -1;
+    // (all lanes; the caller puts a barrier behind it)
+    auto write_offsets = [&](int32_t rp_, int n_) {
+        const int32_t* __restrict__ ref = sub_dofs + (int64_t)rp_ * NMAX;
+        const int32_t r0 = ref[0];
+        if (tid < 16 * KW) soff[tid] = ref[tid < n_ ? tid : 0] - r0;
+        so_rep = rp_;
+    };
+    // the rows this lane writes at the end: result register w of tile t = row 16 t + lk + 4 w of subdomain lj
+    auto out_rows = [&](const int4& hh, int32_t a0_, int32_t (&o)[RT]) {
+        const int32_t pk = __builtin_amdgcn_readfirstlane(hh.y), mb_ = __builtin_amdgcn_readfirstlane(hh.z);
+        const int nrow_ = (pk >> 10) & 1023;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int i = 16 * t + lk + 4 * w;
+            const int32_t so = soff[i < 16 * KW ? i : 0];
+            o[t] = (lj < mb_ && i < nrow_) ? a0_ + so : -1;
+        }
+    };
+    double a[RT][KW], bv[KW];
+    int32_t od[RT], odn[RT];
+    {
+        const int32_t pk = __builtin_amdgcn_readfirstlane(h.y);
+        write_offsets(__builtin_amdgcn_readfirstlane(h.x), pk & 1023);
+        __syncthreads();
+        // B fragments: lane (k, j) = entry 4 step + k of subdomain j's restriction of r
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) bv[kk] = r[a0 + soff[4 * (w + 4 * kk) + lk]];
+        out_rows(h, a0, od);
+    }
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    int nbt = 0;
+    if (DBG) t_loop = __builtin_readcyclecounter();
+    for (;;) {
+        long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if (DBG) t0 = __builtin_readcyclecounter();
+        const int32_t rp = __builtin_amdgcn_readfirstlane(h.x), packed = __builtin_amdgcn_readfirstlane(h.y);
+        const int n = packed & 1023, nrow = (packed >> 10) & 1023;
+        if (rp != cur) {    // (uniform) this lane's A fragments of the new inverse
+            const double* __restrict__ src = inv + inv_ptr[__builtin_amdgcn_readfirstlane(h.w)];
+            // (all loads first, unconditional on a clamped index, then the entries outside the slab to zero: with the
+            // predicate in the load each of the RT KW loads waited for its own data)
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk) {
+                const int c = 4 * (w + 4 * kk) + lk;
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const int i = 16 * t + lj;
+                    a[t][kk] = __builtin_nontemporal_load(src + ((c < n && i < nrow) ? c * nrow + i : 0));
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk) {
+                const int c = 4 * (w + 4 * kk) + lk;
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+                    if (!(c < n && 16 * t + lj < nrow)) a[t][kk] = 0.0;
+            }
+            cur = rp;
+            if (DBG) ++n_reload;
+        }
+        const bool more = b + 1 < b_end;    // (uniform)
+        int4 h2 = make_int4(-1, 0, 0, 0);
+        int32_t a02 = 0;
+        if (more) {
+            const int32_t rpn = __builtin_amdgcn_readfirstlane(hn.x);
+            if (rpn != so_rep) {    // (uniform, rare) the next batch has another representative: its offsets
+                write_offsets(rpn, __builtin_amdgcn_readfirstlane(hn.y) & 1023);
+                __syncthreads();
+            }
+            out_rows(hn, a0n, odn);
+            if (b + 2 < b_end) {
+                h2 = bt4[(int64_t)(b + 2) * (BT_W / 4)];
+                a02 = bt[(int64_t)(b + 2) * BT_W + 4 + lj];
+            }
+        }
+        if (DBG) t1 = __builtin_readcyclecounter();
+        ap_d4 acc[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = ap_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) {
+            if (4 * (w + 4 * kk) < n) {     // (scalar)
+#pragma unroll
+                for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][kk], bv[kk], acc[t], 0, 0, 0);
+            }
+            // this step's fragment is spent: the next batch's entry of r takes its place and flies while the remaining steps are
+            // multiplied and the partial tiles exchanged and stored (unconditional: columns beyond the list read the first dof
+            // against entries of A that are zero)
+            if (more) bv[kk] = r[a0n + soff[4 * (w + 4 * kk) + lk]];
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[w][t][q][lane] = acc[t][q];
+        if (DBG) t2 = __builtin_readcyclecounter();
+        __syncthreads();
+        if (DBG) t3 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+            if (od[t] >= 0) z[od[t]] = ((part[0][t][w][lane] + part[1][t][w][lane]) + part[2][t][w][lane]) + part[3][t][w][lane];
+        if (DBG) {
+            t4 = __builtin_readcyclecounter();
+            tk[0] += t1 - t0;
+            tk[1] += t2 - t1;
+            tk[2] += t3 - t2;
+            tk[3] += t4 - t3;
+            ++nbt;
+        }
+        if (!more) break;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) od[t] = odn[t];
+        h = hn;
+        a0 = a0n;
+        hn = h2;
+        a0n = a02;
+        ++b;
+        __syncthreads();    // part is rewritten by the next batch
+        if (DBG) tk[4] += __builtin_readcyclecounter() - t4;
+    }
+    if (DBG && tid == 0 && (blockIdx.x % 31 == 0 || blockIdx.x + 8 >= gridDim.x)) {
+        const long long t_end = __builtin_readcyclecounter();
+        printf("[k_apply_bt] wg %4d (range %4d): begin %lld, prologue %lld, loop %lld ticks; %d batches, %d inverses; per batch: top %lld, products %lld, "
+               "barrier %lld, sum + stores %lld, rotate + barrier %lld\n", (int)blockIdx.x, wg, t_begin & 0xffffff, t_loop - t_begin, t_end - t_loop, nbt,
+               n_reload, tk[0] / nbt, tk[1] / nbt, tk[2] / nbt, tk[3] / nbt, tk[4] / max(nbt - 1, 1));
+    }
+}
+
+// ---- the batch table of k_apply_bt (setup) ----
+// a run = consecutive places of the apply order with the same representative and sizes (and not across `p_cut`, the first
+// place of the subdomains with ghost dofs when the order is split); a batch = up to sixteen consecutive places of a run
+__global__ void k_bt_flag(const int4* __restrict__ rec, int32_t n, int32_t p_cut, int32_t* __restrict__ start) {
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    bool s = p == 0 || p == p_cut;
+    if (!s) {
+        const int4 a = rec[p], b = rec[p - 1];
+        s = a.y != b.y || a.z != b.z;
+    }
+    start[p] = s ? 1 : 0;
+}
+// run_first[run] = first place of the run (runid = exclusive scan of the flags, +1 at a start - 1 = the run of place p)
+__global__ void k_bt_run_first(const int32_t* __restrict__ start, const int32_t* __restrict__ scan, int32_t n, int32_t nruns,
+                               int32_t* __restrict__ run_first) {
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0) run_first[nruns] = n;
+    if (p < n && start[p]) run_first[scan[p]] = p;
+}
+__global__ void k_bt_batch_flag(const int32_t* __restrict__ start, const int32_t* __restrict__ scan, const int32_t* __restrict__ run_first,
+                                int32_t n, int32_t* __restrict__ bflag) {
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t run = scan[p] + start[p] - 1;
+    bflag[p] = ((p - run_first[run]) % AM_MB) == 0 ? 1 : 0;
+}
+__global__ void k_bt_fill(const int4* __restrict__ rec, const int32_t* __restrict__ start, const int32_t* __restrict__ scan,
+                          const int32_t* __restrict__ run_first, const int32_t* __restrict__ bflag, const int32_t* __restrict__ bscan,
+                          int32_t n, int32_t* __restrict__ bt) {
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || !bflag[p]) return;
+    const int32_t run = scan[p] + start[p] - 1;
+    const int32_t mb = min(AM_MB, run_first[run + 1] - p);
+    const int4 h = rec[p];
+    int32_t* d = bt + (int64_t)bscan[p] * BT_W;
+    d[0] = h.y;
+    d[1] = h.z & ((1 << 20) - 1);
+    d[2] = mb;
+    d[3] = h.x;
+    for (int j = 0; j < AM_MB; ++j) d[4 + j] = j < mb ? rec[p + j].w : h.w;
+}
 
 // Warp-specialised form of the same batched product (round 4; option "apply_kind" 7 -- NOT the default: measured slower).
 // A workgroup of EIGHT waves, one per CU, persistent over up to 1024 places: waves 0-3 multiply -- wave w owns row tile w of the
@@ -1697,6 +1916,8 @@ int schwarz_setup(fedd_ctx* c) {
     // several ranks and option "halo_overlap" the subdomains without ghost dofs first ----
     c->sw_nint = -1;
     c->sw_nconf = 0;
+    c->sw_nbatch = 0;
+    c->sw_nbatch_int = 0;
     {
         const bool split = c->halo_overlap && restricted && (c->n_cols != c->n_rows || !c->halo.peers.empty());
         if (c->sw_dedupe || split) {
@@ -1733,6 +1954,39 @@ int schwarz_setup(fedd_ctx* c) {
             FEDD_HIP(hipStreamSynchronize(c->stream));
             if (split) c->sw_nint = h[0];
             c->sw_nconf = h[1];
+            // batch table of k_apply_bt: when every subdomain conforms (structured meshes) and the inverses are shared
+            c->sw_nbatch = 0;
+            c->sw_nbatch_int = 0;
+            if (c->sw_dedupe && restricted && c->sw_nconf == nsub && nsub > 0 && c->apply_bt) {
+                const int4* rec = (const int4*)(ord + 4 * nsub);
+                FEDD_TRY(c->d_sw_btw.ensure((size_t)(5 * nsub + 8)));
+                int32_t* start = c->d_sw_btw.p;
+                int32_t* scan = start + nsub;
+                int32_t* run_first = scan + nsub;       // [nsub + 1]
+                int32_t* bflag = run_first + nsub + 1;
+                int32_t* bscan = bflag + nsub;
+                const int32_t p_cut = split ? (int32_t)c->sw_nint : -1;
+                hipLaunchKernelGGL(k_bt_flag, gs, blk, 0, c->stream, rec, (int32_t)nsub, p_cut, start);
+                int64_t nruns = 0, nbatch = 0;
+                FEDD_TRY(exclusive_scan_i32(c, start, scan, nsub, &nruns));
+                hipLaunchKernelGGL(k_bt_run_first, gs, blk, 0, c->stream, (const int32_t*)start, (const int32_t*)scan, (int32_t)nsub,
+                                   (int32_t)nruns, run_first);
+                hipLaunchKernelGGL(k_bt_batch_flag, gs, blk, 0, c->stream, (const int32_t*)start, (const int32_t*)scan,
+                                   (const int32_t*)run_first, (int32_t)nsub, bflag);
+                FEDD_TRY(exclusive_scan_i32(c, bflag, bscan, nsub, &nbatch));
+                FEDD_TRY(c->d_sw_bt.ensure((size_t)(nbatch * BT_W + 8)));
+                hipLaunchKernelGGL(k_bt_fill, gs, blk, 0, c->stream, rec, (const int32_t*)start, (const int32_t*)scan,
+                                   (const int32_t*)run_first, (const int32_t*)bflag, (const int32_t*)bscan, (int32_t)nsub, c->d_sw_bt.p);
+                c->sw_nbatch = nbatch;
+                if (split && c->sw_nint > 0 && c->sw_nint < nsub) {
+                    int32_t hb = 0;
+                    FEDD_HIP(hipMemcpyAsync(&hb, bscan + c->sw_nint, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+                    FEDD_HIP(hipStreamSynchronize(c->stream));
+                    c->sw_nbatch_int = hb;
+                } else if (split) {
+                    c->sw_nbatch_int = c->sw_nint >= nsub ? nbatch : 0;
+                }
+            }
         }
     }
     // ---- slab offsets ----
@@ -1870,10 +2124,33 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
                                              : (count >= 256 * 1024 ? 128 : (count >= 128 * 1024 ? 96 : (count >= 48 * 1024 ? 64 : 32)));
                 span = std::max(16, (span + 15) / 16 * 16);     // whole 16-place batches
                 const int nwg = (int)((count + span - 1) / span);
+                // the batch table (every subdomain conforms; "apply_kind" 6 keeps the chunk-record kernel): the places [p0, p0 +
+                // count) are the batches [bt0, bt0 + btn) -- the table was cut at the split of the order
+                const bool use_bt = c->sw_nbatch > 0 && c->apply_kind != 6 && c->apply_kind != 7 && c->apply_dbg <= 0 &&
+                                    (p0 == 0 || p0 == c->sw_nint);
+                const int64_t bt0 = p0 == 0 ? 0 : c->sw_nbatch_int;
+                const int64_t btn = (p0 == 0 && count == c->sw_nsub) ? c->sw_nbatch
+                                                                     : (p0 == 0 ? c->sw_nbatch_int : c->sw_nbatch - c->sw_nbatch_int);
+                // one round of workgroups: the loop over the batches is the whole kernel (prologue 2 %), so every slot of the
+                // chip -- 256 CUs x the workgroups the kernel's registers allow on one -- takes an equal share of the batches
+                // (214^3 cells, 64-node boxes, 10 417 batches: 6 per workgroup 129.6 us, 12: 126.8, 21 = one round: 119.9,
+                // 22: 123.8, 25: 136, 32: 162; 107^3 cells, 1 231 batches: 2: 30.1 us, 3 = one round: 25.1, 4: 33.6)
+                const int occ_bt = c->sw_max_own <= 32 ? 3 : 2;      // (by the registers of the instantiations below: 134 / 153 and 179 ... 256)
+                const int bspan = c->apply_span > 0 ? std::max(1, span / AM_MB)
+                                                    : (int)std::max<int64_t>(1, (btn + 256 * occ_bt - 1) / (256 * occ_bt));
+                const int nwg_bt = (int)((btn + bspan - 1) / bspan);
+                if (use_bt && btn <= 0) return;
 #define APPLY_MFMA(RT, KW)                                                                                                   \
-    hipLaunchKernelGGL((k_apply_mfma<RT, KW>), dim3((unsigned)nwg), blk, 0, c->stream, records + p0,                          \
-                       (const int32_t*)c->d_sub_dofs.p, (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r,         \
-                       d_z_owned, (int32_t)count, span)
+    do {                                                                                                                     \
+        if (use_bt)                                                                                                          \
+            hipLaunchKernelGGL((k_apply_bt<RT, KW>), dim3((unsigned)nwg_bt), blk, 0, c->stream,                               \
+                               (const int32_t*)c->d_sw_bt.p + (int64_t)bt0 * BT_W, (const int32_t*)c->d_sub_dofs.p,          \
+                               (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned, (int32_t)btn, bspan); \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((k_apply_mfma<RT, KW>), dim3((unsigned)nwg), blk, 0, c->stream, records + p0,                  \
+                               (const int32_t*)c->d_sub_dofs.p, (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, \
+                               d_z_owned, (int32_t)count, span);                                                             \
+    } while (0)
                 // (row tiles, column steps per wave) by the largest subdomain: fewer steps = fewer registers = more waves
                 const int64_t mx = c->sw_max_size;
                 // 33 ... 64 owned rows: the row tiles split over the waves, B through LDS (k_apply_ms); "apply_kind" 6 = K-split
@@ -1900,7 +2177,23 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
                     else APPLY_MFMA(2, 16);
                 } else if (c->sw_max_own <= 64) {
                     if (mx <= 160) APPLY_MFMA(4, 10);
-                    else if (mx <= 192) APPLY_MFMA(4, 12);
+                    else if (mx <= 192 && c->apply_dbg > 0) {
+#define APPLY_ABL(A)                                                                                                          \
+    case A:                                                                                                                  \
+        hipLaunchKernelGGL((k_apply_mfma<4, 12, A>), dim3((unsigned)nwg), blk, 0, c->stream, records + p0,                    \
+                           (const int32_t*)c->d_sub_dofs.p, (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r,     \
+                           d_z_owned, (int32_t)count, span);                                                                 \
+        break;
+                        switch (c->apply_dbg) {     // (development: what bounds the kernel; results are wrong by design)
+                            APPLY_ABL(1) APPLY_ABL(3) APPLY_ABL(4) APPLY_ABL(7) APPLY_ABL(23) APPLY_ABL(32) APPLY_ABL(39) APPLY_ABL(55)
+                            default: break;
+                        }
+#undef APPLY_ABL
+                    } else if (mx <= 192 && use_bt && c->apply_dbg == -1) {     // (development: phase clocks of one wave)
+                        hipLaunchKernelGGL((k_apply_bt<4, 12, true>), dim3((unsigned)nwg_bt), blk, 0, c->stream,
+                                           (const int32_t*)c->d_sw_bt.p + (int64_t)bt0 * BT_W, (const int32_t*)c->d_sub_dofs.p,
+                                           (const int64_t*)c->d_inv_ptr.p, (const double*)c->d_inv.p, r, d_z_owned, (int32_t)btn, bspan);
+                    } else if (mx <= 192) APPLY_MFMA(4, 12);
                     else APPLY_MFMA(4, 16);
                 } else {
                     APPLY_MFMA(6, 16);
