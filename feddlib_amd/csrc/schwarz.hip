@@ -1262,7 +1262,6 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
                                                     const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
                                                     const double* __restrict__ r, double* __restrict__ z, int32_t nbatch, int bspan) {
     __shared__ double part[4][RT][4][64];
-    __shared__ int32_t soff[16 * KW];       // dof offsets of a representative's list (entries beyond the list: 0)
     long long t_begin = 0, t_loop = 0;
     int n_reload = 0;
     if (DBG) t_begin = __builtin_readcyclecounter();
@@ -1284,33 +1283,43 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         a0n = bt[(int64_t)(b + 1) * BT_W + 4 + lj];
     }
     int32_t so_rep = -1, cur = -1;
-    // (all lanes; the caller puts a barrier behind it)
-    auto write_offsets = [&](int32_t rp_, int n_) {
+    // byte offsets of the representative's dof list in registers: this lane's KW columns (entries beyond the list: 0 -- they
+    // meet zeros of A) and its RT output rows.  With 32-bit byte offsets on a uniform base the gathers and the stores are one
+    // integer add each (r and z are far below 4 GB: 32-bit dof ids)
+    uint32_t so_c[KW], so_o[RT];
+    auto load_offsets = [&](int32_t rp_, int n_, int nrow_) {
         const int32_t* __restrict__ ref = sub_dofs + (int64_t)rp_ * NMAX;
         const int32_t r0 = ref[0];
-        if (tid < 16 * KW) soff[tid] = ref[tid < n_ ? tid : 0] - r0;
-        so_rep = rp_;
-    };
-    // the rows this lane writes at the end: result register w of tile t = row 16 t + lk + 4 w of subdomain lj
-    auto out_rows = [&](const int4& hh, int32_t a0_, int32_t (&o)[RT]) {
-        const int32_t pk = __builtin_amdgcn_readfirstlane(hh.y), mb_ = __builtin_amdgcn_readfirstlane(hh.z);
-        const int nrow_ = (pk >> 10) & 1023;
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) {
+            const int c = 4 * (w + 4 * kk) + lk;
+            so_c[kk] = (uint32_t)(ref[c < n_ ? c : 0] - r0) * 8u;
+        }
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             const int i = 16 * t + lk + 4 * w;
-            const int32_t so = soff[i < 16 * KW ? i : 0];
-            o[t] = (lj < mb_ && i < nrow_) ? a0_ + so : -1;
+            so_o[t] = (uint32_t)(ref[i < nrow_ ? i : 0] - r0) * 8u;
         }
+        so_rep = rp_;
+    };
+    const char* __restrict__ rb = reinterpret_cast<const char*>(r);
+    char* __restrict__ zb = reinterpret_cast<char*>(z);
+    constexpr uint32_t NO_ROW = 0xffffffffu;
+    // the rows this lane writes at the end: result register w of tile t = row 16 t + lk + 4 w of subdomain lj
+    auto out_rows = [&](const int4& hh, int32_t a0_, uint32_t (&o)[RT]) {
+        const int32_t pk = __builtin_amdgcn_readfirstlane(hh.y), mb_ = __builtin_amdgcn_readfirstlane(hh.z);
+        const int nrow_ = (pk >> 10) & 1023;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) o[t] = (lj < mb_ && 16 * t + lk + 4 * w < nrow_) ? (uint32_t)a0_ * 8u + so_o[t] : NO_ROW;
     };
     double a[RT][KW], bv[KW];
-    int32_t od[RT], odn[RT];
+    uint32_t od[RT], odn[RT];
     {
         const int32_t pk = __builtin_amdgcn_readfirstlane(h.y);
-        write_offsets(__builtin_amdgcn_readfirstlane(h.x), pk & 1023);
-        __syncthreads();
+        load_offsets(__builtin_amdgcn_readfirstlane(h.x), pk & 1023, (pk >> 10) & 1023);
         // B fragments: lane (k, j) = entry 4 step + k of subdomain j's restriction of r
 #pragma unroll
-        for (int kk = 0; kk < KW; ++kk) bv[kk] = r[a0 + soff[4 * (w + 4 * kk) + lk]];
+        for (int kk = 0; kk < KW; ++kk) bv[kk] = *reinterpret_cast<const double*>(rb + ((uint32_t)a0 * 8u + so_c[kk]));
         out_rows(h, a0, od);
     }
     long long tk[6] = {0, 0, 0, 0, 0, 0};
@@ -1347,13 +1356,15 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         const bool more = b + 1 < b_end;    // (uniform)
         int4 h2 = make_int4(-1, 0, 0, 0);
         int32_t a02 = 0;
+        uint32_t a0n8 = 0;
         if (more) {
             const int32_t rpn = __builtin_amdgcn_readfirstlane(hn.x);
             if (rpn != so_rep) {    // (uniform, rare) the next batch has another representative: its offsets
-                write_offsets(rpn, __builtin_amdgcn_readfirstlane(hn.y) & 1023);
-                __syncthreads();
+                const int32_t pkn = __builtin_amdgcn_readfirstlane(hn.y);
+                load_offsets(rpn, pkn & 1023, (pkn >> 10) & 1023);
             }
             out_rows(hn, a0n, odn);
+            a0n8 = (uint32_t)a0n * 8u;
             if (b + 2 < b_end) {
                 h2 = bt4[(int64_t)(b + 2) * (BT_W / 4)];
                 a02 = bt[(int64_t)(b + 2) * BT_W + 4 + lj];
@@ -1365,14 +1376,16 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         for (int t = 0; t < RT; ++t) acc[t] = ap_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk) {
-            if (4 * (w + 4 * kk) < n) {     // (scalar)
+            // (scalar; only the last steps can lie beyond the list of a box that fills the kernel's shape, and a step beyond
+            // it multiplies zeros of A -- the same bits with or without it --, so the first steps carry no test)
+            if (kk + 2 < KW || 4 * (w + 4 * kk) < n) {
 #pragma unroll
                 for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][kk], bv[kk], acc[t], 0, 0, 0);
             }
             // this step's fragment is spent: the next batch's entry of r takes its place and flies while the remaining steps are
             // multiplied and the partial tiles exchanged and stored (unconditional: columns beyond the list read the first dof
             // against entries of A that are zero)
-            if (more) bv[kk] = r[a0n + soff[4 * (w + 4 * kk) + lk]];
+            if (more) bv[kk] = *reinterpret_cast<const double*>(rb + (a0n8 + so_c[kk]));
         }
 #pragma unroll
         for (int t = 0; t < RT; ++t)
@@ -1383,7 +1396,8 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         if (DBG) t3 = __builtin_readcyclecounter();
 #pragma unroll
         for (int t = 0; t < RT; ++t)
-            if (od[t] >= 0) z[od[t]] = ((part[0][t][w][lane] + part[1][t][w][lane]) + part[2][t][w][lane]) + part[3][t][w][lane];
+            if (od[t] != NO_ROW)
+                *reinterpret_cast<double*>(zb + od[t]) = ((part[0][t][w][lane] + part[1][t][w][lane]) + part[2][t][w][lane]) + part[3][t][w][lane];
         if (DBG) {
             t4 = __builtin_readcyclecounter();
             tk[0] += t1 - t0;
