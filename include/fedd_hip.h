@@ -359,10 +359,15 @@ int fedd_gmres_fused_blocks(fedd_ctx* ctx, int* blocks);
  * the scalar forms), 1 = lane-per-row gather, 2 = slot sweep always, 3 = slot-addressed always; "asm_u" pairs per lane whose
  * loads are in flight together in the slot-addressed kernel (P1; default 1); "asm_dbg" ablation switches (development); "apply_kind" 0 = restricted Schwarz
  * apply by the setup's outcome (batched matrix-core kernel when at most a quarter of at least 4096 subdomains have distinct
- * local matrices, else the flat streaming kernel), 1 = strided, 2 = flat without the compact LDS layout, 4 = matrix-core
- * kernel whenever the inverses are shared (any number of subdomains), 7 = the warp-specialised form of that kernel (four waves
- * multiply, four gather r three batches ahead; 33 ... 64 owned rows per subdomain; measured slower, kept for A/B); "apply_span" places per workgroup of that kernel
- * (multiples of 16; 0 = 32 / 64 / 96 / 128 by the number of subdomains); "md2_gy" column groups in flight per row block of the
+ * local matrices -- on the batch table of the setup, k_apply_bt, when every subdomain conforms to its representative, on chunk
+ * records, k_apply_mfma, otherwise --, else the flat streaming kernel), 1 = strided, 2 = flat without the compact LDS layout,
+ * 4 = matrix-core kernel whenever the inverses are shared (any number of subdomains), 6 = the chunk-record kernel k_apply_mfma
+ * also where the batch table exists (A/B; same bits), 7 = the warp-specialised form of that kernel (four waves
+ * multiply, four gather r three batches ahead; 33 ... 64 owned rows per subdomain; measured slower, kept for A/B); "apply_bt" 1
+ * (default) = the setup builds the batch table (0: never); "apply_span" places per workgroup of the matrix-core kernels
+ * (multiples of 16; 0 = one round of workgroups with the batch table, 32 / 64 / 96 / 128 by the number of subdomains without);
+ * "apply_dbg" > 0 ablation bits of k_apply_mfma<4, 12> (development: wrong results by design), -1 = phase clocks of one wave of
+ * k_apply_bt<4, 12> printed by the kernel (tools/apply_phases.py); "md2_gy" column groups in flight per row block of the
  * Gram-Schmidt dot sweep (0 = by vector length), "md2_nch" its 512-row chunks per workgroup (2 or 4; default 4);
  * "gmres_hostwrite" 1 (default) = the solver's small kernel writes the three numbers of the host's lagged convergence test
  * into mapped pinned memory itself, 0 = an asynchronous copy per iteration;
