@@ -1276,12 +1276,12 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
     const int4* __restrict__ bt4 = reinterpret_cast<const int4*>(bt);
     int4 h = bt4[(int64_t)b * (BT_W / 4)];
     int32_t a0 = bt[(int64_t)b * BT_W + 4 + lj];
-    int4 hn = make_int4(-1, 0, 0, 0);
-    int32_t a0n = 0;
-    if (b + 1 < b_end) {
-        hn = bt4[(int64_t)(b + 1) * (BT_W / 4)];
-        a0n = bt[(int64_t)(b + 1) * BT_W + 4 + lj];
-    }
+    // (descriptors are read two batches ahead; past the end of the range the last one again: every load of the loop is issued
+    // in every trip -- behind a branch the compiler's count of the loads in flight goes down by one per branch, and the last
+    // product steps then waited for gathers issued a few hundred cycles before them)
+    const int32_t bn_ = min(b + 1, b_end - 1);
+    int4 hn = bt4[(int64_t)bn_ * (BT_W / 4)];
+    int32_t a0n = bt[(int64_t)bn_ * BT_W + 4 + lj];
     int32_t so_rep = -1, cur = -1;
     // byte offsets of the representative's dof list in registers: this lane's KW columns (entries beyond the list: 0 -- they
     // meet zeros of A) and its RT output rows.  With 32-bit byte offsets on a uniform base the gathers and the stores are one
@@ -1353,23 +1353,19 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
             cur = rp;
             if (DBG) ++n_reload;
         }
-        const bool more = b + 1 < b_end;    // (uniform)
-        int4 h2 = make_int4(-1, 0, 0, 0);
-        int32_t a02 = 0;
-        uint32_t a0n8 = 0;
-        if (more) {
+        const bool more = b + 1 < b_end;    // (uniform; the last trip prepares its own batch once more and drops it)
+        {
             const int32_t rpn = __builtin_amdgcn_readfirstlane(hn.x);
             if (rpn != so_rep) {    // (uniform, rare) the next batch has another representative: its offsets
                 const int32_t pkn = __builtin_amdgcn_readfirstlane(hn.y);
                 load_offsets(rpn, pkn & 1023, (pkn >> 10) & 1023);
             }
-            out_rows(hn, a0n, odn);
-            a0n8 = (uint32_t)a0n * 8u;
-            if (b + 2 < b_end) {
-                h2 = bt4[(int64_t)(b + 2) * (BT_W / 4)];
-                a02 = bt[(int64_t)(b + 2) * BT_W + 4 + lj];
-            }
         }
+        out_rows(hn, a0n, odn);
+        const uint32_t a0n8 = (uint32_t)a0n * 8u;
+        const int32_t b2_ = min(b + 2, b_end - 1);
+        const int4 h2 = bt4[(int64_t)b2_ * (BT_W / 4)];
+        const int32_t a02 = bt[(int64_t)b2_ * BT_W + 4 + lj];
         if (DBG) t1 = __builtin_readcyclecounter();
         ap_d4 acc[RT];
 #pragma unroll
@@ -1385,7 +1381,7 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
             // this step's fragment is spent: the next batch's entry of r takes its place and flies while the remaining steps are
             // multiplied and the partial tiles exchanged and stored (unconditional: columns beyond the list read the first dof
             // against entries of A that are zero)
-            if (more) bv[kk] = *reinterpret_cast<const double*>(rb + (a0n8 + so_c[kk]));
+            bv[kk] = *reinterpret_cast<const double*>(rb + (a0n8 + so_c[kk]));
         }
 #pragma unroll
         for (int t = 0; t < RT; ++t)
@@ -1394,10 +1390,13 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         if (DBG) t2 = __builtin_readcyclecounter();
         __syncthreads();
         if (DBG) t3 = __builtin_readcyclecounter();
+        double zs[RT];      // (all sums first: behind the predicate each tile's LDS reads and adds waited for the one before)
 #pragma unroll
         for (int t = 0; t < RT; ++t)
-            if (od[t] != NO_ROW)
-                *reinterpret_cast<double*>(zb + od[t]) = ((part[0][t][w][lane] + part[1][t][w][lane]) + part[2][t][w][lane]) + part[3][t][w][lane];
+            zs[t] = ((part[0][t][w][lane] + part[1][t][w][lane]) + part[2][t][w][lane]) + part[3][t][w][lane];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+            if (od[t] != NO_ROW) *reinterpret_cast<double*>(zb + od[t]) = zs[t];
         if (DBG) {
             t4 = __builtin_readcyclecounter();
             tk[0] += t1 - t0;
@@ -1414,7 +1413,7 @@ __global__ __launch_bounds__(256, (RT <= 2 && KW <= 10) ? 3 : ((RT <= 4 && KW <=
         hn = h2;
         a0n = a02;
         ++b;
-        __syncthreads();    // part is rewritten by the next batch
+        __syncthreads();    // part is rewritten by the next batch (two buffers and one barrier per batch: measured, no gain)
         if (DBG) tk[4] += __builtin_readcyclecounter() - t4;
     }
     if (DBG && tid == 0 && (blockIdx.x % 31 == 0 || blockIdx.x + 8 >= gridDim.x)) {
@@ -2125,7 +2124,7 @@ int schwarz_apply(fedd_ctx* c, const double* d_r_owned, double* d_z_owned, bool 
         // most subdomains share their inverse (schwarz_dedupe found few distinct local matrices): matrix-core kernel
         // (a few thousand subdomains: their slabs stay in the caches and the flat kernel's shorter dependency chain wins)
         const bool shared = c->sw_dedupe && c->sw_nrep * 4 <= c->sw_nsub && c->sw_max_own <= 96 && c->apply_kind != 2 && c->apply_kind != 1 &&
-                            (c->sw_nsub >= 4096 || c->apply_kind == 4);
+                            (c->sw_nsub >= 4096 || c->apply_kind == 4 || c->apply_kind == 6);
         const int4* records = c->d_sw_order.p ? (const int4*)(c->d_sw_order.p + c->sw_order_off) : nullptr;
         // places [p0, p0 + count) of the order records (all subdomains: p0 = 0, count = sw_nsub)
         auto launch_range = [&](int64_t p0, int64_t count, bool permuted) {

@@ -361,8 +361,8 @@ int fedd_gmres_fused_blocks(fedd_ctx* ctx, int* blocks);
  * apply by the setup's outcome (batched matrix-core kernel when at most a quarter of at least 4096 subdomains have distinct
  * local matrices -- on the batch table of the setup, k_apply_bt, when every subdomain conforms to its representative, on chunk
  * records, k_apply_mfma, otherwise --, else the flat streaming kernel), 1 = strided, 2 = flat without the compact LDS layout,
- * 4 = matrix-core kernel whenever the inverses are shared (any number of subdomains), 6 = the chunk-record kernel k_apply_mfma
- * also where the batch table exists (A/B; same bits), 7 = the warp-specialised form of that kernel (four waves
+ * 4 = matrix-core kernel whenever the inverses are shared (any number of subdomains), 6 = as 4, with the chunk-record kernel
+ * k_apply_mfma also where the batch table exists (A/B and tests; same bits), 7 = the warp-specialised form of that kernel (four waves
  * multiply, four gather r three batches ahead; 33 ... 64 owned rows per subdomain; measured slower, kept for A/B); "apply_bt" 1
  * (default) = the setup builds the batch table (0: never); "apply_span" places per workgroup of the matrix-core kernels
  * (multiples of 16; 0 = one round of workgroups with the batch table, 32 / 64 / 96 / 128 by the number of subdomains without);

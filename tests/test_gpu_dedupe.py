@@ -74,6 +74,11 @@ def test_shared_inverses_give_the_oracle_operator(fedd_lib, ctx, kind, dim, M, t
     scale = np.abs(z0).max()
     np.testing.assert_allclose(z1, z0, rtol=0, atol=1e-11 * scale)
     assert np.array_equal(ctx.schwarz_apply(r), z1)            # fixed summation order
+    # the batch-table kernel (k_apply_bt: what kind 4 runs when every box conforms to its representative) and the chunk-record
+    # kernel (k_apply_mfma, kind 6) form the same products in the same order: the same bits
+    ctx.set_option("apply_kind", 6)
+    assert np.array_equal(ctx.schwarz_apply(r), z1)
+    ctx.set_option("apply_kind", 4)
     # ... and the oracle's operator (when the lattice was not refined, whose rule the oracle shares only for Laplace)
     node_bin, nb, _ = fo.schwarz_bins(m["xyz"], target)
     if nb == info["n_subdomains"]:
