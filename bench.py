@@ -784,6 +784,14 @@ def main():
         if read_ceiling:
             roofline["measured_read_ceiling_GBs"] = read_ceiling
             roofline["frac_of_measured_ceiling"] = d["GBs"] / read_ceiling
+        if "schwarz_apply" in kern and info.get("sum_sizes") and info.get("sum_owned"):
+            # the apply's own roof is the f64 matrix rate (below), whichever class is the dominant one: its entry carries the figures.
+            # 78.6 TFLOP/s is the spec; bare loops of the instruction sustain 66-74 on this chip (tools/microbench/mfma_f64.hip,
+            # profiles/r04_mfma_f64_microbench.txt)
+            fl = 2.0 * info["sum_sizes"] * info["sum_owned"] / max(info["n_subdomains"], 1)
+            tf_ = fl / (kern["schwarz_apply"]["ms_per_launch"] * 1e-3) / 1e12
+            kern["schwarz_apply"].update({"algorithmic_flops": fl, "TFLOPs": tf_, "frac_f64_matrix_peak": tf_ / MFMA_F64_PEAK_TFLOPS,
+                                          "f64_matrix_rate_sustained_by_the_bare_instruction_TFLOPs": [66.0, 74.0]})
         if dominant == "schwarz_apply" and info.get("sum_sizes") and info.get("sum_owned"):
             # the Schwarz apply multiplies every subdomain's restriction of r with its (shared, cache-resident) inverse on the f64
             # matrix cores: 2 n_i rows_i flops per subdomain (boxes of one size: sum n_i x mean rows) against inverse + r + z bytes.
